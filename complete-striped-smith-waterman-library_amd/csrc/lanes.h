@@ -1,0 +1,65 @@
+/*
+ * lanes.h -- the per-lane primitives the kernels are written in.
+ *
+ * gfx950 view: a 64-lane wavefront is four DPP "rows" of 16 lanes.  One row is
+ * one systolic chain: lane i owns a block of consecutive query rows, and each
+ * step hands H/F/column-max to lane i+1 with row_shr / row_ror DPP moves.  Scores
+ * are two signed 16-bit values packed in a 32-bit VGPR (two queries per chain)
+ * and use the packed saturating VOP3P instructions (v_pk_add_i16 clamp,
+ * v_pk_sub_u16 clamp, v_pk_max_i16) -- gfx950 has no packed 8-bit arithmetic.
+ *
+ * When SSW_SIMT_EMU is defined (tests/emu only) the same names are provided by a
+ * fibre-based SIMT emulator so that the very same kernel source can be executed
+ * and checked on a machine without a GPU.  The product library never defines it.
+ */
+#ifndef SSW_LANES_H
+#define SSW_LANES_H
+
+#include <stdint.h>
+
+typedef uint32_t u32;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef SSW_SIMT_EMU
+#include "simt_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define SSW_DEV __device__ __forceinline__
+#define SSW_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+
+/* DPP controls (ISA encodings): row_shr:n = 0x110+n, row_ror:n = 0x120+n */
+SSW_DEV u32 xl_row_shr1_zero(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
+SSW_DEV u32 xl_row_shr1_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x111, 0xf, 0xf, false); }
+template <int N> SSW_DEV u32 xl_row_ror(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xf, 0xf, false); }
+SSW_DEV u32 xl_shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 64); }
+SSW_DEV bool wave_any(bool p) { return __any(p) != 0; }
+SSW_DEV bool wave_all(bool p) { return __all(p) != 0; }
+SSW_DEV void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+
+/* LDS accessors with byte offsets into the dynamic segment */
+SSW_DEV u32x4 lds_ld128(const unsigned char* lds, u32 off) { return *(const u32x4*)(lds + off); }
+SSW_DEV u32 lds_ld32(const unsigned char* lds, u32 off) { return *(const u32*)(lds + off); }
+SSW_DEV u32 lds_ld16(const unsigned char* lds, u32 off) { return *(const uint16_t*)(lds + off); }
+SSW_DEV void lds_st32(unsigned char* lds, u32 off, u32 v) { *(u32*)(lds + off) = v; }
+SSW_DEV void lds_st16(unsigned char* lds, u32 off, u32 v) { *(uint16_t*)(lds + off) = (uint16_t)v; }
+#endif
+
+/* packed 2 x int16 arithmetic (identical source for device and emulation) */
+SSW_DEV u32 pk_adds(u32 a, u32 b)   /* v_pk_add_i16 clamp: signed saturating add */
+{
+	return __builtin_bit_cast(u32, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+SSW_DEV u32 pk_subu(u32 a, u32 b)   /* v_pk_sub_u16 clamp: unsigned saturating subtract */
+{
+	return __builtin_bit_cast(u32, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+SSW_DEV u32 pk_max(u32 a, u32 b)    /* v_pk_max_i16 */
+{
+	return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+SSW_DEV u32 pk_dup(int v) { return ((u32)v & 0xffffu) * 0x10001u; }
+SSW_DEV u32 pk_make(int lo, int hi) { return ((u32)lo & 0xffffu) | ((u32)hi << 16); }
+
+#endif /* SSW_LANES_H */

@@ -1,0 +1,147 @@
+/*
+ * ssw_dev.h -- plain-C structures shared by the C host driver (ssw_host.c) and the HIP
+ * kernels (ssw_kernels.hip), plus the thin C shim through which the host reaches HIP.
+ * Everything here is POD with fixed-width fields.
+ */
+#ifndef SSW_DEV_H
+#define SSW_DEV_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSW_RMAX 24            /* rows per lane supported by the 16-lane chains: queries up to 16*24 = 384 residues */
+#define SSW_MAX_N 32           /* alphabet size limit (profile residues held in LDS) */
+
+/* two queries that share one systolic chain (low / high 16-bit half of every VGPR) */
+typedef struct {
+	int32_t qa;   /* query index of the low half */
+	int32_t qb;   /* query index of the high half, -1: none */
+} ssw_pair;
+
+/* per-(query, current target) device record; filled phase by phase */
+typedef struct {
+	int32_t score1, score2;
+	int32_t ref_begin1, ref_end1, read_begin1, read_end1, ref_end2;
+	int32_t cigarLen;
+	int32_t flag;        /* s_align.flag */
+	int32_t status;      /* 0 ok; 1 the reference returns NULL (8-bit overflow, no 16-bit semantics enabled) */
+	int32_t word;        /* 1: decided under 16-bit rules */
+	int32_t want_begin;  /* phases still to run for this alignment (set by the reduce kernel) */
+	int32_t want_cigar;
+	int32_t rev_score;   /* best score seen by the reverse pass */
+	int64_t cigar_off;   /* word offset of this alignment's CIGAR in the device CIGAR pool */
+} ssw_dres;
+
+/* forward fill: column maxima of every (pair, tile) of one target */
+typedef struct {
+	const int8_t* tgt;       /* codes of the target */
+	int32_t refLen;
+	const int8_t* qcodes;    /* all query codes */
+	const int64_t* qoff;     /* query offsets */
+	const ssw_pair* pairs;   /* pairs of this launch */
+	int32_t npairs;
+	const int8_t* mat;
+	int32_t n;
+	uint32_t gapO2, gapE2;   /* gap penalties replicated in both 16-bit halves */
+	int32_t tile;            /* columns per tile (multiple of 16) */
+	int32_t halo;            /* columns recomputed ahead of a tile so that its state is exact */
+	int32_t ntiles;
+	int32_t bpp;             /* workgroups per pair = ceil(ntiles / 16) */
+	uint32_t* cm16;          /* [npairs][cm_stride]: column max over all 16R rows   (8-bit rules) */
+	uint32_t* cm8;           /* [npairs][cm_stride]: column max over the first 16R-8 rows (16-bit rules, padded queries) */
+	int64_t cm_stride;
+} ssw_fill_args;
+
+/* reduction of the column maxima into score1 / ref_end1 / score2 / ref_end2 */
+typedef struct {
+	const uint32_t* cm16;
+	const uint32_t* cm8;
+	int64_t cm_stride;
+	int32_t refLen;
+	const ssw_pair* pairs;
+	int32_t npairs;
+	const int64_t* qoff;
+	int32_t maskLen;         /* < 0: readLen / 2 */
+	int32_t bias;
+	int32_t score_size;
+	int32_t flag, filters;
+	ssw_dres* res;           /* indexed by query */
+} ssw_reduce_args;
+
+/* locate (read_end1) and reverse (begin position) passes: one 16-lane chain per alignment */
+typedef struct {
+	const int8_t* tgt;
+	int32_t refLen;
+	const int8_t* qcodes;
+	const int64_t* qoff;
+	const int32_t* qlist;    /* queries of this launch */
+	int32_t nq;
+	const int8_t* mat;
+	int32_t n;
+	uint32_t gapO2, gapE2;
+	int32_t gapE;
+	int32_t maxmat;          /* largest matrix entry (halo bound) */
+	int32_t reverse;         /* 0: locate read_end1; 1: reverse pass */
+	int32_t flag, filters, filterd;
+	ssw_dres* res;
+} ssw_capture_args;
+
+/* banded traceback */
+typedef struct {
+	const int8_t* tgt;
+	const int8_t* qcodes;
+	const int64_t* qoff;
+	const int32_t* qlist;
+	int32_t nq;
+	const int8_t* mat;
+	int32_t n;
+	int32_t gapO, gapE;
+	ssw_dres* res;
+	uint8_t* scratch;        /* nq regions of scratch_stride bytes */
+	int64_t scratch_stride;
+	uint32_t* cigar;         /* nq regions of cigar_stride words */
+	int64_t cigar_stride;
+	int32_t* need;           /* per query: 0 done, otherwise bytes of scratch that were needed */
+} ssw_trace_args;
+
+/* compaction of the per-query CIGAR slots into one pool */
+typedef struct {
+	const uint32_t* src;     /* CIGAR slots (res[q].cigar_off indexes into this) */
+	const ssw_dres* res;
+	const int64_t* dst_off;  /* per query: first word in dst */
+	uint32_t* dst;
+	int32_t nq;
+} ssw_gather_args;
+
+/* ---- thin C shim over the HIP runtime + kernel launches (implemented in ssw_kernels.hip) ---- */
+int   ssw_shim_device_count(void);
+int   ssw_shim_set_device(int dev);
+const char* ssw_shim_last_error(void);
+void* ssw_shim_stream_create(void);
+void  ssw_shim_stream_destroy(void* stream);
+int   ssw_shim_stream_sync(void* stream);
+void* ssw_shim_malloc(size_t bytes);
+void  ssw_shim_free(void* p);
+int   ssw_shim_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int   ssw_shim_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int   ssw_shim_memset(void* dst, int value, size_t bytes, void* stream);
+size_t ssw_shim_mem_free_bytes(void);
+void* ssw_shim_event_create(void);
+void  ssw_shim_event_destroy(void* ev);
+int   ssw_shim_event_record(void* ev, void* stream);
+float ssw_shim_event_elapsed_ms(void* start, void* stop);   /* both must have completed */
+
+int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream);
+int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream);
+int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* stream);
+int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);
+int ssw_shim_launch_gather(const ssw_gather_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSW_DEV_H */

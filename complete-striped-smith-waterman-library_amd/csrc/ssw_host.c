@@ -1,0 +1,512 @@
+/*
+ * ssw_host.c -- C host driver of the MI355X-native Smith-Waterman library.
+ *
+ * Implements the ssw.h ABI (ssw_init / ssw_align / init_destroy / align_destroy, replacing reference
+ * src/ssw.c:826-982) and the batch ABI of ssw_gpu.h on top of the HIP kernels, reached only through
+ * the thin shim declared in ssw_dev.h.  There is no CPU implementation of the alignment in this
+ * library: without a device, or for parameters the kernels do not cover, calls fail loudly.
+ *
+ * Batch pipeline per target (all on one HIP stream):
+ *   queries bucketed by R = ceil(readLen/16) and paired  ->  k_fill<R> (column maxima of every tile)
+ *   -> k_reduce (score1, ref_end1, score2, ref_end2, 8/16-bit rule)  -> [flag != 0] k_capture<R> twice
+ *   (read_end1, then begin position)  -> [CIGAR wanted] k_trace  -> records + CIGAR pool to the host.
+ */
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <pthread.h>
+#include "ssw.h"
+#include "ssw_gpu.h"
+#include "ssw_dev.h"
+
+struct _profile {
+	const int8_t* read;    /* borrowed, like the reference (src/ssw.c:842-843) */
+	const int8_t* mat;     /* borrowed */
+	int32_t readLen;
+	int32_t n;
+	int8_t score_size;
+};
+
+typedef struct { void* p; size_t cap; } dbuf;
+
+struct ssw_gpu_ctx {
+	int device;
+	void* stream;
+	char err[512];
+	ssw_gpu_timing tm;
+	dbuf mat, pairs, qlist, res, cm16, cm8, scratch, cigar, need, goff, gpool;
+	void** ev; int nev, capev;          /* event pairs around fill launches */
+	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d;
+	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
+};
+
+struct ssw_gpu_seqs {
+	ssw_gpu_ctx* ctx;
+	int8_t* d_codes;
+	int64_t* d_off;
+	int64_t* h_off;
+	int32_t count;
+	int64_t total;
+};
+
+static char g_open_err[512];
+
+static int fail(ssw_gpu_ctx* c, const char* fmt, const char* detail)
+{
+	char* dst = c ? c->err : g_open_err;
+	snprintf(dst, 512, fmt, detail ? detail : "");
+	return -1;
+}
+
+static void* ensure(ssw_gpu_ctx* c, dbuf* b, size_t bytes)
+{
+	if (b->cap >= bytes && b->p) return b->p;
+	if (b->p) { ssw_shim_stream_sync(c->stream); ssw_shim_free(b->p); b->p = 0; b->cap = 0; }
+	size_t want = bytes + bytes / 8 + 256;
+	b->p = ssw_shim_malloc(want);
+	if (!b->p) { fail(c, "device allocation failed: %s", ssw_shim_last_error()); return 0; }
+	b->cap = want;
+	return b->p;
+}
+
+static void dbuf_free(dbuf* b) { if (b->p) ssw_shim_free(b->p); b->p = 0; b->cap = 0; }
+
+int ssw_gpu_device_count(void) { return ssw_shim_device_count(); }
+
+const char* ssw_gpu_last_error(const ssw_gpu_ctx* ctx) { return ctx ? ctx->err : g_open_err; }
+
+ssw_gpu_ctx* ssw_gpu_open(int device)
+{
+	int n = ssw_shim_device_count();
+	if (n <= 0) { fail(0, "no HIP device available (%s); this library has no CPU path", ssw_shim_last_error()); return 0; }
+	if (device < 0 || device >= n) { fail(0, "device index out of range%s", ""); return 0; }
+	if (ssw_shim_set_device(device)) { fail(0, "hipSetDevice failed: %s", ssw_shim_last_error()); return 0; }
+	ssw_gpu_ctx* c = (ssw_gpu_ctx*)calloc(1, sizeof(*c));
+	c->device = device;
+	c->stream = ssw_shim_stream_create();
+	c->ev_t0 = ssw_shim_event_create(); c->ev_a = ssw_shim_event_create(); c->ev_b = ssw_shim_event_create();
+	c->ev_c = ssw_shim_event_create(); c->ev_d = ssw_shim_event_create();
+	if (!c->stream || !c->ev_t0 || !c->ev_d) { fail(0, "stream/event creation failed: %s", ssw_shim_last_error()); free(c); return 0; }
+	const char* e = getenv("SSW_GPU_CM_BUDGET_MB");
+	c->cm_budget = e ? (size_t)atoll(e) << 20 : (size_t)24 << 30;
+	return c;
+}
+
+void ssw_gpu_close(ssw_gpu_ctx* c)
+{
+	if (!c) return;
+	ssw_shim_set_device(c->device);
+	ssw_shim_stream_sync(c->stream);
+	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
+	dbuf_free(&c->cm8); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool);
+	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
+	free(c->ev);
+	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
+	ssw_shim_event_destroy(c->ev_c); ssw_shim_event_destroy(c->ev_d);
+	ssw_shim_stream_destroy(c->stream);
+	free(c);
+}
+
+ssw_gpu_seqs* ssw_gpu_seqs_upload(ssw_gpu_ctx* c, const int8_t* codes, const int64_t* offsets, int32_t count)
+{
+	if (!c || count < 0 || !offsets) { fail(c, "seqs_upload: bad arguments%s", ""); return 0; }
+	ssw_shim_set_device(c->device);
+	ssw_gpu_seqs* s = (ssw_gpu_seqs*)calloc(1, sizeof(*s));
+	s->ctx = c; s->count = count; s->total = offsets[count] - offsets[0];
+	s->h_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)count + 1));
+	for (int32_t i = 0; i <= count; ++i) s->h_off[i] = offsets[i] - offsets[0];
+	s->d_codes = (int8_t*)ssw_shim_malloc((size_t)s->total + 64);   /* +64: ring prefetch may not run past the end, but keep slack */
+	s->d_off = (int64_t*)ssw_shim_malloc(sizeof(int64_t) * ((size_t)count + 1));
+	if (!s->d_codes || !s->d_off) { fail(c, "device allocation failed: %s", ssw_shim_last_error()); ssw_gpu_seqs_free(s); return 0; }
+	if (ssw_shim_h2d(s->d_codes, codes + offsets[0], (size_t)s->total, c->stream) ||
+	    ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * ((size_t)count + 1), c->stream) ||
+	    ssw_shim_stream_sync(c->stream)) {
+		fail(c, "upload failed: %s", ssw_shim_last_error()); ssw_gpu_seqs_free(s); return 0;
+	}
+	return s;
+}
+
+void ssw_gpu_seqs_free(ssw_gpu_seqs* s)
+{
+	if (!s) return;
+	if (s->ctx) ssw_shim_set_device(s->ctx->device);
+	ssw_shim_free(s->d_codes); ssw_shim_free(s->d_off); free(s->h_off); free(s);
+}
+
+int32_t ssw_gpu_seqs_count(const ssw_gpu_seqs* s) { return s ? s->count : 0; }
+
+int ssw_gpu_last_timing(const ssw_gpu_ctx* c, ssw_gpu_timing* out) { if (!c || !out) return -1; *out = c->tm; return 0; }
+
+/* ------------------------------------------------------------------------------------------------ */
+
+static int32_t halo_for(int32_t P, int32_t maxmat, int32_t gapE)
+{
+	if (gapE <= 0) return 0x3fffffff;
+	int64_t w = (int64_t)P + ((int64_t)P * (maxmat > 0 ? maxmat : 0) + gapE - 1) / gapE + 1;
+	return w > 0x3fffffff ? 0x3fffffff : (int32_t)w;
+}
+
+static void* next_event(ssw_gpu_ctx* c)
+{
+	if (c->nev == c->capev) {
+		int nc = c->capev ? c->capev * 2 : 64;
+		c->ev = (void**)realloc(c->ev, sizeof(void*) * nc);
+		for (int i = c->capev; i < nc; ++i) c->ev[i] = ssw_shim_event_create();
+		c->capev = nc;
+	}
+	return c->ev[c->nev++];
+}
+
+typedef struct { int32_t R; int32_t first_pair, npairs; int32_t first_q, nq; } bucket;
+
+int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
+                        const ssw_gpu_params* prm, ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words)
+{
+	if (!c) return fail(0, "align_batch: NULL context%s", "");
+	if (!Q || !T || !prm || !results || !prm->mat) return fail(c, "align_batch: NULL argument%s", "");
+	if (Q->ctx != c || T->ctx != c) return fail(c, "align_batch: sequences belong to another context%s", "");
+	if (tfirst < 0 || tcount < 0 || tfirst + tcount > T->count) return fail(c, "align_batch: target range out of bounds%s", "");
+	if (prm->n < 1 || prm->n > SSW_MAX_N) return fail(c, "align_batch: alphabet size must be 1..32%s", "");
+	if (prm->score_size < 0 || prm->score_size > 2) return fail(c, "align_batch: score_size must be 0, 1 or 2%s", "");
+	if (prm->gapO <= prm->gapE)
+		return fail(c, "align_batch: unsupported gap penalties: the GPU path requires gap open > gap extension "
+		               "(the reference's result depends on its SIMD stripe layout otherwise)%s", "");
+	ssw_shim_set_device(c->device);
+	if (cigar_pool) *cigar_pool = 0;
+	if (cigar_words) *cigar_words = 0;
+	const int32_t nq = Q->count, n = prm->n;
+	if (nq == 0 || tcount == 0) return 0;
+
+	int32_t bias = 0, maxmat = 0;
+	for (int32_t i = 0; i < n * n; ++i) { if (prm->mat[i] < bias) bias = prm->mat[i]; if (prm->mat[i] > maxmat) maxmat = prm->mat[i]; }
+	bias = (prm->score_size == 0 || prm->score_size == 2) ? -bias : 0;
+
+	/* bucket queries by rows-per-lane, pair neighbours inside a bucket */
+	int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
+	ssw_pair* pairs = (ssw_pair*)malloc(sizeof(ssw_pair) * ((size_t)nq / 2 + SSW_RMAX + 1));
+	int32_t cnt[SSW_RMAX + 2]; memset(cnt, 0, sizeof cnt);
+	int32_t maxlen = 0;
+	for (int32_t q = 0; q < nq; ++q) {
+		int64_t len = Q->h_off[q + 1] - Q->h_off[q];
+		if (len < 1 || len > 16 * SSW_RMAX) {
+			free(order); free(pairs);
+			return fail(c, "align_batch: query length outside 1..384 is not supported by this build%s", "");
+		}
+		if (len > maxlen) maxlen = (int32_t)len;
+		cnt[(len + 15) / 16]++;
+	}
+	bucket bk[SSW_RMAX + 1]; int nb = 0;
+	int32_t start[SSW_RMAX + 2]; int32_t acc = 0;
+	for (int R = 1; R <= SSW_RMAX; ++R) { start[R] = acc; acc += cnt[R]; }
+	{
+		int32_t fillp[SSW_RMAX + 2]; memcpy(fillp, start, sizeof fillp);
+		for (int32_t q = 0; q < nq; ++q) { int R = (int)((Q->h_off[q + 1] - Q->h_off[q] + 15) / 16); order[fillp[R]++] = q; }
+	}
+	int32_t npairs_total = 0;
+	for (int R = 1; R <= SSW_RMAX; ++R) {
+		if (!cnt[R]) continue;
+		bucket b; b.R = R; b.first_q = start[R]; b.nq = cnt[R]; b.first_pair = npairs_total;
+		for (int32_t i = 0; i < cnt[R]; i += 2) {
+			pairs[npairs_total].qa = order[start[R] + i];
+			pairs[npairs_total].qb = i + 1 < cnt[R] ? order[start[R] + i + 1] : -1;
+			++npairs_total;
+		}
+		b.npairs = npairs_total - b.first_pair;
+		bk[nb++] = b;
+	}
+
+	int rc = -1;
+	uint32_t* pool = 0; int64_t pool_words = 0, pool_cap = 0;
+	ssw_dres* hres = (ssw_dres*)malloc(sizeof(ssw_dres) * (size_t)nq);
+	int32_t* hneed = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
+	memset(&c->tm, 0, sizeof c->tm);
+	c->nev = 0;
+
+	int8_t* d_mat = (int8_t*)ensure(c, &c->mat, (size_t)n * n);
+	ssw_pair* d_pairs = (ssw_pair*)ensure(c, &c->pairs, sizeof(ssw_pair) * (size_t)npairs_total);
+	int32_t* d_qlist = (int32_t*)ensure(c, &c->qlist, sizeof(int32_t) * (size_t)nq);
+	ssw_dres* d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq);
+	if (!d_mat || !d_pairs || !d_qlist || !d_res) goto done;
+	ssw_shim_event_record(c->ev_t0, c->stream);
+	if (ssw_shim_h2d(d_mat, prm->mat, (size_t)n * n, c->stream) ||
+	    ssw_shim_h2d(d_pairs, pairs, sizeof(ssw_pair) * (size_t)npairs_total, c->stream) ||
+	    ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nq, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
+
+	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
+	double fill_ms = 0, reduce_ms = 0, locate_ms = 0, trace_ms = 0;
+
+	for (int32_t ti = 0; ti < tcount; ++ti) {
+		const int32_t t = tfirst + ti;
+		const int64_t refLen64 = T->h_off[t + 1] - T->h_off[t];
+		if (refLen64 > 0x7fffff00) { fail(c, "align_batch: target longer than 2^31 is not supported%s", ""); goto done; }
+		const int32_t refLen = (int32_t)refLen64;
+		const int8_t* d_tgt = T->d_codes + T->h_off[t];
+		const int ev_first = c->nev;
+		if (ssw_shim_memset(d_res, 0, sizeof(ssw_dres) * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
+
+		if (refLen > 0) {
+			const int64_t stride = ((int64_t)refLen + 15) / 16 * 16 + 16;
+			for (int b = 0; b < nb; ++b) {
+				const bucket* B = &bk[b];
+				const int32_t P = 16 * B->R, halo_full = halo_for(P, maxmat, prm->gapE);
+				int32_t tile, halo, ntiles;
+				if ((int64_t)halo_full * 8 * 16 >= refLen) { ntiles = 1; tile = (refLen + 15) / 16 * 16; halo = 0; }
+				else {
+					/* multiples of 16 tiles (one workgroup = 16 tiles of one pair); more tiles when few pairs */
+					int64_t want = (4 * 32768 + B->npairs - 1) / B->npairs;
+					int64_t maxt = refLen / ((int64_t)halo_full * 8);
+					if (want > maxt) want = maxt;
+					want = (want + 15) / 16 * 16; if (want < 16) want = 16;
+					tile = (int32_t)(((refLen + want - 1) / want + 15) / 16 * 16);
+					ntiles = (refLen + tile - 1) / tile; halo = halo_full;
+				}
+				int64_t chunk = (int64_t)(c->cm_budget / (size_t)(8 * stride));
+				if (chunk < 1) chunk = 1;
+				if (chunk > B->npairs) chunk = B->npairs;
+				uint32_t* d_cm16 = (uint32_t*)ensure(c, &c->cm16, (size_t)(4 * stride * chunk));
+				uint32_t* d_cm8 = (uint32_t*)ensure(c, &c->cm8, (size_t)(4 * stride * chunk));
+				if (!d_cm16 || !d_cm8) goto done;
+				for (int32_t p0 = 0; p0 < B->npairs; p0 += (int32_t)chunk) {
+					const int32_t np = B->npairs - p0 < chunk ? B->npairs - p0 : (int32_t)chunk;
+					ssw_fill_args fa;
+					fa.tgt = d_tgt; fa.refLen = refLen; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off;
+					fa.pairs = d_pairs + B->first_pair + p0; fa.npairs = np; fa.mat = d_mat; fa.n = n;
+					fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.tile = tile; fa.halo = halo; fa.ntiles = ntiles;
+					fa.bpp = (ntiles + 15) / 16; fa.cm16 = d_cm16; fa.cm8 = d_cm8; fa.cm_stride = stride;
+					void* e0 = next_event(c); void* e1 = next_event(c);
+					ssw_shim_event_record(e0, c->stream);
+					if (ssw_shim_launch_fill(B->R, &fa, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
+					ssw_shim_event_record(e1, c->stream);
+					c->tm.fill_launches++;
+					{
+						int64_t cols = 0;
+						for (int32_t k = 0; k < ntiles; ++k) {
+							int64_t lo = (int64_t)k * tile, hi = lo + tile < refLen ? lo + tile : refLen;
+							int64_t cf = lo - halo > 0 ? lo - halo : 0;
+							cols += hi - cf;
+						}
+						c->tm.fill_cells += cols * P * 2 * np;
+					}
+					ssw_reduce_args ra;
+					ra.cm16 = d_cm16; ra.cm8 = d_cm8; ra.cm_stride = stride; ra.refLen = refLen; ra.pairs = fa.pairs; ra.npairs = np;
+					ra.qoff = Q->d_off; ra.maskLen = prm->maskLen; ra.bias = bias; ra.score_size = prm->score_size;
+					ra.flag = prm->flag; ra.filters = prm->filters; ra.res = d_res;
+					if (ssw_shim_launch_reduce(&ra, c->stream)) { fail(c, "reduce launch failed: %s", ssw_shim_last_error()); goto done; }
+				}
+			}
+		}
+		ssw_shim_event_record(c->ev_a, c->stream);
+
+		if (refLen > 0) {   /* read_end1 always (ssw.c:342-351); begin position only when asked for (ssw.c:916) */
+			for (int pass = 0; pass < (prm->flag != 0 ? 2 : 1); ++pass)
+				for (int b = 0; b < nb; ++b) {
+					const bucket* B = &bk[b];
+					ssw_capture_args ca;
+					ca.tgt = d_tgt; ca.refLen = refLen; ca.qcodes = Q->d_codes; ca.qoff = Q->d_off; ca.qlist = d_qlist + B->first_q;
+					ca.nq = B->nq; ca.mat = d_mat; ca.n = n; ca.gapO2 = gapO2; ca.gapE2 = gapE2; ca.gapE = prm->gapE; ca.maxmat = maxmat;
+					ca.reverse = pass; ca.flag = prm->flag; ca.filters = prm->filters; ca.filterd = prm->filterd; ca.res = d_res;
+					if (ssw_shim_launch_capture(B->R, &ca, c->stream)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
+				}
+		}
+		ssw_shim_event_record(c->ev_b, c->stream);
+
+		int64_t cig_stride = 0;
+		uint32_t* d_cig = 0;
+		int did_trace = 0;
+		if ((prm->flag & 7) != 0 && refLen > 0) {
+			/* one launch over all queries; scratch sized for a band a few doublings wide, grown on demand */
+			const int32_t halo_max = halo_for(16 * bk[nb - 1].R, maxmat, prm->gapE);
+			int64_t span = (int64_t)maxlen + (halo_max < refLen ? halo_max : refLen) + 8;
+			cig_stride = (span + 3) / 4 * 4;
+			d_cig = (uint32_t*)ensure(c, &c->cigar, (size_t)(4 * cig_stride * nq));
+			int32_t* d_need = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * (size_t)nq);
+			if (!d_cig || !d_need) goto done;
+			int64_t sstride = ((int64_t)3 * (2 * 16 + 8) * 4 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;
+			int32_t* list = order; int32_t nlist = nq;      /* `order` already uploaded as d_qlist */
+			int32_t* retry = 0;
+			for (int attempt = 0; attempt < 6 && nlist > 0; ++attempt) {
+				int64_t per_launch = (int64_t)((size_t)16 << 30) / sstride;
+				if (per_launch < 1) { fail(c, "traceback scratch for one alignment exceeds 16 GiB%s", ""); free(retry); goto done; }
+				int32_t* d_list = d_qlist;
+				if (attempt > 0) {
+					if (ssw_shim_h2d(d_qlist, list, sizeof(int32_t) * (size_t)nlist, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); free(retry); goto done; }
+				}
+				int64_t maxneed = 0; int32_t nretry = 0;
+				int32_t* nextlist = (int32_t*)malloc(sizeof(int32_t) * (size_t)nlist);
+				for (int32_t q0 = 0; q0 < nlist; q0 += (int32_t)per_launch) {
+					const int32_t cnt_l = nlist - q0 < per_launch ? nlist - q0 : (int32_t)per_launch;
+					uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)(sstride * cnt_l));
+					if (!d_scr) { free(nextlist); free(retry); goto done; }
+					ssw_trace_args ta;
+					ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_list + q0; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
+					ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = sstride;
+					/* the CIGAR slot of an alignment is addressed by its position in the FIRST list (== position in `order`) */
+					ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need + q0;
+					if (attempt > 0) { ta.cigar = d_cig; }
+					if (ssw_shim_launch_trace(&ta, c->stream) ||
+					    ssw_shim_d2h(hneed + q0, d_need + q0, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
+					    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); free(nextlist); free(retry); goto done; }
+					for (int32_t k = 0; k < cnt_l; ++k)
+						if (hneed[q0 + k] != 0) {
+							if (hneed[q0 + k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); free(nextlist); free(retry); goto done; }
+							if (hneed[q0 + k] > maxneed) maxneed = hneed[q0 + k];
+							nextlist[nretry++] = list[q0 + k];
+						}
+				}
+				did_trace = 1;
+				free(retry); retry = nextlist; list = retry; nlist = nretry;
+				if (nlist > 0) {
+					/* jump straight to the worst case of the remaining alignments' full band */
+					int64_t full = (int64_t)maxlen + (halo_max < refLen ? halo_max : refLen);
+					int64_t worst = (3 * (2 * full + 8) * 4 + (2 * full + 1) * (int64_t)maxlen * 3 + 64 + 15) / 16 * 16;
+					sstride = attempt == 0 && maxneed * 4 < worst ? (maxneed * 4 + 15) / 16 * 16 : worst;
+				}
+			}
+			if (nlist > 0) { fail(c, "internal error: traceback scratch negotiation did not converge%s", ""); free(retry); goto done; }
+			free(retry);
+			if (did_trace && ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nq, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
+		}
+		ssw_shim_event_record(c->ev_c, c->stream);
+
+		if (ssw_shim_d2h(hres, d_res, sizeof(ssw_dres) * (size_t)nq, c->stream) || ssw_shim_stream_sync(c->stream)) {
+			fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
+		}
+		/* CIGARs: pack the used slots into one device pool, one download */
+		int64_t* goffs = 0; int64_t gwords = 0;
+		for (int32_t q = 0; q < nq; ++q) if (hres[q].cigarLen > 0 && hres[q].status == 0) gwords += hres[q].cigarLen;
+		if (gwords > 0) {
+			goffs = (int64_t*)malloc(sizeof(int64_t) * (size_t)nq);
+			int64_t at = 0;
+			for (int32_t q = 0; q < nq; ++q) { goffs[q] = at; if (hres[q].cigarLen > 0 && hres[q].status == 0) at += hres[q].cigarLen; }
+			int64_t* d_goff = (int64_t*)ensure(c, &c->goff, sizeof(int64_t) * (size_t)nq);
+			uint32_t* d_gpool = (uint32_t*)ensure(c, &c->gpool, sizeof(uint32_t) * (size_t)gwords);
+			if (!d_goff || !d_gpool) { free(goffs); goto done; }
+			if (pool_words + gwords > pool_cap) {
+				pool_cap = (pool_words + gwords) * 2 + 1024;
+				pool = (uint32_t*)realloc(pool, sizeof(uint32_t) * (size_t)pool_cap);
+			}
+			ssw_gather_args ga; ga.src = d_cig; ga.res = d_res; ga.dst_off = d_goff; ga.dst = d_gpool; ga.nq = nq;
+			if (ssw_shim_h2d(d_goff, goffs, sizeof(int64_t) * (size_t)nq, c->stream) || ssw_shim_launch_gather(&ga, c->stream) ||
+			    ssw_shim_d2h(pool + pool_words, d_gpool, sizeof(uint32_t) * (size_t)gwords, c->stream)) {
+				fail(c, "CIGAR download failed: %s", ssw_shim_last_error()); free(goffs); goto done;
+			}
+		}
+		for (int32_t q = 0; q < nq; ++q) {
+			const ssw_dres* r = &hres[q];
+			ssw_gpu_result* o = &results[(int64_t)q * tcount + ti];
+			if (r->status >= 2) { fail(c, "internal error: window pass did not reproduce the forward score%s", ""); free(goffs); goto done; }
+			o->score1 = (uint16_t)r->score1; o->score2 = (uint16_t)r->score2;
+			o->ref_begin1 = r->ref_begin1; o->ref_end1 = r->ref_end1; o->read_begin1 = r->read_begin1; o->read_end1 = r->read_end1;
+			o->ref_end2 = r->ref_end2; o->cigarLen = r->cigarLen; o->cigar_off = -1; o->flag = (uint16_t)r->flag; o->status = (uint16_t)r->status;
+			if (r->score1 <= 0 && r->status == 0) { o->ref_begin1 = -1; o->read_begin1 = -1; }
+			if (r->cigarLen > 0 && r->status == 0) o->cigar_off = pool_words + goffs[q];
+			if (r->status == 0 && r->score1 > 0) { if (r->word) c->tm.n_word++; else c->tm.n_byte++; }
+			c->tm.cells += (Q->h_off[q + 1] - Q->h_off[q]) * (int64_t)refLen;
+		}
+		pool_words += gwords;
+		free(goffs);
+		ssw_shim_event_record(c->ev_d, c->stream);
+		if (ssw_shim_stream_sync(c->stream)) { fail(c, "stream sync failed: %s", ssw_shim_last_error()); goto done; }
+		for (int e = ev_first; e + 1 < c->nev; e += 2) fill_ms += ssw_shim_event_elapsed_ms(c->ev[e], c->ev[e + 1]);
+		locate_ms += ssw_shim_event_elapsed_ms(c->ev_a, c->ev_b);
+		trace_ms += ssw_shim_event_elapsed_ms(c->ev_b, c->ev_c);
+		{
+			double span = ssw_shim_event_elapsed_ms(c->ev_t0, c->ev_a);
+			(void)span;
+		}
+	}
+	{
+		double total = ssw_shim_event_elapsed_ms(c->ev_t0, c->ev_d);
+		c->tm.total_ms = total; c->tm.fill_ms = fill_ms; c->tm.locate_ms = locate_ms; c->tm.trace_ms = trace_ms;
+		reduce_ms = total - fill_ms - locate_ms - trace_ms; if (reduce_ms < 0) reduce_ms = 0;
+		c->tm.reduce_ms = reduce_ms;   /* reduction + transfers: everything that is not one of the three timed phases */
+	}
+	if (cigar_pool) { *cigar_pool = pool; pool = 0; }
+	if (cigar_words) *cigar_words = pool_words;
+	rc = 0;
+done:
+	free(pool); free(order); free(pairs); free(hres); free(hneed);
+	return rc;
+}
+
+s_align* ssw_gpu_result_to_align(const ssw_gpu_result* r, const uint32_t* cigar_pool)
+{
+	if (!r || r->status != 0) return 0;
+	s_align* a = (s_align*)calloc(1, sizeof(s_align));
+	a->score1 = r->score1; a->score2 = r->score2; a->ref_begin1 = r->ref_begin1; a->ref_end1 = r->ref_end1;
+	a->read_begin1 = r->read_begin1; a->read_end1 = r->read_end1; a->ref_end2 = r->ref_end2; a->flag = r->flag;
+	if (r->cigarLen > 0 && cigar_pool && r->cigar_off >= 0) {
+		a->cigar = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)r->cigarLen);
+		memcpy(a->cigar, cigar_pool + r->cigar_off, sizeof(uint32_t) * (size_t)r->cigarLen);
+		a->cigarLen = r->cigarLen;
+	}
+	return a;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * ssw.h single-pair ABI on top of the batch path
+ * ------------------------------------------------------------------------------------------------ */
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static ssw_gpu_ctx* g_ctx = 0;
+
+static ssw_gpu_ctx* default_ctx(void)
+{
+	if (!g_ctx) {
+		const char* e = getenv("SSW_GPU_DEVICE");
+		g_ctx = ssw_gpu_open(e ? atoi(e) : 0);
+	}
+	return g_ctx;
+}
+
+s_profile* ssw_init(const int8_t* read, const int32_t readLen, const int8_t* mat, const int32_t n, const int8_t score_size)
+{
+	s_profile* p = (s_profile*)calloc(1, sizeof(struct _profile));
+	p->read = read; p->mat = mat; p->readLen = readLen; p->n = n; p->score_size = score_size;
+	return p;
+}
+
+void init_destroy(s_profile* p) { free(p); }
+
+void align_destroy(s_align* a) { if (a) { free(a->cigar); free(a); } }
+
+s_align* ssw_align(const s_profile* prof, const int8_t* ref, int32_t refLen, const uint8_t weight_gapO,
+                   const uint8_t weight_gapE, const uint8_t flag, const uint16_t filters, const int32_t filterd,
+                   const int32_t maskLen)
+{
+	s_align* out = 0;
+	if (!prof || prof->score_size < 0 || prof->score_size > 2) {
+		fprintf(stderr, "Please call the function ssw_init before ssw_align.\n");
+		return 0;
+	}
+	if (maskLen < 15)
+		fprintf(stderr, "When maskLen < 15, the function ssw_align doesn't return 2nd best alignment information.\n");
+	pthread_mutex_lock(&g_lock);
+	ssw_gpu_ctx* c = default_ctx();
+	if (!c) {
+		fprintf(stderr, "ssw_align: %s\n", ssw_gpu_last_error(0));
+		pthread_mutex_unlock(&g_lock);
+		return 0;
+	}
+	int64_t qo[2] = { 0, prof->readLen }, to[2] = { 0, refLen };
+	ssw_gpu_seqs* Q = ssw_gpu_seqs_upload(c, prof->read, qo, 1);
+	ssw_gpu_seqs* T = Q ? ssw_gpu_seqs_upload(c, ref, to, 1) : 0;
+	if (Q && T) {
+		ssw_gpu_params prm;
+		prm.mat = prof->mat; prm.n = prof->n; prm.gapO = weight_gapO; prm.gapE = weight_gapE; prm.flag = flag;
+		prm.filters = filters; prm.filterd = filterd; prm.maskLen = maskLen < 0 ? 0 : maskLen; prm.score_size = prof->score_size;
+		ssw_gpu_result r; uint32_t* pool = 0; int64_t words = 0;
+		if (ssw_gpu_align_batch(c, Q, T, 0, 1, &prm, &r, &pool, &words) == 0) {
+			if (r.status == 1)
+				fprintf(stderr, "Please set 2 to the score_size parameter of the function ssw_init, otherwise the alignment results will be incorrect.\n");
+			else {
+				out = ssw_gpu_result_to_align(&r, pool);
+				if (out && out->flag == 2)
+					fprintf(stderr, "Warning: The alignment path of one pair of sequences may miss a small part. [ssw.c ssw_align]\n");
+			}
+		} else fprintf(stderr, "ssw_align: %s\n", ssw_gpu_last_error(c));
+		free(pool);
+	} else fprintf(stderr, "ssw_align: %s\n", ssw_gpu_last_error(c));
+	ssw_gpu_seqs_free(Q); ssw_gpu_seqs_free(T);
+	pthread_mutex_unlock(&g_lock);
+	return out;
+}

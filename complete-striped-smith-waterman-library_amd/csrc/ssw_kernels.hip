@@ -1,0 +1,678 @@
+/*
+ * ssw_kernels.hip -- gfx950 kernels of the Smith-Waterman hot path + the thin C shim the
+ * C host driver (ssw_host.c) calls.
+ *
+ * What is computed (reference file:line is mengyao/Complete-Striped-Smith-Waterman-Library src/ssw.c):
+ *   k_fill     the DP fill of sw_sse2_byte / sw_sse2_word (197-386 / 412-588): per target column
+ *              the maximum H over the (zero-padded) query, for both padding rules at once
+ *   k_reduce   the bookkeeping around that fill: best score / first best column (317-340, 523-542)
+ *              and the masked second-best scan (368-381 / 570-583), plus ssw_align's choice between
+ *              8-bit and 16-bit rules (881-899) and its early exits (900-916)
+ *   k_capture  the "where" passes: read_end1 (342-351 / 544-553) and the reverse pass that finds the
+ *              begin position (ssw_align 919-935, sw_sse2_* with ref_dir = 1 and `terminate`)
+ *   k_trace    banded_sw (590-783) + cigar_alignment_score (785-811) + ssw_align's band retry (941-973)
+ *
+ * How (MI355X-first, not the SSE2 layout): the reference keeps one query in 16/8 SIMD lanes with a
+ * striped layout and repairs the vertical (F) dependency with a lazy loop.  Here a DPP row of 16
+ * lanes is a systolic chain: lane l owns R consecutive query rows, processes target column (step - l)
+ * at each step and hands H / F / running column max to lane l+1 with row_shr DPP moves, so the F
+ * dependency is resolved exactly with no lazy loop.  Every VGPR carries TWO queries (packed 2 x int16,
+ * saturating VOP3P arithmetic).  A wavefront runs 4 chains, a 256-thread workgroup 16 chains that
+ * share one query-pair score profile in LDS and take 16 different tiles of the target.  Tiles start
+ * `halo` columns early from the all-zero state, which reproduces the untiled state exactly
+ * (DESIGN.md "exact halo").  See DESIGN.md for the proof sketches and the roofline.
+ */
+#include "lanes.h"
+#include "ssw_dev.h"
+
+#define DEAD2 0x80008000u   /* packed (-32768, -32768): a score that pins H to max(E, F) */
+
+/* ------------------------------------------------------------------------------------------------
+ * LDS map of one chain-group kernel:
+ *   [0, prof_bytes)                      score profile(s): word ((b*C + c)*16 + l)*4 + k holds the packed
+ *                                        scores of residue b against rows l*R + 4c + k of the two queries
+ *   per chain: 160 B   target ring       80 x u16 profile byte-offsets of target columns (64 + 16 mirrored)
+ *              256 B   out16 ring        64 x u32 finished column maxima (all rows)
+ *              256 B   out8 ring         64 x u32 finished column maxima (first 16R-8 rows)
+ * ------------------------------------------------------------------------------------------------ */
+#define RING_BYTES 160
+#define CHAIN_BYTES (RING_BYTES + 256 + 256)
+
+template <int R> struct ChainGeom {
+	static constexpr int C = (R + 3) / 4;          /* 16-byte profile chunks per lane and residue */
+	static constexpr int PSTRIDE = C * 256;        /* profile bytes per residue */
+	static constexpr int A8 = 16 * R - 8;          /* rows that exist under 16-bit rules when the read is padded */
+	static constexpr int TAP = A8 / R;             /* lane whose running maximum covers exactly rows < A8 ... */
+	static constexpr int K8 = A8 % R;              /* ... after K8 of its own rows */
+};
+
+/* build one packed profile: rows of query A in the low halves, query B in the high halves */
+template <int R>
+SSW_DEV void build_profile(unsigned char* lds, u32 base, int first, int nthreads,
+                           const int8_t* mat, int n,
+                           const int8_t* qa, int lena, int reva,
+                           const int8_t* qb, int lenb)
+{
+	constexpr int C = ChainGeom<R>::C;
+	const int total = (n + 1) * C * 64;
+	for (int w = first; w < total; w += nthreads) {
+		const int b = w / (C * 64), rem = w - b * (C * 64);
+		const int c = rem >> 6, l = (rem & 63) >> 2, k = rem & 3;
+		const int r = c * 4 + k, row = l * R + r;
+		u32 v;
+		if (b == n) v = DEAD2;
+		else if (r >= R) v = 0;
+		else {
+			int lo = 0, hi = 0;
+			if (row < lena) lo = mat[b * n + (reva ? qa[lena - 1 - row] : qa[row])];
+			if (qb && row < lenb) hi = mat[b * n + qb[row]];
+			v = pk_make(lo, hi);
+		}
+		lds_st32(lds, base + (u32)w * 4u, v);
+	}
+}
+
+/* one DP step of a chain lane: R rows of one target column for two packed queries */
+template <int R, bool TRACK8>
+SSW_DEV void chain_rows(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f, u32& cm, u32& ck,
+                        u32 gapO2, u32 gapE2)
+{
+	constexpr int K8 = ChainGeom<R>::K8;
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		if (TRACK8 && r == K8) ck = cm;
+		const u32 hold = H[r];
+		const u32 s = sc[r >> 2][r & 3];
+		const u32 h0 = pk_max(pk_adds(d, s), E[r]);   /* E >= 0 supplies the max(0, .) of local alignment */
+		const u32 h = pk_max(h0, f);
+		const u32 t0 = pk_subu(h0, gapO2);            /* gap opened from the F-free value */
+		E[r] = pk_max(pk_subu(E[r], gapE2), t0);
+		f = pk_max(pk_subu(f, gapE2), t0);
+		cm = pk_max(cm, h);
+		H[r] = h;
+		d = hold;
+	}
+}
+
+/* ================================================================================================
+ * k_fill: forward fill, column maxima only.  grid = npairs * bpp workgroups of 256 threads.
+ * ================================================================================================ */
+template <int R>
+__global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
+{
+	typedef ChainGeom<R> G;
+	constexpr int C = G::C;
+	SSW_DYN_LDS(lds);
+	const int tid = (int)threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+	const int pair = (int)blockIdx.x / a.bpp, tchunk = (int)blockIdx.x - pair * a.bpp;
+	const u32 prof_bytes = (u32)(a.n + 1) * G::PSTRIDE;
+	const u32 ring = prof_bytes + (u32)grp * CHAIN_BYTES, out16 = ring + RING_BYTES, out8 = out16 + 256;
+	const u32 nulloff = (u32)a.n * G::PSTRIDE;
+
+	{   /* score profile of this pair, shared by the 16 chains of the workgroup */
+		const ssw_pair pr = a.pairs[pair];
+		const int8_t* qa = a.qcodes + a.qoff[pr.qa];
+		const int lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
+		const int8_t* qb = pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0;
+		const int lenb = pr.qb >= 0 ? (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]) : 0;
+		build_profile<R>(lds, 0, tid, 256, a.mat, a.n, qa, lena, 0, qb, lenb);
+	}
+
+	/* this chain's tile */
+	const int t = tchunk * 16 + grp;
+	const bool active = t < a.ntiles;
+	const int tile_lo = active ? t * a.tile : 0;
+	const int tile_hi = active ? (tile_lo + a.tile < a.refLen ? tile_lo + a.tile : a.refLen) : 0;
+	const int c_first = tile_lo - a.halo > 0 ? tile_lo - a.halo : 0;
+	const int ncols = tile_hi - c_first;
+	int maxcols = a.tile + a.halo; if (maxcols > a.refLen) maxcols = a.refLen;
+	const int nsteps = (maxcols + 16 + 15) & ~15;
+	const int8_t* tg = a.tgt + c_first;
+	uint32_t* o16 = a.cm16 + (int64_t)pair * a.cm_stride + c_first;
+	uint32_t* o8 = a.cm8 + (int64_t)pair * a.cm_stride + c_first;
+	const int store_from = tile_lo - c_first;   /* first traversal column whose maximum is kept */
+
+	/* target ring: columns -16..-1 are "null" columns, 0..15 loaded now, 16..31 in flight */
+	lds_st16(lds, ring + 2u * (48 + l16), nulloff);
+	{
+		int code = l16 < ncols ? tg[l16] : a.n;
+		if (code < 0 || code > a.n) code = a.n;
+		const u32 off = (u32)code * G::PSTRIDE;
+		lds_st16(lds, ring + 2u * l16, off);
+		lds_st16(lds, ring + 2u * (64 + l16), off);
+	}
+	u32 nxt;
+	{
+		const int tc = 16 + l16;
+		int code = tc < ncols ? tg[tc] : a.n;
+		if (code < 0 || code > a.n) code = a.n;
+		nxt = (u32)code * G::PSTRIDE;
+	}
+	__syncthreads();
+
+	u32 H[R], E[R];
+#pragma unroll
+	for (int r = 0; r < R; ++r) { H[r] = 0; E[r] = 0; }
+	u32 Hlast = 0, Fout = 0, cmout = 0, ck = 0, hsave = 0;
+	const u32 lane_prof = (u32)l16 * 16u;
+	const u32 notfirst = l16 ? 0xffffffffu : 0u;
+
+	for (int s0 = 0; s0 < nsteps; s0 += 16) {
+		{   /* stage target columns [s0+16, s0+32), prefetch [s0+32, s0+48) */
+			const int p = (s0 + 16 + l16) & 63;
+			lds_st16(lds, ring + 2u * p, nxt);
+			if (p < 16) lds_st16(lds, ring + 2u * (64 + p), nxt);
+			const int tc = s0 + 32 + l16;
+			int code = tc < ncols ? tg[tc] : a.n;
+			if (code < 0 || code > a.n) code = a.n;
+			nxt = (u32)code * G::PSTRIDE;
+		}
+		wave_lds_fence();   /* lane 0's ring writes of the previous 16 steps are visible to the chain */
+		if (s0 >= 32) {   /* columns [s0-32, s0-16) are complete in the out rings */
+			const int tc = s0 - 32 + l16;
+			if (tc >= store_from && tc < ncols) {
+				o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
+				o8[tc] = lds_ld32(lds, out8 + 4u * (tc & 63));
+			}
+		}
+		wave_lds_fence();
+		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
+#pragma unroll 4
+		for (int j = 0; j < 16; ++j) {
+			const int s = s0 + j;
+			const u32 paddr = lds_ld16(lds, rp + 2u * j) + lane_prof;
+			u32x4 sc[C];
+#pragma unroll
+			for (int c = 0; c < C; ++c) sc[c] = lds_ld128(lds, paddr + 256u * c);
+			const u32 hin = xl_row_shr1_zero(Hlast);
+			u32 f = xl_row_shr1_zero(Fout);
+			const u32 x = xl_row_ror<1>(cmout);
+			const u32 x8 = xl_row_ror<16 - G::TAP>(ck);
+			if (l16 == 0) {   /* lane 0 sees the finished maxima of columns s-16 (all rows) and s-1-TAP (rows < A8) */
+				lds_st32(lds, out16 + 4u * ((s - 16) & 63), x);
+				lds_st32(lds, out8 + 4u * ((s - 1 - G::TAP) & 63), x8);
+			}
+			u32 cm = x & notfirst;
+			chain_rows<R, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);
+			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
+		}
+	}
+	wave_lds_fence();
+	for (int base = nsteps - 32; base < nsteps; base += 16) {
+		const int tc = base + l16;
+		if (tc >= store_from && tc < ncols && tc >= 0) {
+			o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
+			o8[tc] = lds_ld32(lds, out8 + 4u * (tc & 63));
+		}
+	}
+}
+
+/* ================================================================================================
+ * k_reduce: one workgroup per pair; both queries of the pair.
+ * ================================================================================================ */
+SSW_DEV int half16(u32 w, int hi) { return (int)((hi ? (w >> 16) : w) & 0xffffu); }
+
+/* block-wide (max value, then min index) reduction; result valid in every thread */
+SSW_DEV void block_argmax(unsigned char* lds, int tid, int& val, int& idx)
+{
+	lds_st32(lds, 8u * tid, (u32)val);
+	lds_st32(lds, 8u * tid + 4, (u32)idx);
+	__syncthreads();
+	for (int st = 128; st > 0; st >>= 1) {
+		if (tid < st) {
+			int v0 = (int)lds_ld32(lds, 8u * tid), i0 = (int)lds_ld32(lds, 8u * tid + 4);
+			int v1 = (int)lds_ld32(lds, 8u * (tid + st)), i1 = (int)lds_ld32(lds, 8u * (tid + st) + 4);
+			if (v1 > v0 || (v1 == v0 && i1 < i0)) { lds_st32(lds, 8u * tid, (u32)v1); lds_st32(lds, 8u * tid + 4, (u32)i1); }
+		}
+		__syncthreads();
+	}
+	val = (int)lds_ld32(lds, 0); idx = (int)lds_ld32(lds, 4);
+	__syncthreads();
+}
+
+__global__ void __launch_bounds__(256) k_reduce(ssw_reduce_args a)
+{
+	SSW_DYN_LDS(lds);
+	const int tid = (int)threadIdx.x, pair = (int)blockIdx.x;
+	const ssw_pair pr = a.pairs[pair];
+	const u32* w16 = a.cm16 + (int64_t)pair * a.cm_stride;
+	const u32* w8 = a.cm8 + (int64_t)pair * a.cm_stride;
+	for (int hi = 0; hi < 2; ++hi) {
+		const int q = hi ? pr.qb : pr.qa;
+		if (q < 0) continue;
+		const int len = (int)(a.qoff[q + 1] - a.qoff[q]);
+		const bool padded = (len & 15) >= 1 && (len & 15) <= 8;      /* 16-bit rules see 8 rows fewer */
+		const int maskLen = a.maskLen >= 0 ? a.maskLen : len / 2;
+		int best = 0, bidx = 0x7fffffff;
+		for (int c = tid; c < a.refLen; c += 256) {
+			const int v = half16(w16[c], hi);
+			if (v > best) { best = v; bidx = c; }
+		}
+		block_argmax(lds, tid, best, bidx);
+		ssw_dres r;
+		r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = 0; r.read_begin1 = -1; r.read_end1 = 0;
+		r.ref_end2 = 0; r.cigarLen = 0; r.flag = 0; r.status = 0; r.word = 0; r.want_begin = 0; r.want_cigar = 0;
+		r.rev_score = 0; r.cigar_off = 0;
+		const bool have_byte = a.score_size == 0 || a.score_size == 2, have_word = a.score_size == 1 || a.score_size == 2;
+		int word = 0;
+		if (have_byte && best < 255 - a.bias) word = 0;                /* ssw.c:881-899 */
+		else if (have_word) word = 1;
+		else r.status = 1;
+		r.word = word;
+		if (r.status == 0 && best > 0) {
+			const u32* arr = (word && padded) ? w8 : w16;
+			const int lo_edge = bidx - maskLen > 0 ? bidx - maskLen : 0;
+			const int hi_edge = bidx + maskLen > a.refLen ? a.refLen : bidx + maskLen;
+			const int up_from = word ? hi_edge : hi_edge + 1;          /* ssw.c:376 vs 578 */
+			int s2 = 0, i2 = 0x7fffffff;
+			for (int c = tid; c < a.refLen; c += 256) {
+				if (c < lo_edge || c >= up_from) {
+					const int v = half16(arr[c], hi);
+					if (v > s2) { s2 = v; i2 = c; }
+				}
+			}
+			block_argmax(lds, tid, s2, i2);
+			r.score1 = best; r.ref_end1 = bidx;
+			if (maskLen >= 15) { r.score2 = s2; r.ref_end2 = s2 > 0 ? i2 : 0; }
+			else { r.score2 = 0; r.ref_end2 = -1; }
+			r.want_begin = !(a.flag == 0 || (a.flag == 2 && best < a.filters));   /* ssw.c:916 */
+		}
+		if (tid == 0) a.res[q] = r;
+	}
+}
+
+/* ================================================================================================
+ * k_capture: one chain per alignment; tracks the best cell (value, first column, smallest row) of a
+ * window.  reverse == 0: columns [ref_end1 - halo, ref_end1] forward -> read_end1.
+ * reverse == 1: reversed read prefix against columns ref_end1, ref_end1-1, ... -> begin position.
+ * grid = ceil(nq / 4) workgroups of 64 threads (4 chains, each with its own profile).
+ * ================================================================================================ */
+template <int R>
+__global__ void __launch_bounds__(64) k_capture(ssw_capture_args a)
+{
+	typedef ChainGeom<R> G;
+	constexpr int C = G::C;
+	SSW_DYN_LDS(lds);
+	const int tid = (int)threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+	const u32 prof_bytes = (u32)(a.n + 1) * G::PSTRIDE;
+	const u32 prof = (u32)grp * (prof_bytes + CHAIN_BYTES), ring = prof + prof_bytes, red = ring + RING_BYTES;
+	const u32 nulloff = (u32)a.n * G::PSTRIDE;
+	const int job = (int)blockIdx.x * 4 + grp;
+	const int q = job < a.nq ? a.qlist[job] : -1;
+
+	ssw_dres r;
+	bool active = false;
+	if (q >= 0) { r = a.res[q]; active = r.status == 0 && r.score1 > 0 && (a.reverse ? r.want_begin != 0 : 1); }
+	int qlen = 0, plen = 0, c_edge = 0, ncols = 0, P = 16;
+	const int8_t* qc = a.qcodes;
+	if (active) {
+		qc = a.qcodes + a.qoff[q];
+		qlen = (int)(a.qoff[q + 1] - a.qoff[q]);
+		plen = a.reverse ? r.read_end1 + 1 : qlen;
+		P = (plen + 15) & ~15;
+		/* exact halo: a positive-scoring path spans < P + P*max(mat)/gapE columns */
+		long long w = (long long)P + ((long long)P * (a.maxmat > 0 ? a.maxmat : 0) + a.gapE - 1) / (a.gapE > 0 ? a.gapE : 1) + 1;
+		if (a.gapE <= 0 || w > r.ref_end1) w = r.ref_end1;
+		ncols = (int)w + 1;
+		c_edge = a.reverse ? r.ref_end1 : r.ref_end1 - (int)w;   /* traversal column 0 */
+	}
+	build_profile<R>(lds, prof, l16, 16, a.mat, a.n, qc, plen, a.reverse, (const int8_t*)0, 0);
+
+	/* uniform step count for the 4 chains of the wave */
+	int mc = ncols;
+#pragma unroll
+	for (int sh = 16; sh < 64; sh <<= 1) { const int o = (int)xl_shfl((u32)mc, (tid + sh) & 63); mc = o > mc ? o : mc; }
+	const int nsteps = (mc + 16 + 15) & ~15;
+	const int8_t* tg = a.tgt;
+	const int dirstep = a.reverse ? -1 : 1;
+
+	lds_st16(lds, ring + 2u * (48 + l16), nulloff);
+	{
+		int code = l16 < ncols ? tg[c_edge + dirstep * l16] : a.n;
+		if (code < 0 || code > a.n) code = a.n;
+		const u32 off = (u32)code * G::PSTRIDE;
+		lds_st16(lds, ring + 2u * l16, off);
+		lds_st16(lds, ring + 2u * (64 + l16), off);
+	}
+	u32 nxt;
+	{
+		const int tc = 16 + l16;
+		int code = tc < ncols ? tg[c_edge + dirstep * tc] : a.n;
+		if (code < 0 || code > a.n) code = a.n;
+		nxt = (u32)code * G::PSTRIDE;
+	}
+	wave_lds_fence();
+
+	u32 H[R], E[R];
+#pragma unroll
+	for (int k = 0; k < R; ++k) { H[k] = 0; E[k] = 0; }
+	u32 Hlast = 0, Fout = 0, hsave = 0;
+	int best = 0, btc = 0x7fffffff, brow = 0;
+	const u32 lane_prof = prof + (u32)l16 * 16u;
+
+	for (int s0 = 0; s0 < nsteps; s0 += 16) {
+		{
+			const int p = (s0 + 16 + l16) & 63;
+			lds_st16(lds, ring + 2u * p, nxt);
+			if (p < 16) lds_st16(lds, ring + 2u * (64 + p), nxt);
+			const int tc = s0 + 32 + l16;
+			int code = tc < ncols ? tg[c_edge + dirstep * tc] : a.n;
+			if (code < 0 || code > a.n) code = a.n;
+			nxt = (u32)code * G::PSTRIDE;
+		}
+		wave_lds_fence();
+		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
+#pragma unroll 2
+		for (int j = 0; j < 16; ++j) {
+			const int tc = s0 + j - l16;
+			const u32 paddr = lds_ld16(lds, rp + 2u * j) + lane_prof;
+			u32x4 sc[C];
+#pragma unroll
+			for (int c = 0; c < C; ++c) sc[c] = lds_ld128(lds, paddr + 256u * c);
+			const u32 hin = xl_row_shr1_zero(Hlast);
+			u32 f = xl_row_shr1_zero(Fout);
+			u32 cm = 0, ck = 0;
+			chain_rows<R, false>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);
+			hsave = hin; Hlast = H[R - 1]; Fout = f;
+			const int m = (int)(cm & 0xffffu);     /* this lane's maximum in this column (low half = the query) */
+			if (m > best && tc >= 0 && tc < ncols) {
+				best = m; btc = tc;
+#pragma unroll
+				for (int k = R - 1; k >= 0; --k) if ((int)(H[k] & 0xffffu) == m) brow = l16 * R + k;
+			}
+		}
+	}
+
+	/* chain-wide winner: highest value, then first column, then smallest row */
+	lds_st32(lds, red + 12u * l16, (u32)best);
+	lds_st32(lds, red + 12u * l16 + 4, (u32)btc);
+	lds_st32(lds, red + 12u * l16 + 8, (u32)brow);
+	wave_lds_fence();
+	if (l16 == 0 && active) {
+		int bv = 0, bc = 0x7fffffff, br = 0;
+		for (int k = 0; k < 16; ++k) {
+			const int v = (int)lds_ld32(lds, red + 12u * k), c = (int)lds_ld32(lds, red + 12u * k + 4), w = (int)lds_ld32(lds, red + 12u * k + 8);
+			if (v > bv || (v == bv && v > 0 && (c < bc || (c == bc && w < br)))) { bv = v; bc = c; br = w; }
+		}
+		if (!a.reverse) {
+			/* ssw.c:342-351: smallest row holding the maximum, never beyond the last read base */
+			a.res[q].read_end1 = (bv == r.score1) ? (br < qlen - 1 ? br : qlen - 1) : -1;
+			if (bv != r.score1) a.res[q].status = 3;   /* internal error: window did not reproduce score1 */
+		} else {
+			if (bv != r.score1 && ncols <= r.ref_end1) {
+				a.res[q].status = 3;   /* halo bound violated (cannot happen for gapO > gapE) */
+			} else {
+				const int rb = r.ref_end1 - bc, qb = r.read_end1 - (br < plen - 1 ? br : plen - 1);
+				a.res[q].ref_begin1 = rb; a.res[q].read_begin1 = qb; a.res[q].rev_score = bv;
+				if (r.score1 > bv) a.res[q].flag = 2;                       /* ssw.c:932-935 */
+				const int skip = (7 & a.flag) == 0 || ((2 & a.flag) != 0 && r.score1 < a.filters) ||
+				                 ((4 & a.flag) != 0 && (r.ref_end1 - rb > a.filterd || r.read_end1 - qb > a.filterd));   /* ssw.c:938 */
+				a.res[q].want_cigar = !skip;
+			}
+		}
+	}
+}
+
+/* ================================================================================================
+ * k_trace: banded_sw + cigar re-score + band retry, one thread per alignment (scalar int32, exactly the
+ * reference's control flow; the band of short reads is a handful of cells wide).
+ * ================================================================================================ */
+SSW_DEV int band_u(int w, int i, int j) { int x = i - w; if (x < 0) x = 0; return j - x + 1; }       /* ssw.c:92 */
+SSW_DEV int band_d(int w, int i, int j, int p) { int x = i - w; if (x < 0) x = 0; return (j - x) * 3 + p; }  /* ssw.c:95 */
+
+SSW_DEV int trace_one(const int8_t* ref, const int8_t* read, int refLen, int readLen, int score, int gapO, int gapE,
+                      int band_width, const int8_t* mat, int n, unsigned char* scratch, int64_t cap,
+                      u32* cig, int cigcap, int64_t* need)
+{
+	const int NEG = -1073741824;   /* INT32_MIN / 2 */
+	const int len = refLen > readLen ? refLen : readLen;
+	int best = 0, best_i = 0, best_j = 0, width, width_d, i, j;
+	int *hb, *eb, *hc; int8_t* dir;
+	do {
+		width = band_width * 2 + 3; width_d = band_width * 2 + 1;
+		const int64_t rowbytes = (((int64_t)width + 1) * 4 + 15) & ~(int64_t)15;
+		const int64_t want = 3 * rowbytes + (int64_t)width_d * readLen * 3 + 16;
+		if (want > cap) { *need = want; return -2; }
+		hb = (int*)scratch; eb = (int*)(scratch + rowbytes); hc = (int*)(scratch + 2 * rowbytes);
+		dir = (int8_t*)(scratch + 3 * rowbytes);
+		for (j = 1; j < width - 1; ++j) hb[j] = 0;
+		for (i = 0; i < readLen; ++i) {
+			const int beg = i - band_width > 0 ? i - band_width : 0;
+			const int end = i + band_width < refLen - 1 ? i + band_width : refLen - 1;
+			const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+			int f = NEG, u = 0;
+			int8_t* line = dir + (int64_t)width_d * i * 3;
+			hb[0] = 0; hb[edge] = 0; hc[0] = 0;
+			eb[0] = NEG; eb[edge] = NEG;
+			for (j = beg; j <= end; ++j) {
+				u = band_u(band_width, i, j);
+				const int up = band_u(band_width, i - 1, j), lf = band_u(band_width, i, j - 1), dg = band_u(band_width, i - 1, j - 1);
+				int open = i == 0 ? -gapO : hb[up] - gapO;
+				int ext = i == 0 ? NEG : eb[up] - gapE;
+				const int e = open > ext ? open : ext;
+				const int8_t de = open > ext ? 3 : 2;
+				eb[u] = e;
+				line[band_d(band_width, i, j, 0)] = de;
+				open = hc[lf] - gapO; ext = f - gapE;
+				f = open > ext ? open : ext;
+				const int8_t df = open > ext ? 5 : 4;
+				line[band_d(band_width, i, j, 1)] = df;
+				const int e1 = e > 0 ? e : 0, f1 = f > 0 ? f : 0;
+				const int gap = e1 > f1 ? e1 : f1;
+				const int dia = hb[dg] + mat[(int)ref[j] * n + read[i]];
+				const int h = gap > dia ? gap : dia;
+				hc[u] = h;
+				if (h > best) { best = h; best_i = i; best_j = j; }
+				line[band_d(band_width, i, j, 2)] = gap <= dia ? (int8_t)1 : (e1 > f1 ? de : df);
+			}
+			for (j = 1; j <= u; ++j) hb[j] = hc[j];
+		}
+		band_width *= 2;
+	} while (best < score && band_width <= len);
+	band_width /= 2;
+
+	/* walk back from the best cell, emitting run-length ops last-to-first (ssw.c:682-762) */
+	int nops = 0, run = 0, state = 2, cur = 0, prev = 0;
+	i = best_i; j = best_j;
+	while (i >= 0 && j > 0) {
+		const int8_t d = dir[(int64_t)width_d * i * 3 + band_d(band_width, i, j, state)];
+		if (d == 1) { --i; --j; state = 2; cur = 0; }
+		else if (d == 2) { --i; state = 0; cur = 1; }
+		else if (d == 3) { --i; state = 2; cur = 1; }
+		else if (d == 4) { --j; state = 1; cur = 2; }
+		else if (d == 5) { --j; state = 2; cur = 2; }
+		else return -1;
+		if (cur == prev) ++run;
+		else { if (nops < cigcap) cig[nops] = ((u32)run << 4) | (u32)prev; ++nops; prev = cur; run = 1; }
+	}
+	if (cur == 0) { if (nops < cigcap) cig[nops] = ((u32)(run + 1) << 4); ++nops; }
+	else {
+		if (nops < cigcap) cig[nops] = ((u32)run << 4) | (u32)cur; ++nops;
+		if (nops < cigcap) cig[nops] = (1u << 4); ++nops;
+	}
+	if (nops > cigcap) { *need = -(int64_t)nops; return -2; }
+	for (int x = 0, y = nops - 1; x < y; ++x, --y) { const u32 t = cig[x]; cig[x] = cig[y]; cig[y] = t; }
+	return nops;
+}
+
+SSW_DEV int cigar_score(const u32* cig, int n_ops, const int8_t* ref, const int8_t* read, const int8_t* mat, int n, int gapO, int gapE)
+{
+	int score = 0, rp = 0, qp = 0;
+	for (int i = 0; i < n_ops; ++i) {
+		const int len = (int)(cig[i] >> 4), op = (int)(cig[i] & 0xf);
+		if (op == 0) { for (int k = 0; k < len; ++k) score += mat[(int)ref[rp++] * n + read[qp++]]; }
+		else { score -= gapO + (len > 1 ? (len - 1) * gapE : 0); if (op == 1) qp += len; else if (op == 2) rp += len; }
+	}
+	return score;
+}
+
+__global__ void __launch_bounds__(64) k_trace(ssw_trace_args a)
+{
+	const int job = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (job >= a.nq) return;
+	const int q = a.qlist[job];
+	ssw_dres r = a.res[q];
+	a.need[job] = 0;
+	if (!r.want_cigar || r.status != 0) return;
+	const int8_t* ref = a.tgt + r.ref_begin1;
+	const int8_t* read = a.qcodes + a.qoff[q] + r.read_begin1;
+	const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
+	const int d = refLen - readLen;
+	int band = (d < 0 ? -d : d) + 1;
+	const int full = refLen > readLen ? refLen : readLen;
+	u32* cig = a.cigar + (int64_t)q * a.cigar_stride;   /* CIGAR slots are indexed by query, scratch by launch position */
+	unsigned char* scratch = a.scratch + (int64_t)job * a.scratch_stride;
+	int nops;
+	for (;;) {   /* ssw.c:945-957 */
+		int64_t need = 0;
+		nops = trace_one(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, band, a.mat, a.n, scratch, a.scratch_stride,
+		                 cig, (int)a.cigar_stride, &need);
+		if (nops == -2) { a.need[job] = need > 0 ? (int)(need > 0x7fffffff ? 0x7fffffff : need) : -1; return; }
+		if (nops < 0) break;
+		if (cigar_score(cig, nops, ref, read, a.mat, a.n, a.gapO, a.gapE) == r.score1) break;
+		if (band >= full) { nops = -1; break; }
+		band = full;
+	}
+	if (nops < 0) { a.res[q].flag = 1; a.res[q].cigarLen = 0; }
+	else { a.res[q].cigarLen = nops; a.res[q].cigar_off = (int64_t)q * a.cigar_stride; }
+}
+
+/* pack the used part of every CIGAR slot into one contiguous pool (one thread per query) */
+__global__ void __launch_bounds__(256) k_gather(ssw_gather_args a)
+{
+	const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (q >= a.nq) return;
+	const int len = a.res[q].cigarLen;
+	if (len <= 0) return;
+	const u32* src = a.src + a.res[q].cigar_off;
+	u32* dst = a.dst + a.dst_off[q];
+	for (int i = 0; i < len; ++i) dst[i] = src[i];
+}
+
+/* ================================================================================================
+ * launchers (the thin C shim of SURVEY 8b: host code stays C)
+ * ================================================================================================ */
+#ifdef SSW_SIMT_EMU
+template <class A, void (*K)(A)> static void emu_thunk(void* p) { K(*(A*)p); }
+#define SSW_LAUNCH(kern, A, args, grid, block, ldsbytes, stream) \
+	do { (void)(stream); emu::launch(&emu_thunk<A, kern>, (void*)&(args), (unsigned)(grid), (unsigned)(block), (size_t)(ldsbytes)); } while (0)
+#define SSW_LAUNCH_OK() 0
+#else
+static thread_local char g_shim_err[256];
+static int shim_check(hipError_t e, const char* what)
+{
+	if (e == hipSuccess) return 0;
+	snprintf(g_shim_err, sizeof g_shim_err, "%s: %s", what, hipGetErrorString(e));
+	return -1;
+}
+#define SSW_LAUNCH(kern, A, args, grid, block, ldsbytes, stream) \
+	hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(ldsbytes), (hipStream_t)(stream), args)
+#define SSW_LAUNCH_OK() shim_check(hipGetLastError(), "kernel launch")
+#endif
+
+#define FOR_EACH_R(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) \
+                      X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+
+extern "C" int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream)
+{
+	ssw_fill_args args = *a;
+	const int64_t grid = (int64_t)args.npairs * args.bpp;
+	if (grid <= 0) return 0;
+	switch (R) {
+#define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
+		SSW_LAUNCH(k_fill<r>, ssw_fill_args, args, grid, 256, ldsb, stream); } break;
+		FOR_EACH_R(X)
+#undef X
+		default: return -2;
+	}
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream)
+{
+	ssw_reduce_args args = *a;
+	if (args.npairs <= 0) return 0;
+	SSW_LAUNCH(k_reduce, ssw_reduce_args, args, args.npairs, 256, 256 * 8, stream);
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* stream)
+{
+	ssw_capture_args args = *a;
+	if (args.nq <= 0) return 0;
+	const int grid = (args.nq + 3) / 4;
+	switch (R) {
+#define X(r) case r: { const size_t ldsb = 4 * ((size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + CHAIN_BYTES); \
+		SSW_LAUNCH(k_capture<r>, ssw_capture_args, args, grid, 64, ldsb, stream); } break;
+		FOR_EACH_R(X)
+#undef X
+		default: return -2;
+	}
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream)
+{
+	ssw_trace_args args = *a;
+	if (args.nq <= 0) return 0;
+	SSW_LAUNCH(k_trace, ssw_trace_args, args, (args.nq + 63) / 64, 64, 0, stream);
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_launch_gather(const ssw_gather_args* a, void* stream)
+{
+	ssw_gather_args args = *a;
+	if (args.nq <= 0) return 0;
+	SSW_LAUNCH(k_gather, ssw_gather_args, args, (args.nq + 255) / 256, 256, 0, stream);
+	return SSW_LAUNCH_OK();
+}
+
+#ifndef SSW_SIMT_EMU
+/* ---- HIP runtime part of the shim ---- */
+extern "C" const char* ssw_shim_last_error(void) { return g_shim_err; }
+extern "C" int ssw_shim_device_count(void)
+{
+	int n = 0;
+	if (shim_check(hipGetDeviceCount(&n), "hipGetDeviceCount")) return 0;
+	return n;
+}
+extern "C" int ssw_shim_set_device(int dev) { return shim_check(hipSetDevice(dev), "hipSetDevice"); }
+extern "C" void* ssw_shim_stream_create(void)
+{
+	hipStream_t s = 0;
+	if (shim_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return 0;
+	return (void*)s;
+}
+extern "C" void ssw_shim_stream_destroy(void* s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
+extern "C" int ssw_shim_stream_sync(void* s) { return shim_check(hipStreamSynchronize((hipStream_t)s), "hipStreamSynchronize"); }
+extern "C" void* ssw_shim_malloc(size_t bytes)
+{
+	void* p = 0;
+	if (shim_check(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc")) return 0;
+	return p;
+}
+extern "C" void ssw_shim_free(void* p) { if (p) (void)hipFree(p); }
+extern "C" int ssw_shim_h2d(void* d, const void* s, size_t n, void* st) { return n ? shim_check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st), "hipMemcpy H2D") : 0; }
+extern "C" int ssw_shim_d2h(void* d, const void* s, size_t n, void* st) { return n ? shim_check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st), "hipMemcpy D2H") : 0; }
+extern "C" int ssw_shim_memset(void* d, int v, size_t n, void* st) { return n ? shim_check(hipMemsetAsync(d, v, n, (hipStream_t)st), "hipMemset") : 0; }
+extern "C" size_t ssw_shim_mem_free_bytes(void)
+{
+	size_t f = 0, t = 0;
+	if (hipMemGetInfo(&f, &t) != hipSuccess) return 0;
+	return f;
+}
+extern "C" void* ssw_shim_event_create(void)
+{
+	hipEvent_t e = 0;
+	if (shim_check(hipEventCreate(&e), "hipEventCreate")) return 0;
+	return (void*)e;
+}
+extern "C" void ssw_shim_event_destroy(void* e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
+extern "C" int ssw_shim_event_record(void* e, void* s) { return shim_check(hipEventRecord((hipEvent_t)e, (hipStream_t)s), "hipEventRecord"); }
+extern "C" float ssw_shim_event_elapsed_ms(void* a, void* b)
+{
+	float ms = 0.f;
+	if (hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) return -1.f;
+	return ms;
+}
+#endif

@@ -1,0 +1,174 @@
+"""ctypes binding of libssw.so (the MI355X-native Smith-Waterman library).
+
+Two layers, both thin:
+
+* ``CSsw`` mirrors the reference's own ctypes wrapper (reference src/ssw_lib.py:94-197: class
+  ``CSsw`` with ``ssw_init`` / ``ssw_align`` / ``init_destroy`` / ``align_destroy`` and the
+  ``CAlignRes`` field layout of src/ssw_lib.py:61-69) so that code written against it runs unchanged.
+* ``Context`` / ``Seqs`` / ``align_batch`` bind the batch ABI of include/ssw_gpu.h.
+
+This module never computes alignments itself: if the shared library (and through it the HIP device)
+is missing, loading or calling fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libssw.so")
+
+_i8p = C.POINTER(C.c_int8)
+_u32p = C.POINTER(C.c_uint32)
+_i64p = C.POINTER(C.c_int64)
+
+
+class CAlignRes(C.Structure):
+    """s_align (include/ssw.h; reference src/ssw.h:55-66)."""
+    _fields_ = [("nScore", C.c_uint16), ("nScore2", C.c_uint16), ("nRefBeg", C.c_int32), ("nRefEnd", C.c_int32),
+                ("nQryBeg", C.c_int32), ("nQryEnd", C.c_int32), ("nRefEnd2", C.c_int32), ("sCigar", _u32p),
+                ("nCigarLen", C.c_int32), ("nFlag", C.c_uint16)]
+
+
+class Params(C.Structure):
+    """ssw_gpu_params (include/ssw_gpu.h)."""
+    _fields_ = [("mat", _i8p), ("n", C.c_int32), ("gapO", C.c_uint8), ("gapE", C.c_uint8), ("flag", C.c_uint8),
+                ("filters", C.c_uint16), ("filterd", C.c_int32), ("maskLen", C.c_int32), ("score_size", C.c_int8)]
+
+
+class Result(C.Structure):
+    """ssw_gpu_result (include/ssw_gpu.h)."""
+    _fields_ = [("score1", C.c_uint16), ("score2", C.c_uint16), ("ref_begin1", C.c_int32), ("ref_end1", C.c_int32),
+                ("read_begin1", C.c_int32), ("read_end1", C.c_int32), ("ref_end2", C.c_int32), ("cigarLen", C.c_int32),
+                ("cigar_off", C.c_int64), ("flag", C.c_uint16), ("status", C.c_uint16)]
+
+
+class Timing(C.Structure):
+    """ssw_gpu_timing (include/ssw_gpu.h)."""
+    _fields_ = [("total_ms", C.c_double), ("fill_ms", C.c_double), ("fill_launches", C.c_int64),
+                ("fill_cells", C.c_int64), ("cells", C.c_int64), ("reduce_ms", C.c_double), ("locate_ms", C.c_double),
+                ("trace_ms", C.c_double), ("n_word", C.c_int64), ("n_byte", C.c_int64)]
+
+
+RESULT_DTYPE = np.dtype([("score1", "<u2"), ("score2", "<u2"), ("ref_begin1", "<i4"), ("ref_end1", "<i4"),
+                         ("read_begin1", "<i4"), ("read_end1", "<i4"), ("ref_end2", "<i4"), ("cigarLen", "<i4"),
+                         ("cigar_off", "<i8"), ("flag", "<u2"), ("status", "<u2")], align=True)
+assert RESULT_DTYPE.itemsize == C.sizeof(Result)
+
+
+def load(path=None):
+    path = path or os.environ.get("SSW_LIB", DEFAULT_LIB)
+    if not os.path.exists(path):
+        raise OSError("libssw.so not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+    L = C.CDLL(path)
+    L.ssw_init.argtypes = [_i8p, C.c_int32, _i8p, C.c_int32, C.c_int8]
+    L.ssw_init.restype = C.c_void_p
+    L.init_destroy.argtypes = [C.c_void_p]
+    L.init_destroy.restype = None
+    L.ssw_align.argtypes = [C.c_void_p, _i8p, C.c_int32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint16, C.c_int32,
+                            C.c_int32]
+    L.ssw_align.restype = C.POINTER(CAlignRes)
+    L.align_destroy.argtypes = [C.POINTER(CAlignRes)]
+    L.align_destroy.restype = None
+    L.mark_mismatch.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i8p, _i8p, C.c_int32, C.POINTER(_u32p),
+                                C.POINTER(C.c_int32)]
+    L.mark_mismatch.restype = C.c_int32
+    L.ssw_gpu_device_count.restype = C.c_int
+    L.ssw_gpu_open.argtypes = [C.c_int]
+    L.ssw_gpu_open.restype = C.c_void_p
+    L.ssw_gpu_close.argtypes = [C.c_void_p]
+    L.ssw_gpu_close.restype = None
+    L.ssw_gpu_last_error.argtypes = [C.c_void_p]
+    L.ssw_gpu_last_error.restype = C.c_char_p
+    L.ssw_gpu_seqs_upload.argtypes = [C.c_void_p, _i8p, _i64p, C.c_int32]
+    L.ssw_gpu_seqs_upload.restype = C.c_void_p
+    L.ssw_gpu_seqs_free.argtypes = [C.c_void_p]
+    L.ssw_gpu_seqs_free.restype = None
+    L.ssw_gpu_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Params),
+                                      C.c_void_p, C.POINTER(_u32p), _i64p]
+    L.ssw_gpu_align_batch.restype = C.c_int
+    L.ssw_gpu_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+    L.ssw_gpu_last_timing.restype = C.c_int
+    return L
+
+
+class CSsw(object):
+    """Same surface as the reference's src/ssw_lib.py CSsw (sLibPath = directory holding libssw.so)."""
+
+    def __init__(self, sLibPath=None):
+        path = os.path.join(sLibPath, "libssw.so") if sLibPath else None
+        self.ssw = load(path)
+        self.ssw_init = self.ssw.ssw_init
+        self.init_destroy = self.ssw.init_destroy
+        self.ssw_align = self.ssw.ssw_align
+        self.align_destroy = self.ssw.align_destroy
+
+
+class Seqs(object):
+    def __init__(self, ctx, seqs):
+        self.ctx = ctx
+        self.count = len(seqs)
+        off = np.zeros(self.count + 1, dtype=np.int64)
+        for i, s in enumerate(seqs):
+            off[i + 1] = off[i] + len(s)
+        codes = (np.concatenate([np.asarray(s, dtype=np.int8) for s in seqs]) if self.count else
+                 np.zeros(0, dtype=np.int8))
+        codes = np.ascontiguousarray(codes, dtype=np.int8)
+        self.lengths = np.diff(off)
+        self.h = ctx.lib.ssw_gpu_seqs_upload(ctx.h, codes.ctypes.data_as(_i8p), off.ctypes.data_as(_i64p), self.count)
+        if not self.h:
+            raise RuntimeError("ssw_gpu_seqs_upload: " + ctx.error())
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.ssw_gpu_seqs_free(self.h)
+            self.h = None
+
+
+class Context(object):
+    """One GPU (include/ssw_gpu.h ssw_gpu_ctx)."""
+
+    def __init__(self, device=0, lib=None):
+        self.lib = lib if lib is not None and not isinstance(lib, str) else load(lib)
+        self.h = self.lib.ssw_gpu_open(device)
+        if not self.h:
+            raise RuntimeError("ssw_gpu_open: " + self.lib.ssw_gpu_last_error(None).decode())
+
+    def error(self):
+        return self.lib.ssw_gpu_last_error(self.h).decode()
+
+    def upload(self, seqs):
+        return Seqs(self, seqs)
+
+    def align_batch(self, queries, targets, mat, n, gapO=3, gapE=1, flag=0, filters=0, filterd=0, maskLen=-1,
+                    score_size=2, target_first=0, target_count=None, want_cigar=True):
+        """-> (numpy record array [nq, nt] of RESULT_DTYPE, numpy uint32 CIGAR pool)."""
+        if target_count is None:
+            target_count = targets.count - target_first
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        p = Params(mat.ctypes.data_as(_i8p), n, gapO, gapE, flag, filters, filterd, maskLen, score_size)
+        res = np.zeros((queries.count, target_count), dtype=RESULT_DTYPE)
+        pool = _u32p()
+        words = C.c_int64(0)
+        rc = self.lib.ssw_gpu_align_batch(self.h, queries.h, targets.h, target_first, target_count, C.byref(p),
+                                          res.ctypes.data_as(C.c_void_p), C.byref(pool) if want_cigar else None,
+                                          C.byref(words))
+        if rc != 0:
+            raise RuntimeError("ssw_gpu_align_batch: " + self.error())
+        if want_cigar and words.value > 0:
+            cig = np.ctypeslib.as_array(pool, shape=(words.value,)).copy()
+        else:
+            cig = np.zeros(0, dtype=np.uint32)
+        if want_cigar and pool:
+            C.CDLL(None).free(pool)
+        return res, cig
+
+    def timing(self):
+        t = Timing()
+        self.lib.ssw_gpu_last_timing(self.h, C.byref(t))
+        return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def close(self):
+        if self.h:
+            self.lib.ssw_gpu_close(self.h)
+            self.h = None

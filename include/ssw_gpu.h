@@ -1,0 +1,101 @@
+/*
+ * ssw_gpu.h -- batch entry points of the MI355X-native Smith-Waterman library.
+ *
+ * The reference library aligns ONE (query, target) pair per synchronous call
+ * (reference src/ssw.h:126-134); its callers loop "for each read: ssw_init; for
+ * each target: ssw_align" (reference src/main.c:462-526, src/pyssw.py:120-142,
+ * src/ssw_cpp.cpp:319-357).  This header is what such a loop binds instead when
+ * it wants GPU throughput: the same parameters, applied to a whole batch of
+ * device-resident queries x targets, returning one s_align-equivalent record per
+ * pair in the caller's loop order (query-major: reads outer, targets inner).
+ * ssw.h's single-pair functions are implemented on top of this path.
+ *
+ * Plain C ABI: pointers and sizes only.  All functions return 0 on success and a
+ * negative value on failure (ssw_gpu_last_error() has the text); there is no CPU
+ * fallback -- without a usable gfx950 device every entry point fails.
+ */
+#ifndef SSW_GPU_H
+#define SSW_GPU_H
+
+#include <stdint.h>
+#include "ssw.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ssw_gpu_ctx ssw_gpu_ctx;    /* one device + its streams/workspaces */
+typedef struct ssw_gpu_seqs ssw_gpu_seqs;  /* a set of residue-code sequences resident in HBM */
+
+/* Scoring / reporting parameters: the arguments of reference ssw_init + ssw_align
+   (src/ssw.h:86, 126-134) that are not the sequences themselves. */
+typedef struct {
+	const int8_t* mat;   /* n*n scores, mat[target_code*n + read_code] (host pointer) */
+	int32_t n;
+	uint8_t gapO;        /* weight_gapO */
+	uint8_t gapE;        /* weight_gapE */
+	uint8_t flag;        /* as ssw_align */
+	uint16_t filters;
+	int32_t filterd;
+	int32_t maskLen;     /* >= 0: used for every query; < 0: readLen/2 per query (reference src/main.c:464) */
+	int8_t score_size;   /* as ssw_init: 0, 1 or 2 */
+} ssw_gpu_params;
+
+/* One alignment: the fields of s_align (reference src/ssw.h:55-66) with the CIGAR
+   held in a shared pool instead of a per-result pointer. */
+typedef struct {
+	uint16_t score1;
+	uint16_t score2;
+	int32_t ref_begin1;
+	int32_t ref_end1;
+	int32_t read_begin1;
+	int32_t read_end1;
+	int32_t ref_end2;
+	int32_t cigarLen;    /* 0: no path */
+	int64_t cigar_off;   /* first word of this CIGAR in the pool returned by ssw_gpu_align_batch */
+	uint16_t flag;       /* as s_align.flag */
+	uint16_t status;     /* 0 ok; 1 the reference returns NULL here (8-bit overflow with score_size 0) */
+} ssw_gpu_result;
+
+/* Per-phase device time of the last batch call, from HIP events on the library's stream. */
+typedef struct {
+	double total_ms;       /* first launch .. results on host */
+	double fill_ms;        /* sum over forward-fill kernel launches */
+	int64_t fill_launches;
+	int64_t fill_cells;    /* DP cells actually evaluated by the fill kernel (padding + halo included) */
+	int64_t cells;         /* sum of readLen*refLen over the batch (the GCUPS numerator) */
+	double reduce_ms;      /* score1/score2/end-position reduction */
+	double locate_ms;      /* read_end1 + reverse (begin position) passes */
+	double trace_ms;       /* banded traceback + CIGAR re-score */
+	int64_t n_word;        /* alignments decided under 16-bit semantics */
+	int64_t n_byte;        /* alignments decided under 8-bit semantics */
+} ssw_gpu_timing;
+
+int ssw_gpu_device_count(void);
+ssw_gpu_ctx* ssw_gpu_open(int device);          /* NULL on failure */
+void ssw_gpu_close(ssw_gpu_ctx* ctx);
+const char* ssw_gpu_last_error(const ssw_gpu_ctx* ctx);   /* ctx may be NULL: error of the last failed open */
+
+/* Upload `count` sequences: codes of sequence i are codes[offsets[i] .. offsets[i+1]). */
+ssw_gpu_seqs* ssw_gpu_seqs_upload(ssw_gpu_ctx* ctx, const int8_t* codes, const int64_t* offsets, int32_t count);
+void ssw_gpu_seqs_free(ssw_gpu_seqs* s);
+int32_t ssw_gpu_seqs_count(const ssw_gpu_seqs* s);
+
+/*
+ * Align every query to targets [target_first, target_first + target_count).
+ * results[q * target_count + t] receives the record of (query q, target target_first + t).
+ * cigar_pool (optional) receives a malloc()ed array of *cigar_words BAM-packed words (caller frees).
+ */
+int ssw_gpu_align_batch(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* queries, const ssw_gpu_seqs* targets,
+                        int32_t target_first, int32_t target_count, const ssw_gpu_params* params,
+                        ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words);
+
+int ssw_gpu_last_timing(const ssw_gpu_ctx* ctx, ssw_gpu_timing* out);
+
+/* Convert one batch record into a heap s_align (align_destroy()-compatible), copying its CIGAR. */
+s_align* ssw_gpu_result_to_align(const ssw_gpu_result* r, const uint32_t* cigar_pool);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSW_GPU_H */

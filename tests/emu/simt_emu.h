@@ -1,0 +1,134 @@
+/*
+ * tests/emu/simt_emu.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A small fibre-based SIMT emulator: every GPU thread of one workgroup is a
+ * cooperative fibre on a single OS thread; cross-lane operations (DPP moves,
+ * shuffles, votes) and __syncthreads() are rendez-vous points.  It lets the
+ * unmodified kernel source (csrc/ssw_kernels.hip, compiled as C++ with
+ * -DSSW_SIMT_EMU) run in the CPU-only build container so that index math, skew,
+ * rings and tile seams are debugged before GPU minutes are spent.  It is slow by
+ * design and is never part of the product library.
+ *
+ * Semantics follow the gfx950 ISA: wave = 64 lanes, DPP rows = 16 lanes,
+ * row_shr:n reads lane i-n (out-of-row lanes: 0 with bound_ctrl, else the lane
+ * keeps `old`), row_ror:n reads lane (i-n) mod 16.
+ */
+#ifndef SIMT_EMU_H
+#define SIMT_EMU_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __restrict__
+#define SSW_DEV static inline
+
+namespace emu {
+
+struct dim3_t { unsigned x, y, z; };
+
+struct Wave {
+	int live, arrived, gen;
+	uint32_t slot[2][64];
+};
+
+struct Block {
+	int live, arrived, gen;
+	unsigned char* lds;
+	size_t lds_bytes;
+};
+
+struct Fiber {
+	void* sp;
+	unsigned char* stack;
+	int tid, lane, done;
+	Wave* wave;
+};
+
+extern Fiber* cur;
+extern Block blk;
+extern dim3_t block_idx, block_dim, grid_dim;
+
+void yield();
+void wave_sync();
+void block_sync();
+[[noreturn]] void fail(const char* msg);
+
+inline uint32_t exchange(uint32_t v, int src_lane, bool valid, uint32_t other)
+{
+	Wave* w = cur->wave;
+	int g = w->gen & 1;
+	w->slot[g][cur->lane] = v;
+	wave_sync();
+	return valid ? w->slot[g][src_lane] : other;
+}
+
+typedef void (*kernel_thunk)(void* args);
+/* runs fn(args) for every thread of every block, blocks one after another */
+void launch(kernel_thunk fn, void* args, unsigned grid, unsigned block, size_t lds_bytes);
+
+} // namespace emu
+
+struct emu_tid3 { unsigned x, y, z; };
+#define threadIdx (emu_tid3{(unsigned)emu::cur->tid, 0u, 0u})
+#define blockIdx (emu::block_idx)
+#define blockDim (emu::block_dim)
+#define gridDim (emu::grid_dim)
+#define __syncthreads() emu::block_sync()
+#define SSW_DYN_LDS(name) unsigned char* name = emu::blk.lds
+
+typedef uint32_t u32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+SSW_DEV u32 xl_row_shr1_zero(u32 v)
+{
+	int l = emu::cur->lane;
+	return emu::exchange(v, l - 1, (l & 15) != 0, 0u);
+}
+SSW_DEV u32 xl_row_shr1_keep(u32 keep, u32 v)
+{
+	int l = emu::cur->lane;
+	return emu::exchange(v, l - 1, (l & 15) != 0, keep);
+}
+template <int N> SSW_DEV u32 xl_row_ror(u32 v)
+{
+	int l = emu::cur->lane;
+	return emu::exchange(v, (l & ~15) | ((l - N) & 15), true, 0u);
+}
+SSW_DEV u32 xl_shfl(u32 v, int src_lane) { return emu::exchange(v, src_lane & 63, true, 0u); }
+SSW_DEV bool wave_any(bool p)
+{
+	emu::Wave* w = emu::cur->wave;
+	int g = w->gen & 1;
+	w->slot[g][emu::cur->lane] = p ? 1u : 0u;
+	emu::wave_sync();
+	/* finished lanes left stale slots: only count lanes of this wave that are still alive via their own writes */
+	bool r = false;
+	for (int i = 0; i < 64; ++i) r = r || (w->slot[g][i] & 1u);
+	return r;
+}
+SSW_DEV bool wave_all(bool p) { return !wave_any(!p); }
+SSW_DEV void wave_lds_fence() { emu::wave_sync(); }
+
+static inline void emu_lds_check(u32 off, u32 bytes, u32 align, const char* what)
+{
+	if ((off % align) != 0 || (size_t)off + bytes > emu::blk.lds_bytes) {
+		char m[160];
+		snprintf(m, sizeof m, "LDS %s: offset %u (size %u, align %u) outside/unaligned in %zu-byte segment", what, off, bytes, align, emu::blk.lds_bytes);
+		emu::fail(m);
+	}
+}
+SSW_DEV u32x4 lds_ld128(const unsigned char* lds, u32 off) { emu_lds_check(off, 16, 16, "ld128"); u32x4 v; memcpy(&v, lds + off, 16); return v; }
+SSW_DEV u32 lds_ld32(const unsigned char* lds, u32 off) { emu_lds_check(off, 4, 4, "ld32"); u32 v; memcpy(&v, lds + off, 4); return v; }
+SSW_DEV u32 lds_ld16(const unsigned char* lds, u32 off) { emu_lds_check(off, 2, 2, "ld16"); uint16_t v; memcpy(&v, lds + off, 2); return v; }
+SSW_DEV void lds_st32(unsigned char* lds, u32 off, u32 v) { emu_lds_check(off, 4, 4, "st32"); memcpy(lds + off, &v, 4); }
+SSW_DEV void lds_st16(unsigned char* lds, u32 off, u32 v) { emu_lds_check(off, 2, 2, "st16"); uint16_t h = (uint16_t)v; memcpy(lds + off, &h, 2); }
+
+#endif /* SIMT_EMU_H */
