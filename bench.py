@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- GCUPS of the Smith-Waterman hot path (BASELINE.json metric) on N MI355X of one node.
+
+A "step" is one pass of the whole hot path (forward fill + reduction + read_end1 location) over one batch of
+synthetic reads that is already resident in HBM:  BASELINE config 2 -- 100k x 150 bp DNA reads (sampled from the
+target, ~3% substitutions, ~1% indels, 5% random reads) against a 1 Mb random target, match 2 / mismatch -2 /
+gap open 3 / gap extension 1, score_size 2 (8-bit rules with 16-bit fallback), score-only (flag 0) like the
+reference CLI's default run.  With N > 1 every rank aligns its own 100k-read shard against a replicated target
+(no collective on the data path): weak scaling.  GCUPS counts readLen x refLen of the forward matrix only.
+
+Prints ONE JSON line (rank 0).  Besides the contract fields it carries
+  roofline      HBM view of the dominant kernel (k_fill): algorithmic bytes per launch / measured launch time
+  roofline_valu the binding roofline of this integer max-plus recurrence: packed-int16 VALU issue rate
+  cpu_baseline  the unmodified reference (oracle/_ref, its SSE2 path) timed on this host's cores on a bounded sample
+  parity        the same sample compared bit-exactly with the GPU results of the timed batch
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "complete-striped-smith-waterman-library_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9    # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6e12 lane-ops/s (= the FP32 vector FMA rate)
+
+
+def make_reads_fast(ref, nreads, length, seed, sub=0.03, ins=0.005, dele=0.005, frac_random=0.05):
+    """vectorised version of tests/sswutil.sample_reads (same model, different stream): [nreads, length] int8"""
+    rng = np.random.default_rng(seed)
+    span = length + 32
+    off = rng.integers(0, len(ref) - span, size=nreads)
+    is_ins = rng.random((nreads, length)) < ins
+    is_del = (rng.random((nreads, length)) < dele) & ~is_ins
+    consumed = np.cumsum(~is_ins, axis=1) - 1
+    deleted = np.cumsum(is_del, axis=1)
+    src = off[:, None] + np.clip(consumed + deleted, 0, span - 1)
+    reads = ref[src]
+    rnd = rng.integers(0, 4, size=(nreads, length), dtype=np.int8)
+    reads = np.where(is_ins, rnd, reads)
+    do_sub = rng.random((nreads, length)) < sub
+    reads = np.where(do_sub, (reads + 1 + rng.integers(0, 3, size=(nreads, length))) % 4, reads)
+    whole = rng.random(nreads) < frac_random
+    reads[whole] = rnd[whole]
+    return np.ascontiguousarray(reads, dtype=np.int8)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU and step (config 2: 100k)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--ref-len", type=int, default=1_000_000)
+    ap.add_argument("--flag", type=int, default=0, help="ssw_align flag (0 = scores + end positions; 2 = + begin + CIGAR)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the CPU-baseline sample (-1: ~20 s of work; 0: skip)")
+    ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)   # tests point this at the emulated library
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:
+        # One process per GPU.  The data path has no collective (reads are sharded, the target is replicated), so the
+        # only cross-rank traffic is the timing barrier + MAX: it runs over gloo on CPU tensors, which keeps torch's own
+        # HIP runtime out of the processes' data path (libssw.so drives its GPU through its own stream).
+        # SSW_BENCH_BACKEND=nccl switches the barrier to RCCL.
+        import torch
+        import torch.distributed as dist_mod
+        backend = os.environ.get("SSW_BENCH_BACKEND", "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group(backend=backend)
+        dist = dist_mod
+    ngpus = world
+    if args.gpus != ngpus and world == 1 and args.gpus > 1:
+        print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus),
+              file=sys.stderr)
+        sys.exit(2)
+
+    import ssw_amd
+    from sswutil import dna_matrix, random_ref
+    lib = ssw_amd.load(args.lib)
+    if lib.ssw_gpu_device_count() < 1:
+        raise RuntimeError("bench.py: no HIP device visible; libssw.so has no CPU path")
+    ndev = lib.ssw_gpu_device_count()
+    ctx = ssw_amd.Context(local_rank % ndev, lib)
+
+    mat = dna_matrix(2, 2)
+    ref = random_ref(args.ref_len, 1, 4)                                   # seed 1: BASELINE config 2
+    reads = make_reads_fast(ref, args.reads, args.read_len, seed=1000 + rank)
+    # upload through the packed form directly (a Python list of 100k arrays is slow to concatenate)
+    import ctypes as C
+    off = (np.arange(args.reads + 1, dtype=np.int64) * args.read_len)
+    qh = lib.ssw_gpu_seqs_upload(ctx.h, reads.ctypes.data_as(C.POINTER(C.c_int8)), off.ctypes.data_as(C.POINTER(C.c_int64)), args.reads)
+    if not qh:
+        raise RuntimeError(ctx.error())
+    Q = ssw_amd.Seqs.__new__(ssw_amd.Seqs); Q.ctx = ctx; Q.count = args.reads; Q.h = qh
+    T = ctx.upload([ref])
+
+    def step():
+        return ctx.align_batch(Q, T, mat, 5, 3, 1, args.flag, 0, 0, -1, 2, want_cigar=(args.flag & 7) != 0)
+
+    def sync_all():
+        # align_batch() returns only after its stream is synchronised and the results are on the host, so every rank is
+        # idle here; the barrier aligns the ranks' clocks around the timed region.
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    fill_ms = 0.0; fill_launches = 0; fill_cells = 0; phase = {"reduce_ms": 0.0, "locate_ms": 0.0, "trace_ms": 0.0, "total_ms": 0.0}
+    res = None
+    for _ in range(args.steps):
+        res, cig = step()            # align_batch returns with results on the host (stream synchronised inside)
+        tm = ctx.timing()
+        fill_ms += tm["fill_ms"]; fill_launches += tm["fill_launches"]; fill_cells += tm["fill_cells"]
+        for k in phase:
+            phase[k] += tm[k]
+    sync_all()
+    dt = time.perf_counter() - t0
+    tm = ctx.timing()
+    if dist is not None:
+        import torch
+        dev = "cuda" if os.environ.get("SSW_BENCH_BACKEND", "gloo") == "nccl" else "cpu"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    cells_per_step = float(args.reads) * args.read_len * args.ref_len
+    value = cells_per_step * args.steps * ngpus / dt / 1e9
+
+    out = None
+    if rank == 0:
+        launch_ms = fill_ms / max(1, fill_launches)
+        # algorithmic HBM bytes of one k_fill launch (SURVEY 8d / DESIGN.md): per alignment refLen target codes read,
+        # readLen + n^2 query/matrix bytes, 4*refLen column-maximum bytes written (2 rule sets x u16), 40 B result
+        aln_per_launch = args.reads * args.steps / max(1, fill_launches)
+        bytes_per_aln = args.ref_len + args.read_len + 25 + 40 + 4 * args.ref_len
+        achieved_gbs = aln_per_launch * bytes_per_aln / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        # VALU view: 9 packed instructions per (row, column) for two queries -> 4.5 lane-ops per evaluated cell
+        valu_ops = fill_cells * 4.5
+        achieved_valu = valu_ops / (fill_ms * 1e-3) if fill_ms > 0 else 0.0
+        probe = ctx.valu_probe(8192, 4000) if args.lib is None else 0.0   # (skipped on the test emulator)
+        out = {
+            "metric": "GCUPS", "value": round(value, 2), "unit": "GCUPS", "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16x2 (packed; reference u8/int16 semantics)", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: %dk x %d bp DNA reads vs %.1f Mb target per GPU, 2/-2/3/1, score_size 2, flag %d"
+                                   % (args.reads // 1000, args.read_len, args.ref_len / 1e6, args.flag),
+                       "reads_per_gpu": args.reads, "read_len": args.read_len, "ref_len": args.ref_len,
+                       "sharding": "reads sharded across ranks, target replicated, no collective"},
+            "mix": {"word_rules": int(tm["n_word"]), "byte_rules": int(tm["n_byte"])},
+            "phases_ms_per_step": {"fill": round(fill_ms / args.steps, 3), "locate": round(phase["locate_ms"] / args.steps, 3),
+                                   "trace": round(phase["trace_ms"] / args.steps, 3),
+                                   "reduce_and_copies": round(phase["reduce_ms"] / args.steps, 3)},
+            "roofline": {"bound": "hbm", "kernel": "k_fill<%d>" % ((args.read_len + 15) // 16), "achieved": round(achieved_gbs, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                         "launch_ms": round(launch_ms, 3), "launches": int(fill_launches),
+                         "note": "integer max-plus recurrence: HBM is not the binding resource, see roofline_valu"},
+            "roofline_valu": {"bound": "valu-int16x2", "achieved": round(achieved_valu / 1e12, 3), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
+                              "unit": "T lane-op/s", "frac": round(achieved_valu / VALU_PEAK_LANEOPS, 4),
+                              "measured_peak_probe": round(probe / 1e12, 2),
+                              "fill_gcups_padded": round(fill_cells / (fill_ms * 1e-3) / 1e9, 1) if fill_ms > 0 else 0.0},
+        }
+        # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) ----
+        if ngpus == 1 and args.cpu_sample != 0:
+            from sswutil import ref_lib, oracle_align, _ptr, i8p, i32p, i64p
+            cores = os.cpu_count() or 1
+            R = ref_lib()
+            if R is not None:
+                per_read_s = args.read_len * args.ref_len / 2.0e9            # ~2 GCUPS per core
+                ns = args.cpu_sample if args.cpu_sample > 0 else int(max(cores, min(args.reads, 20.0 * cores / per_read_s)))
+                ns = min(ns, args.reads)
+                sample = np.ascontiguousarray(reads[:ns])
+                soff = np.arange(ns + 1, dtype=np.int64) * args.read_len
+                cres = np.zeros((ns, 10), dtype=np.int32)
+                secs = R.refwrap_bench(_ptr(sample, i8p), _ptr(soff, i64p), ns, _ptr(ref, i8p), len(ref), _ptr(mat, i8p), 5, 3, 1,
+                                       args.flag, 0, 0, -1, cores, _ptr(cres, i32p))
+                cpu_gcups = ns * args.read_len * args.ref_len / secs / 1e9
+                g = res[:ns, 0]
+                got = np.stack([g["score1"], g["score2"], g["ref_begin1"], g["ref_end1"], g["read_begin1"], g["read_end1"], g["ref_end2"],
+                                g["cigarLen"], g["flag"]], axis=1).astype(np.int32)
+                mism = int((got != cres[:, :9]).any(axis=1).sum())
+                out["cpu_baseline"] = {"value": round(cpu_gcups, 2), "unit": "GCUPS", "cores": cores, "kind": "reference",
+                                       "per_core": round(cpu_gcups / cores, 2),
+                                       "sample": "first %d reads of the batch vs the same target, ssw_init(...,2)+ssw_align through the C API, "
+                                                 "reference ssw.c built -O2 (oracle/_ref), one thread per core, %.1f s" % (ns, secs)}
+                out["parity"] = {"sample": ns, "mismatching_alignments": mism, "fields": "score1 score2 ref/read begin/end ref_end2 cigarLen flag"}
+            else:
+                ns = args.cpu_sample if args.cpu_sample > 0 else 2
+                t1 = time.perf_counter()
+                mism = 0
+                for i in range(ns):
+                    d, _ = oracle_align(reads[i], mat, 5, ref, 3, 1, args.flag, 0, 0, args.read_len // 2, 2, 0)
+                    g = res[i, 0]
+                    mism += any(int(g[k]) != d[k] for k in ("score1", "score2", "ref_end1", "read_end1", "ref_end2"))
+                secs = time.perf_counter() - t1
+                out["cpu_baseline"] = {"value": round(ns * args.read_len * args.ref_len / secs / 1e9, 3), "unit": "GCUPS", "cores": 1,
+                                       "kind": "port", "sample": "%d reads, scalar lane-model oracle (oracle/_ref not shipped)" % ns}
+                out["parity"] = {"sample": ns, "mismatching_alignments": mism}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    dump = os.environ.get("SSW_BENCH_DUMP")
+    if dump:   # tests: keep every rank's shard and results for an independent check
+        np.savez(os.path.join(dump, "rank%d.npz" % rank), reads=reads, ref=ref, res=res)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    Q.free(); T.free(); ctx.close()
+    return out, res
+
+
+if __name__ == "__main__":
+    main()

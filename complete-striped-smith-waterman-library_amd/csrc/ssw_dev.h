@@ -117,6 +117,14 @@ typedef struct {
 	int32_t nq;
 } ssw_gather_args;
 
+/* device self-test: cross-lane primitive semantics + packed-int16 VALU issue-rate probe */
+typedef struct {
+	uint32_t* lanes_out;     /* 9 x 64 words, may be NULL */
+	uint32_t* sink;          /* one word per thread, may be NULL */
+	int32_t iters;           /* each iteration issues 96 packed 16-bit VALU instructions per wavefront */
+	uint32_t seed;
+} ssw_selftest_args;
+
 /* ---- thin C shim over the HIP runtime + kernel launches (implemented in ssw_kernels.hip) ---- */
 int   ssw_shim_device_count(void);
 int   ssw_shim_set_device(int dev);
@@ -140,6 +148,7 @@ int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream);
 int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* stream);
 int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);
 int ssw_shim_launch_gather(const ssw_gather_args* a, void* stream);
+int ssw_shim_launch_selftest(const ssw_selftest_args* a, int blocks, void* stream);
 
 #ifdef __cplusplus
 }

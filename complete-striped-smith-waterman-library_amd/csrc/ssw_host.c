@@ -88,7 +88,8 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
 	c->ev_c = ssw_shim_event_create(); c->ev_d = ssw_shim_event_create();
 	if (!c->stream || !c->ev_t0 || !c->ev_d) { fail(0, "stream/event creation failed: %s", ssw_shim_last_error()); free(c); return 0; }
 	const char* e = getenv("SSW_GPU_CM_BUDGET_MB");
-	c->cm_budget = e ? (size_t)atoll(e) << 20 : (size_t)24 << 30;
+	c->cm_budget = e ? (size_t)atoll(e) << 20 : (size_t)64 << 30;
+	if (!e) { size_t fr = ssw_shim_mem_free_bytes(); if (fr && c->cm_budget > fr / 2) c->cm_budget = fr / 2; }
 	return c;
 }
 
@@ -427,6 +428,40 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 done:
 	free(pool); free(order); free(pairs); free(hres); free(hneed);
 	return rc;
+}
+
+int ssw_gpu_selftest_lanes(ssw_gpu_ctx* c, uint32_t* out576)
+{
+	if (!c || !out576) return -1;
+	ssw_shim_set_device(c->device);
+	uint32_t* d = (uint32_t*)ssw_shim_malloc(576 * 4);
+	if (!d) return fail(c, "device allocation failed: %s", ssw_shim_last_error());
+	ssw_selftest_args a; a.lanes_out = d; a.sink = 0; a.iters = 0; a.seed = 0;
+	int rc = ssw_shim_launch_selftest(&a, 1, c->stream) || ssw_shim_d2h(out576, d, 576 * 4, c->stream) || ssw_shim_stream_sync(c->stream);
+	ssw_shim_free(d);
+	return rc ? fail(c, "selftest failed: %s", ssw_shim_last_error()) : 0;
+}
+
+/* measured packed-int16 VALU rate of the device in lane-operations per second (both 16-bit halves count as one) */
+double ssw_gpu_valu_probe(ssw_gpu_ctx* c, int32_t blocks, int32_t iters)
+{
+	if (!c || blocks < 1 || iters < 1) return -1.0;
+	ssw_shim_set_device(c->device);
+	uint32_t* sink = (uint32_t*)ssw_shim_malloc((size_t)blocks * 256 * 4);
+	if (!sink) return -1.0;
+	ssw_selftest_args a; a.lanes_out = 0; a.sink = sink; a.iters = iters; a.seed = 0x00030001u;
+	double best = -1.0;
+	for (int rep = 0; rep < 3; ++rep) {
+		ssw_shim_event_record(c->ev_a, c->stream);
+		if (ssw_shim_launch_selftest(&a, blocks, c->stream)) break;
+		ssw_shim_event_record(c->ev_b, c->stream);
+		if (ssw_shim_stream_sync(c->stream)) break;
+		double ms = ssw_shim_event_elapsed_ms(c->ev_a, c->ev_b);
+		double rate = (double)blocks * 256.0 * iters * 96.0 / (ms * 1e-3);
+		if (rate > best) best = rate;
+	}
+	ssw_shim_free(sink);
+	return best;
 }
 
 s_align* ssw_gpu_result_to_align(const ssw_gpu_result* r, const uint32_t* cigar_pool)

@@ -549,6 +549,42 @@ __global__ void __launch_bounds__(256) k_gather(ssw_gather_args a)
 	for (int i = 0; i < len; ++i) dst[i] = src[i];
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * k_selftest: (a) the cross-lane primitives applied to the lane id, so that tests can pin the DPP semantics the
+ * chains rely on (and that the CPU emulator assumes) on real hardware; (b) a packed-int16 VALU issue-rate probe
+ * (8 independent v_pk_add_i16/v_pk_max_i16/v_pk_sub_u16 chains) whose measured rate is the roofline's "peak".
+ * ------------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(256) k_selftest(ssw_selftest_args a)
+{
+	const u32 tid = (u32)threadIdx.x, gid = (u32)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (a.lanes_out && blockIdx.x == 0 && tid < 64) {
+		const u32 v = 100u + tid;
+		a.lanes_out[0 * 64 + tid] = xl_row_shr1_zero(v);
+		a.lanes_out[1 * 64 + tid] = xl_row_shr1_keep(7000u + tid, v);
+		a.lanes_out[2 * 64 + tid] = xl_row_ror<1>(v);
+		a.lanes_out[3 * 64 + tid] = xl_row_ror<2>(v);
+		a.lanes_out[4 * 64 + tid] = xl_row_ror<8>(v);
+		a.lanes_out[5 * 64 + tid] = xl_shfl(v, (int)((tid + 16) & 63));
+		a.lanes_out[6 * 64 + tid] = pk_adds(pk_make(30000, -30000), pk_make((int)tid * 100, -(int)tid * 100));
+		a.lanes_out[7 * 64 + tid] = pk_subu(pk_make((int)tid, 5), pk_make(10, (int)tid));
+		a.lanes_out[8 * 64 + tid] = pk_max(pk_make((int)tid - 32, 3), pk_make(0, (int)tid - 60));
+	}
+	if (a.iters > 0) {
+		u32 x0 = gid, x1 = gid * 3u, x2 = gid * 5u, x3 = gid * 7u, x4 = gid * 11u, x5 = gid * 13u, x6 = gid * 17u, x7 = gid * 19u;
+		const u32 g = a.seed;
+		for (int it = 0; it < a.iters; ++it) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {   /* 8 chains x 3 packed ops x 4 = 96 VOP3P per iteration */
+				x0 = pk_max(pk_subu(pk_adds(x0, g), g), x0); x1 = pk_max(pk_subu(pk_adds(x1, g), g), x1);
+				x2 = pk_max(pk_subu(pk_adds(x2, g), g), x2); x3 = pk_max(pk_subu(pk_adds(x3, g), g), x3);
+				x4 = pk_max(pk_subu(pk_adds(x4, g), g), x4); x5 = pk_max(pk_subu(pk_adds(x5, g), g), x5);
+				x6 = pk_max(pk_subu(pk_adds(x6, g), g), x6); x7 = pk_max(pk_subu(pk_adds(x7, g), g), x7);
+			}
+		}
+		if (a.sink) a.sink[gid] = x0 ^ x1 ^ x2 ^ x3 ^ x4 ^ x5 ^ x6 ^ x7;
+	}
+}
+
 /* ================================================================================================
  * launchers (the thin C shim of SURVEY 8b: host code stays C)
  * ================================================================================================ */
@@ -565,8 +601,14 @@ static int shim_check(hipError_t e, const char* what)
 	snprintf(g_shim_err, sizeof g_shim_err, "%s: %s", what, hipGetErrorString(e));
 	return -1;
 }
+/* dynamic LDS above 64 KiB (large protein profiles: up to 160 KiB per workgroup on gfx950) needs an opt-in per kernel */
+template <class K> static void shim_allow_lds(K kern, size_t bytes)
+{
+	if (bytes > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 #define SSW_LAUNCH(kern, A, args, grid, block, ldsbytes, stream) \
-	hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(ldsbytes), (hipStream_t)(stream), args)
+	do { shim_allow_lds(kern, (size_t)(ldsbytes)); \
+	     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(ldsbytes), (hipStream_t)(stream), args); } while (0)
 #define SSW_LAUNCH_OK() shim_check(hipGetLastError(), "kernel launch")
 #endif
 
@@ -616,6 +658,13 @@ extern "C" int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream)
 	ssw_trace_args args = *a;
 	if (args.nq <= 0) return 0;
 	SSW_LAUNCH(k_trace, ssw_trace_args, args, (args.nq + 63) / 64, 64, 0, stream);
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_launch_selftest(const ssw_selftest_args* a, int blocks, void* stream)
+{
+	ssw_selftest_args args = *a;
+	SSW_LAUNCH(k_selftest, ssw_selftest_args, args, blocks, 256, 0, stream);
 	return SSW_LAUNCH_OK();
 }
 

@@ -89,6 +89,10 @@ def load(path=None):
     L.ssw_gpu_align_batch.restype = C.c_int
     L.ssw_gpu_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.ssw_gpu_last_timing.restype = C.c_int
+    L.ssw_gpu_selftest_lanes.argtypes = [C.c_void_p, _u32p]
+    L.ssw_gpu_selftest_lanes.restype = C.c_int
+    L.ssw_gpu_valu_probe.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.ssw_gpu_valu_probe.restype = C.c_double
     return L
 
 
@@ -167,6 +171,15 @@ class Context(object):
         t = Timing()
         self.lib.ssw_gpu_last_timing(self.h, C.byref(t))
         return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def selftest_lanes(self):
+        out = np.zeros((9, 64), dtype=np.uint32)
+        if self.lib.ssw_gpu_selftest_lanes(self.h, out.ctypes.data_as(_u32p)) != 0:
+            raise RuntimeError("ssw_gpu_selftest_lanes: " + self.error())
+        return out
+
+    def valu_probe(self, blocks=4096, iters=2000):
+        return float(self.lib.ssw_gpu_valu_probe(self.h, blocks, iters))
 
     def close(self):
         if self.h:

@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors from the UNMODIFIED reference (oracle/_ref/libssw_ref.so,
+built by oracle/Makefile from /root/reference/src/ssw.c) and from the reference's demo data.
+
+Run in the build container (needs /root/reference):   python tests/golden/make_golden.py
+
+Outputs (committed; the GPU box has no /root/reference):
+  tests/golden/golden_small.json   demo pairs + seeded random/adversarial cases: inputs, parameters and the
+                                   reference's s_align fields + CIGAR words
+  tests/golden/chr3_1M.npz         the demo target demo/1M.fa (codes, 1 MB -> ~250 KB compressed), the 100 demo
+                                   54-mers and the numbers of demo/new.txt (the reference's own golden stdout)
+"""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from sswutil import (RES_FIELDS, blosum50, dna_matrix, encode_aa, encode_dna, mutate, random_ref,  # noqa: E402
+                     ref_align)
+
+DEMO = "/root/reference/demo"
+
+
+def read_fx(path):
+    """minimal FASTA/FASTQ reader -> [(name, seq)]"""
+    out, name, seq, mode = [], None, [], None
+    with open(path) as f:
+        lines = [l.rstrip("\n") for l in f]
+    i = 0
+    while i < len(lines):
+        l = lines[i]
+        if l.startswith(">"):
+            if name is not None:
+                out.append((name, "".join(seq)))
+            name, seq, mode = l[1:].split()[0] if len(l) > 1 else "", [], "fa"
+        elif l.startswith("@") and mode != "fa":
+            if name is not None:
+                out.append((name, "".join(seq)))
+            name, seq = l[1:].split()[0], [lines[i + 1]]
+            i += 3
+            mode = "fq"
+        elif mode == "fa" and l:
+            seq.append(l)
+        i += 1
+    if name is not None:
+        out.append((name, "".join(seq)))
+    return out
+
+
+def case(name, kind, read, ref, mat, n, gapO, gapE, flag, filters, filterd, maskLen, score_size=2):
+    d, cig = ref_align(read, mat, n, ref, gapO, gapE, flag, filters, filterd, maskLen, score_size)
+    return {"name": name, "kind": kind, "read": [int(x) for x in read], "ref": [int(x) for x in ref],
+            "mat": [int(x) for x in mat], "n": n, "gapO": gapO, "gapE": gapE, "flag": flag, "filters": filters,
+            "filterd": filterd, "maskLen": maskLen, "score_size": score_size,
+            "expect": None if d is None else {k: d[k] for k in RES_FIELDS}, "cigar": cig}
+
+
+def main():
+    cases = []
+    dna = dna_matrix(2, 2)
+    b50 = blosum50()
+    # 1. the known-answer pair of reference src/example.c:105-156 (2/-2/3/1, maskLen 15, flag 1)
+    cases.append(case("example_c", "dna", encode_dna("CTGAGCCGGTAAATC"),
+                      encode_dna("CAGCCTTTCTGACCCGGAAATCAAAATAGGCACAACAAA"), dna_matrix(2, 2), 5, 3, 1, 1, 0, 0, 15))
+    # 2. BASELINE config 1: demo/target.fastq x demo/query.fastq, as ssw_test -c does (flag 2, maskLen readLen/2)
+    tg = read_fx(os.path.join(DEMO, "target.fastq"))
+    qs = read_fx(os.path.join(DEMO, "query.fastq"))
+    for qn, q in qs:
+        for tn, t in tg:
+            for flag in (0, 2):
+                cases.append(case("config1:%s:%s:flag%d" % (qn, tn, flag), "dna", encode_dna(q), encode_dna(t), dna, 5, 3, 1,
+                                  flag, 0, 0, len(q) // 2))
+    # 3. protein demo (ssw_test -p -c): BLOSUM50, 3/1
+    p1 = read_fx(os.path.join(DEMO, "protein1.fa"))[0][1]
+    p2 = read_fx(os.path.join(DEMO, "protein2.fa"))[0][1]
+    cases.append(case("protein1x2", "aa", encode_aa(p2), encode_aa(p1), b50, 24, 3, 1, 2, 0, 0, len(p2) // 2))
+    cases.append(case("protein2x1", "aa", encode_aa(p1), encode_aa(p2), b50, 24, 3, 1, 2, 0, 0, len(p1) // 2))
+    # 4. pRef / pRead, r1 (a 56-op CIGAR on the + strand), 1k.fa x query.fastq (README sample)
+    pr = read_fx(os.path.join(DEMO, "pRef.fa"))[0][1]
+    pq = read_fx(os.path.join(DEMO, "pRead.fa"))[0][1]
+    cases.append(case("pRef_pRead", "dna", encode_dna(pq), encode_dna(pr), dna, 5, 3, 1, 2, 0, 0, len(pq) // 2))
+    r1 = read_fx(os.path.join(DEMO, "r1.fa"))[0][1]
+    r1q = read_fx(os.path.join(DEMO, "r1_query.fq"))[0][1]
+    cases.append(case("r1_plus", "dna", encode_dna(r1q), encode_dna(r1), dna, 5, 3, 1, 2, 0, 0, len(r1q) // 2))
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    r1rc = "".join(comp.get(ch, "N") for ch in reversed(r1q.upper()))
+    cases.append(case("r1_minus", "dna", encode_dna(r1rc), encode_dna(r1), dna, 5, 3, 1, 2, 0, 0, len(r1q) // 2))
+    k1 = read_fx(os.path.join(DEMO, "1k.fa"))[0][1]
+    for qn, q in qs:
+        cases.append(case("1k:%s" % qn, "dna", encode_dna(q), encode_dna(k1), dna, 5, 3, 1, 2, 0, 0, len(q) // 2))
+
+    # 5. seeded random / adversarial cases (gapO > gapE: the GPU path's domain), all flags and score sizes
+    rng = np.random.default_rng(20250925)
+    for it in range(260):
+        if it % 4 != 3:
+            n, kind, nc = 5, "dna", 4
+            mat = dna_matrix(int(rng.integers(1, 4)), int(rng.integers(1, 6)))
+            refLen = int(rng.integers(30, 700))
+            ref = random_ref(refLen, int(rng.integers(1 << 30)), 4, 0.02)
+            if it % 16 == 0:   # low complexity: many ties
+                ref = np.tile(rng.integers(0, 4, size=int(rng.integers(1, 5)), dtype=np.int8), refLen)[:refLen]
+        else:
+            n, kind, nc = 24, "aa", 20
+            mat = b50
+            refLen = int(rng.integers(30, 400))
+            ref = rng.integers(0, 20, size=refLen, dtype=np.int8)
+        rl = int(rng.integers(4, 260))
+        if rng.random() < 0.75 and refLen > rl + 24:
+            off = int(rng.integers(0, refLen - rl - 16))
+            read = mutate(ref[off:off + rl + 8], rng, 0.06 if kind == "dna" else 0.2, 0.03, 0.03, nc)[:rl]
+            if len(read) < 4:
+                read = rng.integers(0, nc, size=rl, dtype=np.int8)
+        else:
+            read = rng.integers(0, nc, size=rl, dtype=np.int8)
+        gapE = int(rng.integers(1, 4))
+        gapO = gapE + int(rng.integers(1, 6))
+        flag = int(rng.choice([0, 1, 2, 8, 9, 15, 4, 6, 3]))
+        filters = int(rng.choice([0, 0, 25, 70]))
+        filterd = int(rng.choice([0, 25, 1000]))
+        maskLen = int(rng.choice([len(read) // 2, len(read) // 2, 15, 10, 40]))
+        ss = int(rng.choice([2, 2, 2, 0, 1]))
+        cases.append(case("rand%03d" % it, kind, read, ref, mat, n, gapO, gapE, flag, filters, filterd, maskLen, ss))
+    with open(os.path.join(HERE, "golden_small.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_golden.py", "source": "oracle/_ref/libssw_ref.so (reference ssw.c v1.2.6)",
+                   "cases": cases}, f, separators=(",", ":"))
+    print("golden_small.json:", len(cases), "cases")
+
+    # 6. the reference's own golden stdout: ssw_test demo/1M.fa demo/54mer_hap1_1.100.fastq == demo/new.txt
+    t = read_fx(os.path.join(DEMO, "1M.fa"))[0][1]
+    reads = read_fx(os.path.join(DEMO, "54mer_hap1_1.100.fastq"))
+    txt = open(os.path.join(DEMO, "new.txt")).read()
+    rows = re.findall(r"optimal_alignment_score: (\d+)\tsuboptimal_alignment_score: (\d+)\tstrand: (.)\ttarget_end: (\d+)\tquery_end: (\d+)", txt)
+    names = re.findall(r"query_name: (\S+)", txt)
+    assert len(rows) == len(reads) == 100 and names == [r[0] for r in reads]
+    expect = np.array([[int(a), int(b), int(d), int(e)] for a, b, c, d, e in rows], dtype=np.int32)   # 1-based ends as printed
+    # cross-check new.txt against the compiled reference through the C API before committing it
+    tcodes = encode_dna(t)
+    for i in (0, 1, 57, 99):
+        d, _ = ref_align(encode_dna(reads[i][1]), dna, 5, tcodes, 3, 1, 0, 0, 0, len(reads[i][1]) // 2)
+        assert [d["score1"], d["score2"], d["ref_end1"] + 1, d["read_end1"] + 1] == list(expect[i]), (i, d, expect[i])
+    np.savez_compressed(os.path.join(HERE, "chr3_1M.npz"), target=tcodes,
+                        reads=np.stack([encode_dna(r[1]) for r in reads]), expect=expect)
+    print("chr3_1M.npz: target", len(tcodes), "reads", len(reads))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""The REAL host driver (csrc/ssw_host.c) and the REAL kernel source (csrc/ssw_kernels.hip) executed on the
+CPU SIMT emulator (tests/emu) and compared with the reference / oracle, end to end through the batch C-ABI.
+This is how kernel logic is debugged without a GPU; the GPU runs of the same comparisons are in
+tests/test_gpu_parity.py.  CPU only, small sizes (the emulator is ~1000x slower than the device)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ssw_amd
+from parity import compare_batch, make_reads
+from sswutil import blosum50, dna_matrix, random_ref
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def ectx(emu_lib_path):
+    ctx = ssw_amd.Context(0, ssw_amd.load(emu_lib_path))
+    yield ctx
+    ctx.close()
+
+
+def _run(ctx, reads, refs, mat, n, gapO=3, gapE=1, flag=0, filters=0, filterd=0, maskLen=-1, ss=2):
+    Q = ctx.upload(reads); T = ctx.upload(refs)
+    try:
+        res, cig = ctx.align_batch(Q, T, mat, n, gapO, gapE, flag, filters, filterd, maskLen, ss)
+    finally:
+        Q.free(); T.free()
+    bad = compare_batch(res, cig, reads, refs, mat, n, gapO, gapE, flag, filters, filterd, maskLen, ss)
+    assert not bad, "\n".join(bad)
+    return res
+
+
+def test_score_only_mixed_lengths(ectx):
+    rng = np.random.default_rng(1)
+    ref = random_ref(700, 11, 4, 0.01)
+    reads = make_reads(rng, ref, 12, [150, 150, 54, 33, 100, 16, 17, 1, 8, 151, 160, 145], 4)
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5)
+
+
+@pytest.mark.parametrize("flag", [1, 2, 8, 9, 15, 6])
+def test_begin_and_cigar(ectx, flag):
+    rng = np.random.default_rng(20 + flag)
+    ref = random_ref(500, 12 + flag, 4, 0.01)
+    reads = make_reads(rng, ref, 10, rng.integers(10, 180, size=10), 4)
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=flag, filters=int(rng.choice([0, 40])), filterd=int(rng.choice([0, 60, 1000])))
+
+
+def test_protein_blosum50(ectx):
+    rng = np.random.default_rng(3)
+    ref = rng.integers(0, 20, size=260, dtype=np.int8)
+    reads = make_reads(rng, ref, 6, [60, 100, 33, 200, 129, 17], 20, sub=0.2)
+    _run(ectx, reads, [ref], blosum50(), 24, flag=2)
+
+
+def test_tiled_target_with_halo(ectx):
+    """target long enough that the fill kernel tiles it: every tile restarts `halo` columns early from zero."""
+    rng = np.random.default_rng(4)
+    ref = random_ref(60000, 13, 4, 0.001)
+    reads = make_reads(rng, ref, 5, [33, 40, 48, 20, 47], 4, frac_random=0.0)
+    res = _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
+    assert ectx.timing()["fill_cells"] > 60000 * 48 * 2   # halo columns were recomputed
+
+
+def test_multiple_targets_and_8bit_overflow_null(ectx):
+    rng = np.random.default_rng(5)
+    refs = [random_ref(int(L), 30 + i, 4, 0.0) for i, L in enumerate([300, 90, 411])]
+    reads = make_reads(rng, refs[0], 6, [150, 140, 30, 150, 149, 12], 4, sub=0.01, ins=0.0, dele=0.0, frac_random=0.0)
+    # score_size 0: clean 150-mers overflow 8 bits -> the reference returns NULL (status 1)
+    res = _run(ectx, reads, refs, dna_matrix(2, 2), 5, flag=1, ss=0)
+    assert (res["status"] == 1).any() and (res["status"] == 0).any()
+    _run(ectx, reads, refs, dna_matrix(2, 2), 5, flag=1, ss=1)
+
+
+def test_randomised_parameters(ectx):
+    rng = np.random.default_rng(6)
+    for _ in range(25):
+        kind = "dna" if rng.random() < 0.7 else "aa"
+        nq = int(rng.integers(1, 9))
+        refLen = int(rng.integers(10, 600))
+        if kind == "dna":
+            n, nc, mat = 5, 4, dna_matrix(int(rng.integers(1, 4)), int(rng.integers(1, 6)))
+            ref = random_ref(refLen, int(rng.integers(1 << 30)), 4, 0.02)
+        else:
+            n, nc, mat = 24, 20, blosum50()
+            ref = rng.integers(0, 20, size=refLen, dtype=np.int8)
+        gapE = int(rng.integers(1, 4)); gapO = gapE + int(rng.integers(1, 6))
+        reads = make_reads(rng, ref, nq, rng.integers(1, 200, size=nq), nc)
+        _run(ectx, reads, [ref], mat, n, gapO, gapE, flag=int(rng.choice([0, 1, 2, 8, 9, 15, 4, 6, 3])),
+             filters=int(rng.choice([0, 0, 30, 80])), filterd=int(rng.choice([0, 20, 1000])),
+             maskLen=int(rng.choice([-1, -1, 15, 10, 40])), ss=int(rng.choice([2, 2, 2, 0, 1])))
+
+
+def test_golden_small_through_emulated_library(ectx):
+    with open(os.path.join(HERE, "golden", "golden_small.json")) as f:
+        cases = json.load(f)["cases"]
+    from sswutil import RES_FIELDS
+    for c in cases[:60]:
+        read = np.array(c["read"], dtype=np.int8); ref = np.array(c["ref"], dtype=np.int8)
+        mat = np.array(c["mat"], dtype=np.int8)
+        Q = ectx.upload([read]); T = ectx.upload([ref])
+        res, cig = ectx.align_batch(Q, T, mat, c["n"], c["gapO"], c["gapE"], c["flag"], c["filters"], c["filterd"], c["maskLen"],
+                                    c["score_size"])
+        Q.free(); T.free()
+        g = res[0, 0]
+        if c["expect"] is None:
+            assert int(g["status"]) == 1, c["name"]
+        else:
+            assert {k: int(g[k]) for k in RES_FIELDS} == c["expect"], c["name"]
+            assert [int(x) for x in cig[int(g["cigar_off"]):int(g["cigar_off"]) + int(g["cigarLen"])]] == c["cigar"] or c["expect"]["cigarLen"] == 0
+
+
+def test_unsupported_parameters_fail_loudly(ectx):
+    ref = random_ref(100, 1, 4)
+    Q = ectx.upload([ref[:30]]); T = ectx.upload([ref])
+    with pytest.raises(RuntimeError, match="gap open > gap extension"):
+        ectx.align_batch(Q, T, dna_matrix(2, 2), 5, 1, 1)
+    Q2 = ectx.upload([np.zeros(500, dtype=np.int8)])
+    with pytest.raises(RuntimeError, match="query length"):
+        ectx.align_batch(Q2, T, dna_matrix(2, 2), 5, 3, 1)
+    Q.free(); Q2.free(); T.free()
+
+
+def test_single_pair_abi_on_emulator(emu_lib_path):
+    """ssw_init / ssw_align / align_destroy of ssw.h through ctypes, like the reference's src/pyssw.py does."""
+    import ctypes as C
+    from sswutil import encode_dna
+    lib = ssw_amd.load(emu_lib_path)
+    read = encode_dna("CTGAGCCGGTAAATC"); ref = encode_dna("CAGCCTTTCTGACCCGGAAATCAAAATAGGCACAACAAA"); mat = dna_matrix(2, 2)
+    i8p = C.POINTER(C.c_int8)
+    p = lib.ssw_init(read.ctypes.data_as(i8p), len(read), mat.ctypes.data_as(i8p), 5, 2)
+    a = lib.ssw_align(p, ref.ctypes.data_as(i8p), len(ref), 3, 1, 1, 0, 0, 15)
+    assert a
+    s = a.contents
+    assert (s.nScore, s.nScore2, s.nRefBeg, s.nRefEnd, s.nQryBeg, s.nQryEnd, s.nRefEnd2, s.nCigarLen) == (21, 8, 8, 21, 0, 14, 4, 3)
+    assert [s.sCigar[i] for i in range(3)] == [144, 17, 80]
+    lib.align_destroy(a); lib.init_destroy(p)

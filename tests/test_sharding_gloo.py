@@ -1,0 +1,43 @@
+"""The N > 1 path of bench.py (one process per GPU, reads sharded by rank, target replicated, barrier + MAX-over-ranks
+timing, rank 0 prints one JSON line) exercised with world_size 2 over gloo on CPU: the ranks drive the emulated
+library (tests/emu) instead of a GPU.  Every rank's shard is then checked against the oracle."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from sswutil import dna_matrix, oracle_align
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_two_rank_bench_over_gloo(emu_lib_path, tmp_path):
+    env = dict(os.environ, SSW_BENCH_DUMP=str(tmp_path), SSW_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--reads", "5", "--ref-len", "2500", "--read-len", "70", "--cpu-sample", "0", "--lib", emu_lib_path]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # only rank 0 prints
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["metric"] == "GCUPS" and out["value"] >= 0
+    assert out["steps"] == 1 and out["warmup"] == 1 and out["higher_is_better"] is True and "roofline" in out
+    mat = dna_matrix(2, 2)
+    seen = []
+    for rank in (0, 1):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        seen.append(z["reads"].tobytes())
+        for i, rd in enumerate(z["reads"]):
+            d, _ = oracle_align(rd, mat, 5, z["ref"], 3, 1, 0, 0, 0, len(rd) // 2, 2, 0)
+            g = z["res"][i, 0]
+            assert all(int(g[k]) == d[k] for k in ("score1", "score2", "ref_end1", "read_end1", "ref_end2")), (rank, i)
+    assert seen[0] != seen[1]                   # the ranks really worked on different shards
