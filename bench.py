@@ -154,6 +154,14 @@ def main(argv=None):
         valu_ops = fill_cells * 4.5
         achieved_valu = valu_ops / (fill_ms * 1e-3) if fill_ms > 0 else 0.0
         probe = ctx.valu_probe(8192, 4000) if args.lib is None else 0.0   # (skipped on the test emulator)
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (profiles/), scaled to this run's pairs per launch
+            with open(os.path.join(ROOT, "profiles", "round1_traffic.json")) as f:
+                tj = json.load(f)
+            if args.read_len == 150 and args.ref_len == 1_000_000:
+                traffic = round(tj["hbm_bytes_per_pair"] * (aln_per_launch / 2.0) / (launch_ms * 1e-3) / 1e9, 2)   # GB/s, like `achieved`
+        except Exception:
+            traffic = None
         out = {
             "metric": "GCUPS", "value": round(value, 2), "unit": "GCUPS", "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -167,7 +175,8 @@ def main(argv=None):
                                    "trace": round(phase["trace_ms"] / args.steps, 3),
                                    "reduce_and_copies": round(phase["reduce_ms"] / args.steps, 3)},
             "roofline": {"bound": "hbm", "kernel": "k_fill<%d>" % ((args.read_len + 15) // 16), "achieved": round(achieved_gbs, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_note": "GB/s from rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE of this kernel (profiles/round1_traffic.json), per launch",
                          "launch_ms": round(launch_ms, 3), "launches": int(fill_launches),
                          "note": "integer max-plus recurrence: HBM is not the binding resource, see roofline_valu"},
             "roofline_valu": {"bound": "valu-int16x2", "achieved": round(achieved_valu / 1e12, 3), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
@@ -181,14 +190,20 @@ def main(argv=None):
             cores = os.cpu_count() or 1
             R = ref_lib()
             if R is not None:
-                per_read_s = args.read_len * args.ref_len / 2.0e9            # ~2 GCUPS per core
-                ns = args.cpu_sample if args.cpu_sample > 0 else int(max(cores, min(args.reads, 20.0 * cores / per_read_s)))
-                ns = min(ns, args.reads)
-                sample = np.ascontiguousarray(reads[:ns])
-                soff = np.arange(ns + 1, dtype=np.int64) * args.read_len
-                cres = np.zeros((ns, 10), dtype=np.int32)
-                secs = R.refwrap_bench(_ptr(sample, i8p), _ptr(soff, i64p), ns, _ptr(ref, i8p), len(ref), _ptr(mat, i8p), 5, 3, 1,
-                                       args.flag, 0, 0, -1, cores, _ptr(cres, i32p))
+                def cpu_run(k):
+                    sample = np.ascontiguousarray(reads[:k])
+                    soff = np.arange(k + 1, dtype=np.int64) * args.read_len
+                    cres = np.zeros((k, 10), dtype=np.int32)
+                    secs = R.refwrap_bench(_ptr(sample, i8p), _ptr(soff, i64p), k, _ptr(ref, i8p), len(ref), _ptr(mat, i8p), 5, 3, 1,
+                                           args.flag, 0, 0, -1, cores, _ptr(cres, i32p))
+                    return secs, cres
+                if args.cpu_sample > 0:
+                    ns = min(args.cpu_sample, args.reads)
+                else:   # pilot of one read per core, then a sample sized for ~15 s of wall-clock on all cores
+                    pilot = min(args.reads, cores)
+                    s0, _ = cpu_run(pilot)
+                    ns = int(min(args.reads, max(pilot, pilot / max(s0, 1e-3) * 15.0)))
+                secs, cres = cpu_run(ns)
                 cpu_gcups = ns * args.read_len * args.ref_len / secs / 1e9
                 g = res[:ns, 0]
                 got = np.stack([g["score1"], g["score2"], g["ref_begin1"], g["ref_end1"], g["read_begin1"], g["read_end1"], g["ref_end2"],
