@@ -30,9 +30,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define SSW_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 
 /* DPP controls (ISA encodings): row_shr:n = 0x110+n, row_ror:n = 0x120+n */
-SSW_DEV u32 xl_row_shr1_zero(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
+SSW_DEV u32 xl_row_shr1_zero(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x111, 0xf, 0xf, true); }
 SSW_DEV u32 xl_row_shr1_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x111, 0xf, 0xf, false); }
-template <int N> SSW_DEV u32 xl_row_ror(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xf, 0xf, false); }
+template <int N> SSW_DEV u32 xl_row_ror(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x120 + N, 0xf, 0xf, true); }
 SSW_DEV u32 xl_shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 64); }
 SSW_DEV bool wave_any(bool p) { return __any(p) != 0; }
 SSW_DEV bool wave_all(bool p) { return __all(p) != 0; }

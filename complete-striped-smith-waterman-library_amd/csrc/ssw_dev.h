@@ -144,6 +144,7 @@ int   ssw_shim_event_record(void* ev, void* stream);
 float ssw_shim_event_elapsed_ms(void* start, void* stop);   /* both must have completed */
 
 int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream);
+int ssw_shim_fill_resident_blocks(int R, int n);
 int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream);
 int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* stream);
 int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);

@@ -264,6 +264,10 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 				int64_t chunk = (int64_t)(c->cm_budget / (size_t)(8 * stride));
 				if (chunk < 1) chunk = 1;
 				if (chunk > B->npairs) chunk = B->npairs;
+				{   /* whole rounds of resident workgroups per launch (all workgroups of a launch take the same time) */
+					const int64_t resident = ssw_shim_fill_resident_blocks(B->R, n), bpp = (ntiles + 15) / 16;
+					if (resident > 0 && chunk < B->npairs && chunk * bpp >= resident) chunk = (chunk * bpp / resident) * resident / bpp;
+				}
 				uint32_t* d_cm16 = (uint32_t*)ensure(c, &c->cm16, (size_t)(4 * stride * chunk));
 				uint32_t* d_cm8 = (uint32_t*)ensure(c, &c->cm8, (size_t)(4 * stride * chunk));
 				if (!d_cm16 || !d_cm8) goto done;

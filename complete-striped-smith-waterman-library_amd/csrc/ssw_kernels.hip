@@ -155,7 +155,6 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 	for (int r = 0; r < R; ++r) { H[r] = 0; E[r] = 0; }
 	u32 Hlast = 0, Fout = 0, cmout = 0, ck = 0, hsave = 0;
 	const u32 lane_prof = (u32)l16 * 16u;
-	const u32 notfirst = l16 ? 0xffffffffu : 0u;
 
 	for (int s0 = 0; s0 < nsteps; s0 += 16) {
 		{   /* stage target columns [s0+16, s0+32), prefetch [s0+32, s0+48) */
@@ -172,14 +171,15 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 			const int tc = s0 - 32 + l16;
 			if (tc >= store_from && tc < ncols) {
 				o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
-				o8[tc] = lds_ld32(lds, out8 + 4u * (tc & 63));
+				o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
 			}
 		}
 		wave_lds_fence();
 		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
-#pragma unroll 4
+		/* lane 0 parks finished maxima: column s-16 (all rows) and column s-1-TAP (rows < A8, stored in the slot of s-16) */
+		const u32 ob16 = out16 + 4u * (u32)((s0 - 16) & 63), ob8 = out8 + 4u * (u32)((s0 - 16) & 63);
+#pragma unroll
 		for (int j = 0; j < 16; ++j) {
-			const int s = s0 + j;
 			const u32 paddr = lds_ld16(lds, rp + 2u * j) + lane_prof;
 			u32x4 sc[C];
 #pragma unroll
@@ -188,11 +188,12 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 			u32 f = xl_row_shr1_zero(Fout);
 			const u32 x = xl_row_ror<1>(cmout);
 			const u32 x8 = xl_row_ror<16 - G::TAP>(ck);
-			if (l16 == 0) {   /* lane 0 sees the finished maxima of columns s-16 (all rows) and s-1-TAP (rows < A8) */
-				lds_st32(lds, out16 + 4u * ((s - 16) & 63), x);
-				lds_st32(lds, out8 + 4u * ((s - 1 - G::TAP) & 63), x8);
+			u32 cm = x;
+			if (l16 == 0) {
+				lds_st32(lds, ob16 + 4u * j, x);
+				lds_st32(lds, ob8 + 4u * j, x8);
+				cm = 0;
 			}
-			u32 cm = x & notfirst;
 			chain_rows<R, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
 		}
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 		const int tc = base + l16;
 		if (tc >= store_from && tc < ncols && tc >= 0) {
 			o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
-			o8[tc] = lds_ld32(lds, out8 + 4u * (tc & 63));
+			o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
 		}
 	}
 }
@@ -235,49 +236,87 @@ __global__ void __launch_bounds__(256) k_reduce(ssw_reduce_args a)
 	SSW_DYN_LDS(lds);
 	const int tid = (int)threadIdx.x, pair = (int)blockIdx.x;
 	const ssw_pair pr = a.pairs[pair];
-	const u32* w16 = a.cm16 + (int64_t)pair * a.cm_stride;
-	const u32* w8 = a.cm8 + (int64_t)pair * a.cm_stride;
-	for (int hi = 0; hi < 2; ++hi) {
-		const int q = hi ? pr.qb : pr.qa;
+	const u32x4* w16 = (const u32x4*)(a.cm16 + (int64_t)pair * a.cm_stride);   /* cm_stride is a multiple of 16 words */
+	const u32x4* w8 = (const u32x4*)(a.cm8 + (int64_t)pair * a.cm_stride);
+	const int nvec = (a.refLen + 3) >> 2;
+
+	/* pass 1 (one sweep for both queries): best score and its first column */
+	int best[2] = { 0, 0 }, bidx[2] = { 0x7fffffff, 0x7fffffff };
+	for (int v = tid; v < nvec; v += 256) {
+		const u32x4 w = w16[v];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int c = v * 4 + k;
+			if (c < a.refLen) {
+				const int lo = (int)(w[k] & 0xffffu), hi = (int)(w[k] >> 16);
+				if (lo > best[0]) { best[0] = lo; bidx[0] = c; }
+				if (hi > best[1]) { best[1] = hi; bidx[1] = c; }
+			}
+		}
+	}
+	block_argmax(lds, tid, best[0], bidx[0]);
+	block_argmax(lds, tid, best[1], bidx[1]);
+
+	ssw_dres r[2];
+	int use8[2] = { 0, 0 }, lo_edge[2] = { 0, 0 }, up_from[2] = { 0, 0 }, live[2] = { 0, 0 }, mlen[2] = { 0, 0 };
+	for (int h = 0; h < 2; ++h) {
+		const int q = h ? pr.qb : pr.qa;
+		ssw_dres& x = r[h];
+		x.score1 = 0; x.score2 = 0; x.ref_begin1 = -1; x.ref_end1 = 0; x.read_begin1 = -1; x.read_end1 = 0;
+		x.ref_end2 = 0; x.cigarLen = 0; x.flag = 0; x.status = 0; x.word = 0; x.want_begin = 0; x.want_cigar = 0;
+		x.rev_score = 0; x.cigar_off = 0;
 		if (q < 0) continue;
 		const int len = (int)(a.qoff[q + 1] - a.qoff[q]);
 		const bool padded = (len & 15) >= 1 && (len & 15) <= 8;      /* 16-bit rules see 8 rows fewer */
-		const int maskLen = a.maskLen >= 0 ? a.maskLen : len / 2;
-		int best = 0, bidx = 0x7fffffff;
-		for (int c = tid; c < a.refLen; c += 256) {
-			const int v = half16(w16[c], hi);
-			if (v > best) { best = v; bidx = c; }
-		}
-		block_argmax(lds, tid, best, bidx);
-		ssw_dres r;
-		r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = 0; r.read_begin1 = -1; r.read_end1 = 0;
-		r.ref_end2 = 0; r.cigarLen = 0; r.flag = 0; r.status = 0; r.word = 0; r.want_begin = 0; r.want_cigar = 0;
-		r.rev_score = 0; r.cigar_off = 0;
+		mlen[h] = a.maskLen >= 0 ? a.maskLen : len / 2;
 		const bool have_byte = a.score_size == 0 || a.score_size == 2, have_word = a.score_size == 1 || a.score_size == 2;
 		int word = 0;
-		if (have_byte && best < 255 - a.bias) word = 0;                /* ssw.c:881-899 */
+		if (have_byte && best[h] < 255 - a.bias) word = 0;             /* ssw.c:881-899 */
 		else if (have_word) word = 1;
-		else r.status = 1;
-		r.word = word;
-		if (r.status == 0 && best > 0) {
-			const u32* arr = (word && padded) ? w8 : w16;
-			const int lo_edge = bidx - maskLen > 0 ? bidx - maskLen : 0;
-			const int hi_edge = bidx + maskLen > a.refLen ? a.refLen : bidx + maskLen;
-			const int up_from = word ? hi_edge : hi_edge + 1;          /* ssw.c:376 vs 578 */
-			int s2 = 0, i2 = 0x7fffffff;
-			for (int c = tid; c < a.refLen; c += 256) {
-				if (c < lo_edge || c >= up_from) {
-					const int v = half16(arr[c], hi);
-					if (v > s2) { s2 = v; i2 = c; }
+		else x.status = 1;
+		x.word = word;
+		if (x.status == 0 && best[h] > 0) {
+			live[h] = 1;
+			use8[h] = word && padded;
+			lo_edge[h] = bidx[h] - mlen[h] > 0 ? bidx[h] - mlen[h] : 0;
+			const int hi_edge = bidx[h] + mlen[h] > a.refLen ? a.refLen : bidx[h] + mlen[h];
+			up_from[h] = word ? hi_edge : hi_edge + 1;                 /* ssw.c:376 vs 578 */
+		}
+	}
+
+	/* pass 2: masked second best; each column-maximum stream is swept at most once */
+	int s2[2] = { 0, 0 }, i2[2] = { 0x7fffffff, 0x7fffffff };
+	for (int arr = 0; arr < 2; ++arr) {
+		const bool want0 = live[0] && use8[0] == arr, want1 = live[1] && use8[1] == arr;
+		if (!want0 && !want1) continue;
+		const u32x4* src = arr ? w8 : w16;
+		for (int v = tid; v < nvec; v += 256) {
+			const u32x4 w = src[v];
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int c = v * 4 + k;
+				if (c < a.refLen) {
+					const int lo = (int)(w[k] & 0xffffu), hi = (int)(w[k] >> 16);
+					if (want0 && (c < lo_edge[0] || c >= up_from[0]) && lo > s2[0]) { s2[0] = lo; i2[0] = c; }
+					if (want1 && (c < lo_edge[1] || c >= up_from[1]) && hi > s2[1]) { s2[1] = hi; i2[1] = c; }
 				}
 			}
-			block_argmax(lds, tid, s2, i2);
-			r.score1 = best; r.ref_end1 = bidx;
-			if (maskLen >= 15) { r.score2 = s2; r.ref_end2 = s2 > 0 ? i2 : 0; }
-			else { r.score2 = 0; r.ref_end2 = -1; }
-			r.want_begin = !(a.flag == 0 || (a.flag == 2 && best < a.filters));   /* ssw.c:916 */
 		}
-		if (tid == 0) a.res[q] = r;
+	}
+	block_argmax(lds, tid, s2[0], i2[0]);
+	block_argmax(lds, tid, s2[1], i2[1]);
+	if (tid == 0) {
+		for (int h = 0; h < 2; ++h) {
+			const int q = h ? pr.qb : pr.qa;
+			if (q < 0) continue;
+			if (live[h]) {
+				r[h].score1 = best[h]; r[h].ref_end1 = bidx[h];
+				if (mlen[h] >= 15) { r[h].score2 = s2[h]; r[h].ref_end2 = s2[h] > 0 ? i2[h] : 0; }
+				else { r[h].score2 = 0; r[h].ref_end2 = -1; }
+				r[h].want_begin = !(a.flag == 0 || (a.flag == 2 && best[h] < a.filters));   /* ssw.c:916 */
+			}
+			a.res[q] = r[h];
+		}
 	}
 }
 
@@ -628,6 +667,27 @@ extern "C" int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream)
 		default: return -2;
 	}
 	return SSW_LAUNCH_OK();
+}
+
+/* workgroups of k_fill<R> that are resident on the whole device at once (0: unknown) -- lets the host size a launch as a
+   whole number of "rounds" so that no CU idles through a partial last round */
+extern "C" int ssw_shim_fill_resident_blocks(int R, int n)
+{
+#ifdef SSW_SIMT_EMU
+	(void)R; (void)n; return 0;
+#else
+	int per_cu = 0, dev = 0, cus = 0;
+	switch (R) {
+#define X(r) case r: { const size_t ldsb = (size_t)(n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
+		shim_allow_lds(k_fill<r>, ldsb); \
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fill<r>, 256, ldsb) != hipSuccess) per_cu = 0; } break;
+		FOR_EACH_R(X)
+#undef X
+		default: return 0;
+	}
+	if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+	return per_cu * cus;
+#endif
 }
 
 extern "C" int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream)
