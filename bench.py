@@ -60,6 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--ref-len", type=int, default=1_000_000)
     ap.add_argument("--flag", type=int, default=0, help="ssw_align flag (0 = scores + end positions; 2 = + begin + CIGAR)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the CPU-baseline sample (-1: ~20 s of work; 0: skip)")
+    ap.add_argument("--sub", type=float, default=0.03, help="substitution rate of the synthetic reads")
+    ap.add_argument("--indel", type=float, default=0.005, help="insertion rate = deletion rate of the synthetic reads")
+    ap.add_argument("--mask-len", type=int, default=-1, help="maskLen (-1: readLen/2 per read, like the reference CLI)")
     ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)   # tests point this at the emulated library
     return ap.parse_args(argv)
 
@@ -98,7 +101,7 @@ def main(argv=None):
 
     mat = dna_matrix(2, 2)
     ref = random_ref(args.ref_len, 1, 4)                                   # seed 1: BASELINE config 2
-    reads = make_reads_fast(ref, args.reads, args.read_len, seed=1000 + rank)
+    reads = make_reads_fast(ref, args.reads, args.read_len, seed=1000 + rank, sub=args.sub, ins=args.indel, dele=args.indel)
     # upload through the packed form directly (a Python list of 100k arrays is slow to concatenate)
     import ctypes as C
     off = (np.arange(args.reads + 1, dtype=np.int64) * args.read_len)
@@ -109,7 +112,7 @@ def main(argv=None):
     T = ctx.upload([ref])
 
     def step():
-        return ctx.align_batch(Q, T, mat, 5, 3, 1, args.flag, 0, 0, -1, 2, want_cigar=(args.flag & 7) != 0)
+        return ctx.align_batch(Q, T, mat, 5, 3, 1, args.flag, 0, 0, args.mask_len, 2, want_cigar=(args.flag & 7) != 0)
 
     def sync_all():
         # align_batch() returns only after its stream is synchronised and the results are on the host, so every rank is
@@ -166,8 +169,9 @@ def main(argv=None):
             "metric": "GCUPS", "value": round(value, 2), "unit": "GCUPS", "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16x2 (packed; reference u8/int16 semantics)", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: %dk x %d bp DNA reads vs %.1f Mb target per GPU, 2/-2/3/1, score_size 2, flag %d"
-                                   % (args.reads // 1000, args.read_len, args.ref_len / 1e6, args.flag),
+            "config": {"workload": "%s: %d x %d bp DNA reads vs %.1f Mb target per GPU, 2/-2/3/1, score_size 2, flag %d"
+                                   % ("BASELINE config 2" if (args.reads, args.read_len, args.ref_len) == (100000, 150, 1000000) else "custom",
+                                      args.reads, args.read_len, args.ref_len / 1e6, args.flag),
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "ref_len": args.ref_len,
                        "sharding": "reads sharded across ranks, target replicated, no collective"},
             "mix": {"word_rules": int(tm["n_word"]), "byte_rules": int(tm["n_byte"])},
@@ -195,7 +199,7 @@ def main(argv=None):
                     soff = np.arange(k + 1, dtype=np.int64) * args.read_len
                     cres = np.zeros((k, 10), dtype=np.int32)
                     secs = R.refwrap_bench(_ptr(sample, i8p), _ptr(soff, i64p), k, _ptr(ref, i8p), len(ref), _ptr(mat, i8p), 5, 3, 1,
-                                           args.flag, 0, 0, -1, cores, _ptr(cres, i32p))
+                                           args.flag, 0, 0, args.mask_len, cores, _ptr(cres, i32p))
                     return secs, cres
                 if args.cpu_sample > 0:
                     ns = min(args.cpu_sample, args.reads)

@@ -90,6 +90,38 @@ typedef struct {
 	ssw_dres* res;
 } ssw_capture_args;
 
+/*
+ * generic chain kernel (k_chainx): one 16-lane chain per job with its OWN profile; queries of any length are cut
+ * into row strips of 16R rows that the chain processes one after the other, handing the bottom boundary
+ * (H, F, running column maxima) of a strip to the next through HBM.  mode 0: forward fill of (pair, tile) jobs ->
+ * column maxima; mode 1/2: locate / reverse windows of single queries -> best cell (as k_capture).
+ */
+typedef struct {
+	const int8_t* tgt;
+	int32_t refLen;
+	const int8_t* qcodes;
+	const int64_t* qoff;
+	const int8_t* mat;
+	int32_t n;
+	uint32_t gapO2, gapE2;
+	int32_t gapE, maxmat;
+	int32_t njobs;
+	/* fill mode */
+	const ssw_pair* pairs;
+	int32_t tile, halo, ntiles;
+	uint32_t* cm16;
+	uint32_t* cm8;
+	int64_t cm_stride;
+	/* capture mode */
+	const int32_t* qlist;
+	int32_t reverse;
+	int32_t flag, filters, filterd;
+	ssw_dres* res;
+	/* strip boundary hand-off: njobs regions of bnd_stride records of 4 words (H, F, colmax16, colmax8) */
+	uint32_t* bnd;
+	int64_t bnd_stride;
+} ssw_chainx_args;
+
 /* banded traceback */
 typedef struct {
 	const int8_t* tgt;
@@ -147,6 +179,7 @@ int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream);
 int ssw_shim_fill_resident_blocks(int R, int n);
 int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream);
 int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* stream);
+int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args* a, void* stream);
 int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);
 int ssw_shim_launch_gather(const ssw_gather_args* a, void* stream);
 int ssw_shim_launch_selftest(const ssw_selftest_args* a, int blocks, void* stream);

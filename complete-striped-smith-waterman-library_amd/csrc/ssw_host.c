@@ -34,7 +34,7 @@ struct ssw_gpu_ctx {
 	void* stream;
 	char err[512];
 	ssw_gpu_timing tm;
-	dbuf mat, pairs, qlist, res, cm16, cm8, scratch, cigar, need, goff, gpool;
+	dbuf mat, pairs, qlist, res, cm16, cm8, scratch, cigar, need, goff, gpool, bnd;
 	void** ev; int nev, capev;          /* event pairs around fill launches */
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
@@ -99,7 +99,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_set_device(c->device);
 	ssw_shim_stream_sync(c->stream);
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
-	dbuf_free(&c->cm8); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool);
+	dbuf_free(&c->cm8); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
 	free(c->ev);
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
@@ -158,7 +158,16 @@ static void* next_event(ssw_gpu_ctx* c)
 	return c->ev[c->nev++];
 }
 
-typedef struct { int32_t R; int32_t first_pair, npairs; int32_t first_q, nq; } bucket;
+/* queries that share a chain geometry: short queries (<= 384 residues) by R = ceil(len/16) rows per lane, one strip;
+   longer ones by their padded length P16, cut into `strips` row strips of 16*R rows (k_chainx) */
+typedef struct { int32_t R, strips, P16; int32_t first_pair, npairs; int32_t first_q, nq; } bucket;
+typedef struct { int32_t key, q; } keyed;
+static int keyed_cmp(const void* a, const void* b)
+{
+	const keyed* x = (const keyed*)a; const keyed* y = (const keyed*)b;
+	if (x->key != y->key) return x->key < y->key ? -1 : 1;
+	return x->q < y->q ? -1 : (x->q > y->q);
+}
 
 int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
                         const ssw_gpu_params* prm, ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words)
@@ -182,39 +191,46 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 	for (int32_t i = 0; i < n * n; ++i) { if (prm->mat[i] < bias) bias = prm->mat[i]; if (prm->mat[i] > maxmat) maxmat = prm->mat[i]; }
 	bias = (prm->score_size == 0 || prm->score_size == 2) ? -bias : 0;
 
-	/* bucket queries by rows-per-lane, pair neighbours inside a bucket */
+	/* bucket the queries by chain geometry, pair neighbours inside a bucket */
 	int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
-	ssw_pair* pairs = (ssw_pair*)malloc(sizeof(ssw_pair) * ((size_t)nq / 2 + SSW_RMAX + 1));
-	int32_t cnt[SSW_RMAX + 2]; memset(cnt, 0, sizeof cnt);
-	int32_t maxlen = 0;
+	ssw_pair* pairs = (ssw_pair*)malloc(sizeof(ssw_pair) * ((size_t)nq + 1));
+	keyed* keys = (keyed*)malloc(sizeof(keyed) * (size_t)nq);
+	bucket* bk = 0; int nb = 0;
+	int32_t maxlen = 0, npairs_total = 0;
 	for (int32_t q = 0; q < nq; ++q) {
 		int64_t len = Q->h_off[q + 1] - Q->h_off[q];
-		if (len < 1 || len > 16 * SSW_RMAX) {
-			free(order); free(pairs);
-			return fail(c, "align_batch: query length outside 1..384 is not supported by this build%s", "");
+		if (len < 1 || len > 0x3fffff00) {
+			free(order); free(pairs); free(keys);
+			return fail(c, "align_batch: empty (or absurdly long) query%s", "");
 		}
 		if (len > maxlen) maxlen = (int32_t)len;
-		cnt[(len + 15) / 16]++;
+		keys[q].q = q;
+		keys[q].key = len <= 16 * SSW_RMAX ? (int32_t)((len + 15) / 16) : (int32_t)(SSW_RMAX + (len + 15) / 16);
 	}
-	bucket bk[SSW_RMAX + 1]; int nb = 0;
-	int32_t start[SSW_RMAX + 2]; int32_t acc = 0;
-	for (int R = 1; R <= SSW_RMAX; ++R) { start[R] = acc; acc += cnt[R]; }
-	{
-		int32_t fillp[SSW_RMAX + 2]; memcpy(fillp, start, sizeof fillp);
-		for (int32_t q = 0; q < nq; ++q) { int R = (int)((Q->h_off[q + 1] - Q->h_off[q] + 15) / 16); order[fillp[R]++] = q; }
-	}
-	int32_t npairs_total = 0;
-	for (int R = 1; R <= SSW_RMAX; ++R) {
-		if (!cnt[R]) continue;
-		bucket b; b.R = R; b.first_q = start[R]; b.nq = cnt[R]; b.first_pair = npairs_total;
-		for (int32_t i = 0; i < cnt[R]; i += 2) {
-			pairs[npairs_total].qa = order[start[R] + i];
-			pairs[npairs_total].qb = i + 1 < cnt[R] ? order[start[R] + i + 1] : -1;
+	qsort(keys, (size_t)nq, sizeof(keyed), keyed_cmp);
+	for (int32_t i = 0; i < nq; ) {
+		int32_t j = i;
+		while (j < nq && keys[j].key == keys[i].key) ++j;
+		bk = (bucket*)realloc(bk, sizeof(bucket) * (size_t)(nb + 1));
+		bucket b;
+		if (keys[i].key <= SSW_RMAX) { b.R = keys[i].key; b.strips = 1; b.P16 = 16 * b.R; }
+		else {
+			b.P16 = 16 * (keys[i].key - SSW_RMAX);
+			b.strips = (b.P16 + 16 * SSW_RMAX - 1) / (16 * SSW_RMAX);
+			b.R = (b.P16 + 16 * b.strips - 1) / (16 * b.strips);        /* balanced strips, R <= SSW_RMAX */
+		}
+		b.first_q = i; b.nq = j - i; b.first_pair = npairs_total;
+		for (int32_t k = i; k < j; ++k) order[k] = keys[k].q;
+		for (int32_t k = i; k < j; k += 2) {
+			pairs[npairs_total].qa = order[k];
+			pairs[npairs_total].qb = k + 1 < j ? order[k + 1] : -1;
 			++npairs_total;
 		}
 		b.npairs = npairs_total - b.first_pair;
 		bk[nb++] = b;
+		i = j;
 	}
+	free(keys);
 
 	int rc = -1;
 	uint32_t* pool = 0; int64_t pool_words = 0, pool_cap = 0;
@@ -249,25 +265,31 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 			const int64_t stride = ((int64_t)refLen + 15) / 16 * 16 + 16;
 			for (int b = 0; b < nb; ++b) {
 				const bucket* B = &bk[b];
-				const int32_t P = 16 * B->R, halo_full = halo_for(P, maxmat, prm->gapE);
+				const int32_t P = B->P16, halo_full = halo_for(P, maxmat, prm->gapE);
+				const int use_x = B->strips > 1;     /* long queries: strip kernel, one job per chain */
+				const int gran = use_x ? 1 : 16;     /* k_fill: one workgroup = 16 tiles of one pair */
 				int32_t tile, halo, ntiles;
-				if ((int64_t)halo_full * 8 * 16 >= refLen) { ntiles = 1; tile = (refLen + 15) / 16 * 16; halo = 0; }
+				if ((int64_t)halo_full * 8 * gran >= refLen) { ntiles = 1; tile = (refLen + 15) / 16 * 16; halo = 0; }
 				else {
-					/* multiples of 16 tiles (one workgroup = 16 tiles of one pair); more tiles when few pairs */
+					/* enough chains to fill the device several times over, halo overhead <= 1/8 */
 					int64_t want = (4 * 32768 + B->npairs - 1) / B->npairs;
 					int64_t maxt = refLen / ((int64_t)halo_full * 8);
 					if (want > maxt) want = maxt;
-					want = (want + 15) / 16 * 16; if (want < 16) want = 16;
+					want = (want + gran - 1) / gran * gran; if (want < gran) want = gran;
 					tile = (int32_t)(((refLen + want - 1) / want + 15) / 16 * 16);
 					ntiles = (refLen + tile - 1) / tile; halo = halo_full;
 				}
-				int64_t chunk = (int64_t)(c->cm_budget / (size_t)(8 * stride));
+				const int64_t maxcols = (((int64_t)tile + halo < refLen ? (int64_t)tile + halo : refLen) + 31) / 16 * 16;
+				int64_t per_pair = 8 * stride + (use_x ? 16 * maxcols * ntiles : 0);
+				int64_t chunk = (int64_t)(c->cm_budget / (size_t)per_pair);
 				if (chunk < 1) chunk = 1;
 				if (chunk > B->npairs) chunk = B->npairs;
-				{   /* whole rounds of resident workgroups per launch (all workgroups of a launch take the same time) */
+				if (!use_x) {   /* whole rounds of resident workgroups per launch (all workgroups of a launch take the same time) */
 					const int64_t resident = ssw_shim_fill_resident_blocks(B->R, n), bpp = (ntiles + 15) / 16;
 					if (resident > 0 && chunk < B->npairs && chunk * bpp >= resident) chunk = (chunk * bpp / resident) * resident / bpp;
 				}
+				uint32_t* d_bnd = 0;
+				if (use_x) { d_bnd = (uint32_t*)ensure(c, &c->bnd, (size_t)(16 * maxcols * ntiles * chunk)); if (!d_bnd) goto done; }
 				uint32_t* d_cm16 = (uint32_t*)ensure(c, &c->cm16, (size_t)(4 * stride * chunk));
 				uint32_t* d_cm8 = (uint32_t*)ensure(c, &c->cm8, (size_t)(4 * stride * chunk));
 				if (!d_cm16 || !d_cm8) goto done;
@@ -280,6 +302,14 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 					fa.bpp = (ntiles + 15) / 16; fa.cm16 = d_cm16; fa.cm8 = d_cm8; fa.cm_stride = stride;
 					void* e0 = next_event(c); void* e1 = next_event(c);
 					ssw_shim_event_record(e0, c->stream);
+					if (use_x) {
+						ssw_chainx_args xa; memset(&xa, 0, sizeof xa);
+						xa.tgt = d_tgt; xa.refLen = refLen; xa.qcodes = Q->d_codes; xa.qoff = Q->d_off; xa.mat = d_mat; xa.n = n;
+						xa.gapO2 = gapO2; xa.gapE2 = gapE2; xa.gapE = prm->gapE; xa.maxmat = maxmat; xa.njobs = np * ntiles;
+						xa.pairs = fa.pairs; xa.tile = tile; xa.halo = halo; xa.ntiles = ntiles; xa.cm16 = d_cm16; xa.cm8 = d_cm8;
+						xa.cm_stride = stride; xa.bnd = d_bnd; xa.bnd_stride = maxcols;
+						if (ssw_shim_launch_chainx(B->R, 0, &xa, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
+					} else
 					if (ssw_shim_launch_fill(B->R, &fa, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
 					ssw_shim_event_record(e1, c->stream);
 					c->tm.fill_launches++;
@@ -290,7 +320,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 							int64_t cf = lo - halo > 0 ? lo - halo : 0;
 							cols += hi - cf;
 						}
-						c->tm.fill_cells += cols * P * 2 * np;
+						c->tm.fill_cells += cols * (int64_t)(16 * B->R * B->strips) * 2 * np;
 					}
 					ssw_reduce_args ra;
 					ra.cm16 = d_cm16; ra.cm8 = d_cm8; ra.cm_stride = stride; ra.refLen = refLen; ra.pairs = fa.pairs; ra.npairs = np;
@@ -306,6 +336,23 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 			for (int pass = 0; pass < (prm->flag != 0 ? 2 : 1); ++pass)
 				for (int b = 0; b < nb; ++b) {
 					const bucket* B = &bk[b];
+					if (B->strips > 1) {
+						const int32_t hw = halo_for(B->P16, maxmat, prm->gapE);
+						const int64_t wcols = (((int64_t)(hw < refLen ? hw : refLen) + 1) + 31) / 16 * 16;
+						int64_t per = (int64_t)(c->cm_budget / (size_t)(16 * wcols)); if (per < 1) per = 1;
+						for (int32_t q0 = 0; q0 < B->nq; q0 += (int32_t)per) {
+							const int32_t cnt_q = B->nq - q0 < per ? B->nq - q0 : (int32_t)per;
+							uint32_t* d_bnd = (uint32_t*)ensure(c, &c->bnd, (size_t)(16 * wcols * cnt_q));
+							if (!d_bnd) goto done;
+							ssw_chainx_args xa; memset(&xa, 0, sizeof xa);
+							xa.tgt = d_tgt; xa.refLen = refLen; xa.qcodes = Q->d_codes; xa.qoff = Q->d_off; xa.mat = d_mat; xa.n = n;
+							xa.gapO2 = gapO2; xa.gapE2 = gapE2; xa.gapE = prm->gapE; xa.maxmat = maxmat; xa.njobs = cnt_q;
+							xa.qlist = d_qlist + B->first_q + q0; xa.reverse = pass; xa.flag = prm->flag; xa.filters = prm->filters;
+							xa.filterd = prm->filterd; xa.res = d_res; xa.bnd = d_bnd; xa.bnd_stride = wcols;
+							if (ssw_shim_launch_chainx(B->R, 1, &xa, c->stream)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
+						}
+						continue;
+					}
 					ssw_capture_args ca;
 					ca.tgt = d_tgt; ca.refLen = refLen; ca.qcodes = Q->d_codes; ca.qoff = Q->d_off; ca.qlist = d_qlist + B->first_q;
 					ca.nq = B->nq; ca.mat = d_mat; ca.n = n; ca.gapO2 = gapO2; ca.gapE2 = gapE2; ca.gapE = prm->gapE; ca.maxmat = maxmat;
@@ -320,7 +367,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 		int did_trace = 0;
 		if ((prm->flag & 7) != 0 && refLen > 0) {
 			/* one launch over all queries; scratch sized for a band a few doublings wide, grown on demand */
-			const int32_t halo_max = halo_for(16 * bk[nb - 1].R, maxmat, prm->gapE);
+			const int32_t halo_max = halo_for((maxlen + 15) / 16 * 16, maxmat, prm->gapE);
 			int64_t span = (int64_t)maxlen + (halo_max < refLen ? halo_max : refLen) + 8;
 			cig_stride = (span + 3) / 4 * 4;
 			d_cig = (uint32_t*)ensure(c, &c->cigar, (size_t)(4 * cig_stride * nq));
@@ -430,7 +477,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 	if (cigar_words) *cigar_words = pool_words;
 	rc = 0;
 done:
-	free(pool); free(order); free(pairs); free(hres); free(hneed);
+	free(pool); free(order); free(pairs); free(hres); free(hneed); free(bk);
 	return rc;
 }
 

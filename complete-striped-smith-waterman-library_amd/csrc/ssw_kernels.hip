@@ -453,6 +453,282 @@ __global__ void __launch_bounds__(64) k_capture(ssw_capture_args a)
 }
 
 /* ================================================================================================
+ * k_chainx: generic chain kernel -- any query length (row strips), one profile per chain, 4 chains per 64-thread
+ * workgroup.  CAPTURE = false: forward fill of (pair, tile) jobs, column maxima to cm16/cm8.
+ * CAPTURE = true: locate / reverse window of one query, best cell to the result record (same contract as k_capture).
+ * ================================================================================================ */
+#define BND_RING_BYTES (64 * 16)
+#define CHAINX_BYTES (RING_BYTES + 2 * BND_RING_BYTES + 16 * 12)
+
+template <int R>
+SSW_DEV void build_profile_strip(unsigned char* lds, u32 base, int first, int nthreads, const int8_t* mat, int n,
+                                 const int8_t* qa, int lena, int reva, const int8_t* qb, int lenb, int row0, int rows_total)
+{
+	constexpr int C = ChainGeom<R>::C;
+	const int total = (n + 1) * C * 64;
+	for (int w = first; w < total; w += nthreads) {
+		const int b = w / (C * 64), rem = w - b * (C * 64);
+		const int c = rem >> 6, l = (rem & 63) >> 2, k = rem & 3;
+		const int r = c * 4 + k, row = row0 + l * R + r;
+		u32 v;
+		if (r >= R) v = 0;
+		else if (b == n || row >= rows_total) v = DEAD2;      /* null residue / rows below the padded query */
+		else {
+			int lo = 0, hi = 0;
+			if (row < lena) lo = mat[b * n + (reva ? qa[lena - 1 - row] : qa[row])];
+			if (qb && row < lenb) hi = mat[b * n + qb[row]];
+			v = pk_make(lo, hi);
+		}
+		lds_st32(lds, base + (u32)w * 4u, v);
+	}
+}
+
+template <int R> struct ChainState {
+	u32 H[R], E[R];
+	u32 Hlast, Fout, cmout, cm8out, hsave;
+	int best, btc, brow;
+};
+
+struct StripCtx {
+	u32 prof, ring, bin, bout, nulloff;
+	int l16, ncols, nsteps, c_edge, dirstep, store_from, row0;
+	bool mine, first, last;
+	const int8_t* tg;
+	u32* bnd;          /* this job's boundary records */
+	u32* o16; u32* o8; /* fill: column maxima of the last strip */
+	u32 gapO2, gapE2;
+	int n;
+};
+
+template <int R, bool CAPTURE, bool MASK8>
+SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st, const u32 (&m8)[R])
+{
+	typedef ChainGeom<R> G;
+	constexpr int C = G::C;
+	const int l16 = x.l16;
+	/* rings: target columns -16..-1 null, 0..15 now, 16..31 in flight; boundary-in likewise */
+	lds_st16(lds, x.ring + 2u * (48 + l16), x.nulloff);
+	{
+		int code = l16 < x.ncols ? x.tg[x.c_edge + x.dirstep * l16] : x.n;
+		if (code < 0 || code > x.n) code = x.n;
+		const u32 off = (u32)code * G::PSTRIDE;
+		lds_st16(lds, x.ring + 2u * l16, off);
+		lds_st16(lds, x.ring + 2u * (64 + l16), off);
+	}
+	u32 nxt;
+	{
+		const int tc = 16 + l16;
+		int code = tc < x.ncols ? x.tg[x.c_edge + x.dirstep * tc] : x.n;
+		if (code < 0 || code > x.n) code = x.n;
+		nxt = (u32)code * G::PSTRIDE;
+	}
+	const u32x4 zero4 = { 0u, 0u, 0u, 0u };
+	const bool take = !x.first && x.mine;
+	{
+		u32x4 rec = zero4;
+		if (take && l16 < x.ncols) rec = *(const u32x4*)(x.bnd + 4 * (int64_t)l16);
+		lds_st128(lds, x.bin + 16u * l16, rec);
+		lds_st128(lds, x.bin + 16u * (48 + l16), zero4);
+	}
+	u32x4 nb = zero4;
+	if (take && 16 + l16 < x.ncols) nb = *(const u32x4*)(x.bnd + 4 * (int64_t)(16 + l16));
+#pragma unroll
+	for (int r = 0; r < R; ++r) { st.H[r] = 0; st.E[r] = 0; }
+	st.Hlast = 0; st.Fout = 0; st.cmout = 0; st.cm8out = 0; st.hsave = 0;
+	const u32 lane_prof = x.prof + (u32)l16 * 16u;
+	wave_lds_fence();
+
+	for (int s0 = 0; s0 < x.nsteps; s0 += 16) {
+		{   /* stage [s0+16, s0+32), prefetch [s0+32, s0+48) */
+			const int p = (s0 + 16 + l16) & 63;
+			lds_st16(lds, x.ring + 2u * p, nxt);
+			if (p < 16) lds_st16(lds, x.ring + 2u * (64 + p), nxt);
+			lds_st128(lds, x.bin + 16u * p, nb);
+			const int tc = s0 + 32 + l16;
+			int code = tc < x.ncols ? x.tg[x.c_edge + x.dirstep * tc] : x.n;
+			if (code < 0 || code > x.n) code = x.n;
+			nxt = (u32)code * G::PSTRIDE;
+			nb = zero4;
+			if (take && tc < x.ncols) nb = *(const u32x4*)(x.bnd + 4 * (int64_t)tc);
+		}
+		wave_lds_fence();
+		if (s0 >= 32) {   /* boundary-out records of columns [s0-32, s0-16) are complete */
+			const int tc = s0 - 32 + l16;
+			if (x.mine && tc < x.ncols) {
+				const u32x4 rec = lds_ld128(lds, x.bout + 16u * (tc & 63));
+				if (!x.last) *(u32x4*)(x.bnd + 4 * (int64_t)tc) = rec;
+				else if (!CAPTURE && tc >= x.store_from) { x.o16[tc] = rec[2]; x.o8[tc] = rec[3]; }
+			}
+		}
+		wave_lds_fence();
+		const u32 rp = x.ring + 2u * (u32)((s0 - l16) & 63);
+#pragma unroll 2
+		for (int j = 0; j < 16; ++j) {
+			const int s = s0 + j, tc = s - l16;
+			const u32 paddr = lds_ld16(lds, rp + 2u * j) + lane_prof;
+			u32x4 sc[C];
+#pragma unroll
+			for (int c = 0; c < C; ++c) sc[c] = lds_ld128(lds, paddr + 256u * c);
+			const u32x4 rec = lds_ld128(lds, x.bin + 16u * (s & 63));       /* what lane 0 receives from the strip above */
+			const u32 hin = xl_row_shr1_keep(rec[0], st.Hlast);
+			u32 f = xl_row_shr1_keep(rec[1], st.Fout);
+			u32 cm = xl_row_shr1_keep(rec[2], st.cmout);
+			u32 cm8 = MASK8 ? xl_row_shr1_keep(rec[3], st.cm8out) : 0u;
+			u32 d = st.hsave;
+			u32 lm = 0;   /* capture: this lane's own maximum in this column */
+#pragma unroll
+			for (int r = 0; r < R; ++r) {
+				const u32 hold = st.H[r];
+				const u32 sv = sc[r >> 2][r & 3];
+				const u32 h0 = pk_max(pk_adds(d, sv), st.E[r]);
+				const u32 h = pk_max(h0, f);
+				const u32 t0 = pk_subu(h0, x.gapO2);
+				st.E[r] = pk_max(pk_subu(st.E[r], x.gapE2), t0);
+				f = pk_max(pk_subu(f, x.gapE2), t0);
+				if (CAPTURE) lm = pk_max(lm, h); else cm = pk_max(cm, h);
+				if (MASK8) cm8 = pk_max(cm8, h & m8[r]);
+				st.H[r] = h;
+				d = hold;
+			}
+			st.hsave = hin; st.Hlast = st.H[R - 1]; st.Fout = f; st.cmout = cm; st.cm8out = MASK8 ? cm8 : cm;
+			if (l16 == 15) {
+				const u32x4 o = { st.Hlast, st.Fout, st.cmout, st.cm8out };
+				lds_st128(lds, x.bout + 16u * ((s - 15) & 63), o);
+			}
+			if (CAPTURE) {
+				const int m = (int)(lm & 0xffffu);
+				if (x.mine && tc >= 0 && tc < x.ncols && (m > st.best || (m == st.best && m > 0 && tc < st.btc))) {
+					st.best = m; st.btc = tc;
+#pragma unroll
+					for (int k = R - 1; k >= 0; --k) if ((int)(st.H[k] & 0xffffu) == m) st.brow = x.row0 + l16 * R + k;
+				}
+			}
+		}
+	}
+	wave_lds_fence();
+	for (int base = x.nsteps - 32; base < x.nsteps; base += 16) {
+		const int tc = base + l16;
+		if (x.mine && tc >= 0 && tc < x.ncols) {
+			const u32x4 rec = lds_ld128(lds, x.bout + 16u * (tc & 63));
+			if (!x.last) *(u32x4*)(x.bnd + 4 * (int64_t)tc) = rec;
+			else if (!CAPTURE && tc >= x.store_from) { x.o16[tc] = rec[2]; x.o8[tc] = rec[3]; }
+		}
+	}
+	dev_fence();   /* the next strip of this chain re-reads the boundary records through HBM */
+}
+
+template <int R, bool CAPTURE>
+__global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
+{
+	typedef ChainGeom<R> G;
+	SSW_DYN_LDS(lds);
+	const int tid = (int)threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+	const u32 prof_bytes = (u32)(a.n + 1) * G::PSTRIDE;
+	StripCtx x;
+	x.prof = (u32)grp * (prof_bytes + CHAINX_BYTES); x.ring = x.prof + prof_bytes; x.bin = x.ring + RING_BYTES;
+	x.bout = x.bin + BND_RING_BYTES; x.nulloff = (u32)a.n * G::PSTRIDE;
+	const u32 red = x.bout + BND_RING_BYTES;
+	x.l16 = l16; x.gapO2 = a.gapO2; x.gapE2 = a.gapE2; x.n = a.n; x.tg = a.tgt;
+	const int job = (int)blockIdx.x * 4 + grp;
+	const bool valid = job < a.njobs;
+
+	const int8_t *qa = a.qcodes, *qb = 0;
+	int lena = 0, lenb = 0, rev = 0, rows_total = 0, p8a = 0, p8b = 0, q = -1, qlen = 0;
+	bool active = false;
+	ssw_dres r;
+	x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0;
+	if (!CAPTURE) {
+		if (valid) {
+			const int pair = job / a.ntiles, t = job - pair * a.ntiles;
+			const ssw_pair pr = a.pairs[pair];
+			qa = a.qcodes + a.qoff[pr.qa]; lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
+			if (pr.qb >= 0) { qb = a.qcodes + a.qoff[pr.qb]; lenb = (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]); }
+			rows_total = ((lena > lenb ? lena : lenb) + 15) & ~15;
+			p8a = (lena + 7) & ~7; p8b = qb ? (lenb + 7) & ~7 : rows_total;
+			const int tile_lo = t * a.tile, tile_hi = tile_lo + a.tile < a.refLen ? tile_lo + a.tile : a.refLen;
+			const int c_first = tile_lo - a.halo > 0 ? tile_lo - a.halo : 0;
+			x.c_edge = c_first; x.ncols = tile_hi - c_first; x.store_from = tile_lo - c_first;
+			x.o16 = a.cm16 + (int64_t)pair * a.cm_stride + c_first; x.o8 = a.cm8 + (int64_t)pair * a.cm_stride + c_first;
+			active = true;
+		}
+	} else {
+		q = valid ? a.qlist[job] : -1;
+		if (q >= 0) { r = a.res[q]; active = r.status == 0 && r.score1 > 0 && (a.reverse ? r.want_begin != 0 : 1); }
+		if (active) {
+			qa = a.qcodes + a.qoff[q];
+			qlen = (int)(a.qoff[q + 1] - a.qoff[q]);
+			lena = a.reverse ? r.read_end1 + 1 : qlen;
+			rev = a.reverse;
+			rows_total = (lena + 15) & ~15;
+			long long w = (long long)rows_total + ((long long)rows_total * (a.maxmat > 0 ? a.maxmat : 0) + a.gapE - 1) / (a.gapE > 0 ? a.gapE : 1) + 1;
+			if (a.gapE <= 0 || w > r.ref_end1) w = r.ref_end1;
+			x.ncols = (int)w + 1;
+			x.c_edge = a.reverse ? r.ref_end1 : r.ref_end1 - (int)w;
+			x.dirstep = a.reverse ? -1 : 1;
+		}
+	}
+	const int S = active ? (rows_total + 16 * R - 1) / (16 * R) : 0;
+	int maxS = S, mc = x.ncols;
+#pragma unroll
+	for (int sh = 16; sh < 64; sh <<= 1) {
+		const int o1 = (int)xl_shfl((u32)maxS, (tid + sh) & 63), o2 = (int)xl_shfl((u32)mc, (tid + sh) & 63);
+		maxS = o1 > maxS ? o1 : maxS; mc = o2 > mc ? o2 : mc;
+	}
+	x.nsteps = (mc + 16 + 15) & ~15;
+	x.bnd = a.bnd + (int64_t)(valid ? job : 0) * a.bnd_stride * 4;
+
+	ChainState<R> st;
+	st.best = 0; st.btc = 0x7fffffff; st.brow = 0;
+	u32 m8[R];
+	for (int sidx = 0; sidx < maxS; ++sidx) {
+		x.mine = sidx < S; x.first = sidx == 0; x.last = sidx == S - 1; x.row0 = sidx * 16 * R;
+		build_profile_strip<R>(lds, x.prof, l16, 16, a.mat, a.n, qa, lena, rev, qb, lenb, x.row0, x.mine ? rows_total : 0);
+		bool need_mask = false;
+		if (!CAPTURE) {
+			need_mask = x.mine && x.last && (p8a < rows_total || p8b < rows_total);
+#pragma unroll
+			for (int k = 0; k < R; ++k) {
+				const int row = x.row0 + l16 * R + k;
+				m8[k] = (row < p8a ? 0xffffu : 0u) | (row < p8b ? 0xffff0000u : 0u);
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < R; ++k) m8[k] = 0;
+		}
+		if (!CAPTURE && wave_any(need_mask)) run_strip<R, CAPTURE, true>(lds, x, st, m8);
+		else run_strip<R, CAPTURE, false>(lds, x, st, m8);
+	}
+
+	if (CAPTURE) {
+		lds_st32(lds, red + 12u * l16, (u32)st.best);
+		lds_st32(lds, red + 12u * l16 + 4, (u32)st.btc);
+		lds_st32(lds, red + 12u * l16 + 8, (u32)st.brow);
+		wave_lds_fence();
+		if (l16 == 0 && active) {
+			int bv = 0, bc = 0x7fffffff, br = 0;
+			for (int k = 0; k < 16; ++k) {
+				const int v = (int)lds_ld32(lds, red + 12u * k), c = (int)lds_ld32(lds, red + 12u * k + 4), w = (int)lds_ld32(lds, red + 12u * k + 8);
+				if (v > bv || (v == bv && v > 0 && (c < bc || (c == bc && w < br)))) { bv = v; bc = c; br = w; }
+			}
+			if (!a.reverse) {
+				a.res[q].read_end1 = (bv == r.score1) ? (br < qlen - 1 ? br : qlen - 1) : -1;
+				if (bv != r.score1) a.res[q].status = 3;
+			} else {
+				if (bv != r.score1 && x.ncols <= r.ref_end1) a.res[q].status = 3;
+				else {
+					const int rb = r.ref_end1 - bc, qbeg = r.read_end1 - (br < lena - 1 ? br : lena - 1);
+					a.res[q].ref_begin1 = rb; a.res[q].read_begin1 = qbeg; a.res[q].rev_score = bv;
+					if (r.score1 > bv) a.res[q].flag = 2;
+					const int skip = (7 & a.flag) == 0 || ((2 & a.flag) != 0 && r.score1 < a.filters) ||
+					                 ((4 & a.flag) != 0 && (r.ref_end1 - rb > a.filterd || r.read_end1 - qbeg > a.filterd));
+					a.res[q].want_cigar = !skip;
+				}
+			}
+		}
+	}
+}
+
+/* ================================================================================================
  * k_trace: banded_sw + cigar re-score + band retry, one thread per alignment (scalar int32, exactly the
  * reference's control flow; the band of short reads is a handful of cells wide).
  * ================================================================================================ */
@@ -706,6 +982,22 @@ extern "C" int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* s
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = 4 * ((size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + CHAIN_BYTES); \
 		SSW_LAUNCH(k_capture<r>, ssw_capture_args, args, grid, 64, ldsb, stream); } break;
+		FOR_EACH_R(X)
+#undef X
+		default: return -2;
+	}
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args* a, void* stream)
+{
+	ssw_chainx_args args = *a;
+	if (args.njobs <= 0) return 0;
+	const int grid = (args.njobs + 3) / 4;
+	switch (R) {
+#define X(r) case r: { const size_t ldsb = 4 * ((size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + CHAINX_BYTES); \
+		if (capture) SSW_LAUNCH((k_chainx<r, true>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
+		else SSW_LAUNCH((k_chainx<r, false>), ssw_chainx_args, args, grid, 64, ldsb, stream); } break;
 		FOR_EACH_R(X)
 #undef X
 		default: return -2;

@@ -117,10 +117,7 @@ def test_unsupported_parameters_fail_loudly(ectx):
     Q = ectx.upload([ref[:30]]); T = ectx.upload([ref])
     with pytest.raises(RuntimeError, match="gap open > gap extension"):
         ectx.align_batch(Q, T, dna_matrix(2, 2), 5, 1, 1)
-    Q2 = ectx.upload([np.zeros(500, dtype=np.int8)])
-    with pytest.raises(RuntimeError, match="query length"):
-        ectx.align_batch(Q2, T, dna_matrix(2, 2), 5, 3, 1)
-    Q.free(); Q2.free(); T.free()
+    Q.free(); T.free()
 
 
 def test_single_pair_abi_on_emulator(emu_lib_path):

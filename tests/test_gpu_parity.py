@@ -195,3 +195,41 @@ def test_cross_lane_primitives_match_isa_semantics(gpu_ctx):
     assert (h[0, :, 0] == np.minimum(32767, 30000 + lane * 100)).all() and (h[0, :, 1] == np.maximum(-32768, -30000 - lane * 100)).all()
     assert (h[1, :, 0] == np.maximum(0, lane - 10)).all() and (h[1, :, 1] == np.maximum(0, 5 - lane)).all()
     assert (h[2, :, 0] == np.maximum(lane - 32, 0)).all() and (h[2, :, 1] == np.maximum(3, lane - 60)).all()
+
+
+def test_long_queries_row_strips(gpu_ctx):
+    """queries longer than 384 residues run as row strips with boundary hand-off (k_chainx)"""
+    rng = np.random.default_rng(21)
+    ref = random_ref(6000, 77, 4, 0.005)
+    lens = [385, 400, 401, 408, 409, 512, 777, 1000, 1537, 2000, 3000, 390]
+    reads = make_reads(rng, ref, 36, lens, 4, sub=0.03, ins=0.01, dele=0.01, frac_random=0.1)
+    for flag in (0, 2, 9):
+        _run(gpu_ctx, reads, [ref], dna_matrix(2, 2), 5, flag=flag)
+    _run(gpu_ctx, reads, [ref], dna_matrix(2, 2), 5, flag=1, maskLen=15, ss=1)
+    # proteins up to ~1000 residues (BASELINE config 5 length range), BLOSUM50
+    bg = rng.integers(0, 20, size=3000, dtype=np.int8)
+    preads = make_reads(rng, bg, 16, [450, 390, 600, 999, 385, 1000, 50, 300], 20, sub=0.15)
+    _run(gpu_ctx, preads, [bg[:1200].copy(), bg[500:2500].copy()], blosum50(), 24, flag=2)
+
+
+def test_long_queries_tiled_target(gpu_ctx):
+    """long queries against a target long enough to be tiled: strips x tiles x halo"""
+    rng = np.random.default_rng(22)
+    ref = random_ref(200_000, 78, 4)
+    reads = make_reads(rng, ref, 12, [400, 450, 390, 401, 640, 1000], 4, sub=0.03, ins=0.005, dele=0.005, frac_random=0.0)
+    _run(gpu_ctx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
+
+
+def test_config4_shape_sample(gpu_ctx):
+    """BASELINE config 4 shape: 10 kb queries vs a 100 kb target with traceback (flag 2); a sample against the reference"""
+    rng = np.random.default_rng(23)
+    ref = random_ref(100_000, 3, 4)
+    reads = make_reads(rng, ref, 24, [10000], 4, sub=0.01, ins=0.0025, dele=0.0025, frac_random=0.0)
+    res, cig = _run(gpu_ctx, reads, [ref], dna_matrix(2, 2), 5, flag=2, maskLen=5000, check=[0, 7, 23])
+    assert (res["score1"][:, 0] > 15000).all() and (res["cigarLen"][:, 0] > 0).all()
+    for i in range(24):     # every CIGAR is consistent with its coordinates
+        r = res[i, 0]
+        ops = cig[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["cigarLen"])]
+        m = sum(int(x >> 4) for x in ops if (x & 15) == 0); ins = sum(int(x >> 4) for x in ops if (x & 15) == 1)
+        de = sum(int(x >> 4) for x in ops if (x & 15) == 2)
+        assert m + ins == r["read_end1"] - r["read_begin1"] + 1 and m + de == r["ref_end1"] - r["ref_begin1"] + 1
