@@ -36,6 +36,7 @@ template <int N> SSW_DEV u32 xl_row_ror(u32 v) { return (u32)__builtin_amdgcn_mo
 SSW_DEV u32 xl_shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 64); }
 SSW_DEV bool wave_any(bool p) { return __any(p) != 0; }
 SSW_DEV bool wave_all(bool p) { return __all(p) != 0; }
+SSW_DEV unsigned long long wave_ballot(bool p) { return __ballot(p); }
 SSW_DEV void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
 /* LDS accessors with byte offsets into the dynamic segment */

@@ -56,6 +56,31 @@ typedef struct {
 	int64_t cm_stride;
 } ssw_fill_args;
 
+/*
+ * database search (many short targets, scores + end positions only): one workgroup = one query pair against 16
+ * targets; the chain also tracks the best cell and reduces its own column maxima, so one launch produces final records.
+ */
+typedef struct {
+	const int8_t* tcodes;    /* all target codes */
+	const int64_t* toff;     /* target offsets (device) */
+	const int32_t* tlist;    /* targets of this launch, sorted by length */
+	int32_t ntl;
+	int32_t tfirst;          /* res index of target t is (t - tfirst) */
+	int32_t res_nt;          /* targets per query in res */
+	const int8_t* qcodes;
+	const int64_t* qoff;
+	const ssw_pair* pairs;
+	int32_t npairs;
+	const int8_t* mat;
+	int32_t n;
+	uint32_t gapO2, gapE2;
+	uint32_t* cm16;          /* [npairs * ntl][cm_stride] */
+	uint32_t* cm8;
+	int64_t cm_stride;
+	int32_t maskLen, bias, score_size;
+	ssw_dres* res;           /* [query][res_nt] */
+} ssw_filldb_args;
+
 /* reduction of the column maxima into score1 / ref_end1 / score2 / ref_end2 */
 typedef struct {
 	const uint32_t* cm16;
@@ -122,6 +147,31 @@ typedef struct {
 	int64_t bnd_stride;
 } ssw_chainx_args;
 
+/*
+ * literal lane model (k_literal): for gap penalties with gapO <= gapE the reference's answer depends on its striped
+ * SIMD layout and on when its lazy-F loop stops, so one DPP row re-enacts one SSE2 register -- 16 unsigned 8-bit
+ * lanes (sw_sse2_byte) or 8 signed 16-bit lanes (sw_sse2_word) -- instruction for instruction.
+ * pass 0: forward fill (8-bit rules, then 16-bit on overflow) -> score1/ref_end1/read_end1/score2/ref_end2;
+ * pass 1: reverse fill with `terminate` -> begin position.
+ */
+typedef struct {
+	const int8_t* tgt;
+	int32_t refLen;
+	const int8_t* qcodes;
+	const int64_t* qoff;
+	const int32_t* qlist;
+	int32_t nq;
+	const int8_t* mat;
+	int32_t n;
+	int32_t gapO, gapE;
+	int32_t pass;
+	int32_t maskLen, bias, score_size;
+	int32_t flag, filters, filterd;
+	ssw_dres* res;
+	uint8_t* scratch;        /* nq regions of scratch_stride bytes */
+	int64_t scratch_stride;
+} ssw_literal_args;
+
 /* banded traceback */
 typedef struct {
 	const int8_t* tgt;
@@ -177,9 +227,11 @@ float ssw_shim_event_elapsed_ms(void* start, void* stop);   /* both must have co
 
 int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream);
 int ssw_shim_fill_resident_blocks(int R, int n);
+int ssw_shim_launch_filldb(int R, const ssw_filldb_args* a, void* stream);
 int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream);
 int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* stream);
 int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args* a, void* stream);
+int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream);
 int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);
 int ssw_shim_launch_gather(const ssw_gather_args* a, void* stream);
 int ssw_shim_launch_selftest(const ssw_selftest_args* a, int blocks, void* stream);

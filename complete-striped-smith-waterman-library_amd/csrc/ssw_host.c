@@ -34,7 +34,7 @@ struct ssw_gpu_ctx {
 	void* stream;
 	char err[512];
 	ssw_gpu_timing tm;
-	dbuf mat, pairs, qlist, res, cm16, cm8, scratch, cigar, need, goff, gpool, bnd;
+	dbuf mat, pairs, qlist, res, cm16, cm8, scratch, cigar, need, goff, gpool, bnd, tlist;
 	void** ev; int nev, capev;          /* event pairs around fill launches */
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
@@ -99,7 +99,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_set_device(c->device);
 	ssw_shim_stream_sync(c->stream);
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
-	dbuf_free(&c->cm8); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd);
+	dbuf_free(&c->cm8); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
 	free(c->ev);
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
@@ -169,6 +169,88 @@ static int keyed_cmp(const void* a, const void* b)
 	return x->q < y->q ? -1 : (x->q > y->q);
 }
 
+/*
+ * Database-search path: many short targets, flag == 0.  One fused launch (k_filldb) per (bucket, target chunk) instead
+ * of three launches per target; targets are sorted by length so that the 16 chains of a workgroup finish together.
+ */
+typedef struct { int32_t len, t; } tkey;
+static int tkey_cmp(const void* a, const void* b)
+{
+	const tkey* x = (const tkey*)a; const tkey* y = (const tkey*)b;
+	if (x->len != y->len) return x->len < y->len ? -1 : 1;
+	return x->t < y->t ? -1 : (x->t > y->t);
+}
+
+static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
+                    const ssw_gpu_params* prm, ssw_gpu_result* results, const bucket* bk, int nb, const ssw_pair* d_pairs,
+                    const int8_t* d_mat, int32_t bias, int32_t maxtlen)
+{
+	const int32_t nq = Q->count, n = prm->n;
+	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
+	const int64_t stride = ((int64_t)maxtlen + 15) / 16 * 16 + 16;
+	int rc = -1;
+	tkey* tk = (tkey*)malloc(sizeof(tkey) * (size_t)tcount);
+	int32_t* tl = (int32_t*)malloc(sizeof(int32_t) * (size_t)tcount);
+	ssw_dres* hres = 0;
+	/* result records of a sub-batch of targets stay in HBM until the sub-batch is done */
+	int64_t tsub = (int64_t)(c->cm_budget / 2) / ((int64_t)nq * (int64_t)sizeof(ssw_dres));
+	if (tsub < 16) tsub = 16;
+	if (tsub > tcount) tsub = tcount;
+	hres = (ssw_dres*)malloc(sizeof(ssw_dres) * (size_t)nq * (size_t)tsub);
+	for (int32_t t0 = 0; t0 < tcount; t0 += (int32_t)tsub) {
+		const int32_t nt = tcount - t0 < tsub ? tcount - t0 : (int32_t)tsub;
+		for (int32_t k = 0; k < nt; ++k) { tk[k].t = tfirst + t0 + k; tk[k].len = (int32_t)(T->h_off[tfirst + t0 + k + 1] - T->h_off[tfirst + t0 + k]); }
+		qsort(tk, (size_t)nt, sizeof(tkey), tkey_cmp);
+		int32_t nz = 0;
+		for (int32_t k = 0; k < nt; ++k) if (tk[k].len > 0) tl[nz++] = tk[k].t;      /* empty targets keep their zeroed records */
+		ssw_dres* d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq * (size_t)nt);
+		int32_t* d_tl = (int32_t*)ensure(c, &c->tlist, sizeof(int32_t) * (size_t)(nz > 0 ? nz : 1));
+		if (!d_res || !d_tl) goto done;
+		if (ssw_shim_memset(d_res, 0, sizeof(ssw_dres) * (size_t)nq * (size_t)nt, c->stream) ||
+		    ssw_shim_h2d(d_tl, tl, sizeof(int32_t) * (size_t)nz, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
+		for (int b = 0; b < nb && nz > 0; ++b) {
+			const bucket* B = &bk[b];
+			int64_t per = (int64_t)(c->cm_budget / 2) / (8 * stride * (int64_t)B->npairs);   /* targets per launch */
+			per = per / 16 * 16; if (per < 16) per = 16;
+			int64_t cap = per < nz ? per : nz;
+			uint32_t* d_cm16 = (uint32_t*)ensure(c, &c->cm16, (size_t)(4 * stride * cap * B->npairs));
+			uint32_t* d_cm8 = (uint32_t*)ensure(c, &c->cm8, (size_t)(4 * stride * cap * B->npairs));
+			if (!d_cm16 || !d_cm8) goto done;
+			for (int32_t k0 = 0; k0 < nz; k0 += (int32_t)per) {
+				ssw_filldb_args fa;
+				fa.tcodes = T->d_codes; fa.toff = T->d_off; fa.tlist = d_tl + k0; fa.ntl = nz - k0 < per ? nz - k0 : (int32_t)per;
+				fa.tfirst = tfirst + t0; fa.res_nt = nt; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off; fa.pairs = d_pairs + B->first_pair;
+				fa.npairs = B->npairs; fa.mat = d_mat; fa.n = n; fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.cm16 = d_cm16; fa.cm8 = d_cm8;
+				fa.cm_stride = stride; fa.maskLen = prm->maskLen; fa.bias = bias; fa.score_size = prm->score_size; fa.res = d_res;
+				void* e0 = next_event(c); void* e1 = next_event(c);
+				ssw_shim_event_record(e0, c->stream);
+				if (ssw_shim_launch_filldb(B->R, &fa, c->stream)) { fail(c, "filldb launch failed: %s", ssw_shim_last_error()); goto done; }
+				ssw_shim_event_record(e1, c->stream);
+				c->tm.fill_launches++;
+				for (int32_t k = 0; k < fa.ntl; ++k)
+					c->tm.fill_cells += (T->h_off[tl[k0 + k] + 1] - T->h_off[tl[k0 + k]]) * (int64_t)B->P16 * 2 * B->npairs;
+			}
+		}
+		if (ssw_shim_d2h(hres, d_res, sizeof(ssw_dres) * (size_t)nq * (size_t)nt, c->stream) || ssw_shim_stream_sync(c->stream)) {
+			fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
+		}
+		for (int32_t q = 0; q < nq; ++q)
+			for (int32_t k = 0; k < nt; ++k) {
+				const ssw_dres* r = &hres[(int64_t)q * nt + k];
+				ssw_gpu_result* o = &results[(int64_t)q * tcount + t0 + k];
+				o->score1 = (uint16_t)r->score1; o->score2 = (uint16_t)r->score2; o->ref_begin1 = -1; o->ref_end1 = r->ref_end1;
+				o->read_begin1 = -1; o->read_end1 = r->read_end1; o->ref_end2 = r->ref_end2; o->cigarLen = 0; o->cigar_off = -1;
+				o->flag = 0; o->status = (uint16_t)r->status;
+				if (r->status == 0 && r->score1 > 0) { if (r->word) c->tm.n_word++; else c->tm.n_byte++; }
+				c->tm.cells += (Q->h_off[q + 1] - Q->h_off[q]) * (T->h_off[tfirst + t0 + k + 1] - T->h_off[tfirst + t0 + k]);
+			}
+	}
+	rc = 0;
+done:
+	free(tk); free(tl); free(hres);
+	return rc;
+}
+
 int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
                         const ssw_gpu_params* prm, ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words)
 {
@@ -178,9 +260,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 	if (tfirst < 0 || tcount < 0 || tfirst + tcount > T->count) return fail(c, "align_batch: target range out of bounds%s", "");
 	if (prm->n < 1 || prm->n > SSW_MAX_N) return fail(c, "align_batch: alphabet size must be 1..32%s", "");
 	if (prm->score_size < 0 || prm->score_size > 2) return fail(c, "align_batch: score_size must be 0, 1 or 2%s", "");
-	if (prm->gapO <= prm->gapE)
-		return fail(c, "align_batch: unsupported gap penalties: the GPU path requires gap open > gap extension "
-		               "(the reference's result depends on its SIMD stripe layout otherwise)%s", "");
+	const int literal = prm->gapO <= prm->gapE;   /* layout-dependent regime of the reference: lane-model kernel (k_literal) */
 	ssw_shim_set_device(c->device);
 	if (cigar_pool) *cigar_pool = 0;
 	if (cigar_words) *cigar_words = 0;
@@ -252,6 +332,23 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
 	double fill_ms = 0, reduce_ms = 0, locate_ms = 0, trace_ms = 0;
 
+	{   /* database search: scores only, several short targets, short queries -> fused kernel */
+		int all_short = 1; int64_t maxt = 0;
+		for (int b = 0; b < nb; ++b) if (bk[b].strips > 1) all_short = 0;
+		for (int32_t ti = 0; ti < tcount; ++ti) { int64_t L = T->h_off[tfirst + ti + 1] - T->h_off[tfirst + ti]; if (L > maxt) maxt = L; }
+		const char* dis = getenv("SSW_GPU_NO_DB");
+		if (!literal && prm->flag == 0 && tcount >= 4 && all_short && maxt <= 65536 && !(dis && dis[0] == '1')) {
+			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt)) goto done;
+			ssw_shim_event_record(c->ev_d, c->stream);
+			if (ssw_shim_stream_sync(c->stream)) { fail(c, "stream sync failed: %s", ssw_shim_last_error()); goto done; }
+			for (int e = 0; e + 1 < c->nev; e += 2) fill_ms += ssw_shim_event_elapsed_ms(c->ev[e], c->ev[e + 1]);
+			c->tm.total_ms = ssw_shim_event_elapsed_ms(c->ev_t0, c->ev_d); c->tm.fill_ms = fill_ms;
+			c->tm.reduce_ms = c->tm.total_ms - fill_ms; if (c->tm.reduce_ms < 0) c->tm.reduce_ms = 0;
+			rc = 0;
+			goto done;
+		}
+	}
+
 	for (int32_t ti = 0; ti < tcount; ++ti) {
 		const int32_t t = tfirst + ti;
 		const int64_t refLen64 = T->h_off[t + 1] - T->h_off[t];
@@ -261,7 +358,30 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 		const int ev_first = c->nev;
 		if (ssw_shim_memset(d_res, 0, sizeof(ssw_dres) * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
 
-		if (refLen > 0) {
+		if (refLen > 0 && literal) {
+			/* scratch per alignment: 4 x [segments][16] int16 + codes + maxColumn (sized for the 16-bit kernel: 8 lanes) */
+			const int64_t seg8 = ((int64_t)maxlen + 7) / 8;
+			const int64_t sstr = (seg8 * 16 * 2 * 4 + seg8 * 16 + 64 + (int64_t)refLen * 2 + 64 + 15) / 16 * 16;
+			int64_t per = (int64_t)(c->cm_budget / (size_t)sstr); if (per < 1) per = 1;
+			void* e0 = next_event(c); void* e1 = next_event(c);
+			ssw_shim_event_record(e0, c->stream);
+			for (int pass = 0; pass < (prm->flag != 0 ? 2 : 1); ++pass)
+				for (int32_t q0 = 0; q0 < nq; q0 += (int32_t)per) {
+					const int32_t cnt_q = nq - q0 < per ? nq - q0 : (int32_t)per;
+					uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)(sstr * cnt_q));
+					if (!d_scr) goto done;
+					ssw_literal_args la;
+					la.tgt = d_tgt; la.refLen = refLen; la.qcodes = Q->d_codes; la.qoff = Q->d_off; la.qlist = d_qlist + q0; la.nq = cnt_q;
+					la.mat = d_mat; la.n = n; la.gapO = prm->gapO; la.gapE = prm->gapE; la.pass = pass; la.maskLen = prm->maskLen; la.bias = bias;
+					la.score_size = prm->score_size; la.flag = prm->flag; la.filters = prm->filters; la.filterd = prm->filterd; la.res = d_res;
+					la.scratch = d_scr; la.scratch_stride = sstr;
+					if (ssw_shim_launch_literal(&la, c->stream)) { fail(c, "literal launch failed: %s", ssw_shim_last_error()); goto done; }
+				}
+			ssw_shim_event_record(e1, c->stream);
+			c->tm.fill_launches++;
+			for (int32_t q = 0; q < nq; ++q) c->tm.fill_cells += (Q->h_off[q + 1] - Q->h_off[q]) * (int64_t)refLen;
+		}
+		if (refLen > 0 && !literal) {
 			const int64_t stride = ((int64_t)refLen + 15) / 16 * 16 + 16;
 			for (int b = 0; b < nb; ++b) {
 				const bucket* B = &bk[b];
@@ -332,7 +452,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 		}
 		ssw_shim_event_record(c->ev_a, c->stream);
 
-		if (refLen > 0) {   /* read_end1 always (ssw.c:342-351); begin position only when asked for (ssw.c:916) */
+		if (refLen > 0 && !literal) {   /* read_end1 always (ssw.c:342-351); begin position only when asked for (ssw.c:916) */
 			for (int pass = 0; pass < (prm->flag != 0 ? 2 : 1); ++pass)
 				for (int b = 0; b < nb; ++b) {
 					const bucket* B = &bk[b];
@@ -406,6 +526,8 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 						}
 				}
 				did_trace = 1;
+				if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace attempt %d: %d alignments, scratch %lld B each, %d need more (max %lld B)\n",
+				                                     attempt, nlist, (long long)sstride, nretry, (long long)maxneed);
 				free(retry); retry = nextlist; list = retry; nlist = nretry;
 				if (nlist > 0) {
 					/* jump straight to the worst case of the remaining alignments' full band */

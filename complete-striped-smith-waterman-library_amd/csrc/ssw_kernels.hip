@@ -209,6 +209,196 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 }
 
 /* ================================================================================================
+ * k_filldb: database search.  Same chains as k_fill, but the 16 chains of a workgroup take 16 different (short,
+ * untiled) targets, each lane also remembers where the running column maximum last grew, and the chain reduces its
+ * own column maxima afterwards: score1 / ref_end1 / read_end1 / score2 / ref_end2 come out of ONE launch.
+ * grid = npairs * ceil(ntl / 16) workgroups of 256 threads.
+ * ================================================================================================ */
+template <int R>
+__global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
+{
+	typedef ChainGeom<R> G;
+	constexpr int C = G::C;
+	SSW_DYN_LDS(lds);
+	const int tid = (int)threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+	const int tchunks = (a.ntl + 15) / 16;
+	const int pair = (int)blockIdx.x / tchunks, tchunk = (int)blockIdx.x - pair * tchunks;
+	const u32 prof_bytes = (u32)(a.n + 1) * G::PSTRIDE;
+	const u32 ring = prof_bytes + (u32)grp * CHAIN_BYTES, out16 = ring + RING_BYTES, out8 = out16 + 256;
+	const u32 nulloff = (u32)a.n * G::PSTRIDE;
+	const ssw_pair pr = a.pairs[pair];
+	const int lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
+	const int lenb = pr.qb >= 0 ? (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]) : 0;
+	build_profile<R>(lds, 0, tid, 256, a.mat, a.n, a.qcodes + a.qoff[pr.qa], lena, 0,
+	                 pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0, lenb);
+
+	const int slot = tchunk * 16 + grp;
+	const bool active = slot < a.ntl;
+	const int t = active ? a.tlist[slot] : 0;
+	const int8_t* tg = a.tcodes + a.toff[t];
+	const int ncols = active ? (int)(a.toff[t + 1] - a.toff[t]) : 0;
+	uint32_t* o16 = a.cm16 + ((int64_t)pair * a.ntl + (active ? slot : 0)) * a.cm_stride;
+	uint32_t* o8 = a.cm8 + ((int64_t)pair * a.ntl + (active ? slot : 0)) * a.cm_stride;
+	/* uniform step count of the workgroup: the longest of its 16 targets (lists are sorted by length) */
+	int maxcols = 0;
+	{
+		const int last = tchunk * 16 + 15 < a.ntl ? tchunk * 16 + 15 : a.ntl - 1;
+		for (int k = tchunk * 16; k <= last; ++k) { const int tt = a.tlist[k]; const int L = (int)(a.toff[tt + 1] - a.toff[tt]); maxcols = L > maxcols ? L : maxcols; }
+	}
+	const int nsteps = (maxcols + 16 + 15) & ~15;
+
+	lds_st16(lds, ring + 2u * (48 + l16), nulloff);
+	{
+		int code = l16 < ncols ? tg[l16] : a.n;
+		if (code < 0 || code > a.n) code = a.n;
+		const u32 off = (u32)code * G::PSTRIDE;
+		lds_st16(lds, ring + 2u * l16, off);
+		lds_st16(lds, ring + 2u * (64 + l16), off);
+	}
+	u32 nxt;
+	{
+		const int tc = 16 + l16;
+		int code = tc < ncols ? tg[tc] : a.n;
+		if (code < 0 || code > a.n) code = a.n;
+		nxt = (u32)code * G::PSTRIDE;
+	}
+	__syncthreads();
+
+	u32 H[R], E[R];
+#pragma unroll
+	for (int r = 0; r < R; ++r) { H[r] = 0; E[r] = 0; }
+	u32 Hlast = 0, Fout = 0, cmout = 0, ck = 0, hsave = 0;
+	u32 best = 0;                                   /* packed: highest running column maximum this lane has seen */
+	int btc[2] = { 0x7fffffff, 0x7fffffff }, brow[2] = { 0x7fffffff, 0x7fffffff };
+	const u32 lane_prof = (u32)l16 * 16u;
+
+	for (int s0 = 0; s0 < nsteps; s0 += 16) {
+		{
+			const int p = (s0 + 16 + l16) & 63;
+			lds_st16(lds, ring + 2u * p, nxt);
+			if (p < 16) lds_st16(lds, ring + 2u * (64 + p), nxt);
+			const int tc = s0 + 32 + l16;
+			int code = tc < ncols ? tg[tc] : a.n;
+			if (code < 0 || code > a.n) code = a.n;
+			nxt = (u32)code * G::PSTRIDE;
+		}
+		wave_lds_fence();
+		if (s0 >= 32) {
+			const int tc = s0 - 32 + l16;
+			if (tc < ncols) {
+				o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
+				o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
+			}
+		}
+		wave_lds_fence();
+		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
+		const u32 ob16 = out16 + 4u * (u32)((s0 - 16) & 63), ob8 = out8 + 4u * (u32)((s0 - 16) & 63);
+#pragma unroll 4
+		for (int j = 0; j < 16; ++j) {
+			const int tc = s0 + j - l16;
+			const u32 paddr = lds_ld16(lds, rp + 2u * j) + lane_prof;
+			u32x4 sc[C];
+#pragma unroll
+			for (int c = 0; c < C; ++c) sc[c] = lds_ld128(lds, paddr + 256u * c);
+			const u32 hin = xl_row_shr1_zero(Hlast);
+			u32 f = xl_row_shr1_zero(Fout);
+			const u32 x = xl_row_ror<1>(cmout);
+			const u32 x8 = xl_row_ror<16 - G::TAP>(ck);
+			u32 cm = x;
+			if (l16 == 0) {
+				lds_st32(lds, ob16 + 4u * j, x);
+				lds_st32(lds, ob8 + 4u * j, x8);
+				cm = 0;
+			}
+			chain_rows<R, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);
+			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
+			/* best cell: the first lane (top-down) whose running maximum reaches a new high holds its smallest row */
+			const u32 nb = pk_max(best, cm);
+			if (nb != best && tc >= 0 && tc < ncols) {
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const int nv = (int)((nb >> (16 * h)) & 0xffffu), ov = (int)((best >> (16 * h)) & 0xffffu);
+					if (nv > ov) {
+						btc[h] = tc; brow[h] = 0x7fffffff;
+#pragma unroll
+						for (int k = R - 1; k >= 0; --k) if ((int)((H[k] >> (16 * h)) & 0xffffu) == nv) brow[h] = l16 * R + k;
+					}
+				}
+				best = nb;
+			}
+		}
+	}
+	wave_lds_fence();
+	for (int base = nsteps - 32; base < nsteps; base += 16) {
+		const int tc = base + l16;
+		if (tc >= 0 && tc < ncols) {
+			o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
+			o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
+		}
+	}
+	dev_fence();   /* the chain re-reads its own column maxima below */
+
+	/* ---- per chain, per query: reduce (the role of k_reduce + the locate pass) ---- */
+	const u32 red = ring;   /* the rings are free now: 16 lanes x 16 bytes */
+	for (int h = 0; h < 2; ++h) {
+		const int q = h ? pr.qb : pr.qa;
+		if (q < 0) continue;                         /* uniform in the workgroup */
+		const int len = h ? lenb : lena;
+		const int myv = (int)((best >> (16 * h)) & 0xffffu);
+		lds_st32(lds, red + 16u * l16, (u32)myv);
+		lds_st32(lds, red + 16u * l16 + 4, (u32)btc[h]);
+		lds_st32(lds, red + 16u * l16 + 8, (u32)brow[h]);
+		wave_lds_fence();
+		int bv = 0, bc = 0x7fffffff, br = 0x7fffffff;
+		for (int k = 0; k < 16; ++k) {               /* every lane computes the same winner: value, then column, then lane order */
+			const int v = (int)lds_ld32(lds, red + 16u * k), cc = (int)lds_ld32(lds, red + 16u * k + 4), w = (int)lds_ld32(lds, red + 16u * k + 8);
+			if (v > bv || (v == bv && v > 0 && cc < bc)) { bv = v; bc = cc; br = w; }
+		}
+		wave_lds_fence();
+		const bool padded = (len & 15) >= 1 && (len & 15) <= 8;
+		const int maskLen = a.maskLen >= 0 ? a.maskLen : len / 2;
+		const bool have_byte = a.score_size == 0 || a.score_size == 2, have_word = a.score_size == 1 || a.score_size == 2;
+		int word = 0, status = 0;
+		if (have_byte && bv < 255 - a.bias) word = 0;
+		else if (have_word) word = 1;
+		else status = 1;
+		int s2 = 0, i2 = 0x7fffffff;
+		if (status == 0 && bv > 0) {
+			const uint32_t* arr = (word && padded) ? o8 : o16;
+			const int lo_edge = bc - maskLen > 0 ? bc - maskLen : 0;
+			const int hi_edge = bc + maskLen > ncols ? ncols : bc + maskLen;
+			const int up_from = word ? hi_edge : hi_edge + 1;
+			for (int c = l16; c < ncols; c += 16) {
+				if (c < lo_edge || c >= up_from) {
+					const int v = (int)((arr[c] >> (16 * h)) & 0xffffu);
+					if (v > s2) { s2 = v; i2 = c; }
+				}
+			}
+		}
+		lds_st32(lds, red + 16u * l16, (u32)s2);
+		lds_st32(lds, red + 16u * l16 + 4, (u32)i2);
+		wave_lds_fence();
+		if (l16 == 0 && active) {
+			for (int k = 1; k < 16; ++k) {
+				const int v = (int)lds_ld32(lds, red + 16u * k), cc = (int)lds_ld32(lds, red + 16u * k + 4);
+				if (v > s2 || (v == s2 && cc < i2)) { s2 = v; i2 = cc; }
+			}
+			ssw_dres r;
+			r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = 0; r.read_begin1 = -1; r.read_end1 = 0;
+			r.ref_end2 = 0; r.cigarLen = 0; r.flag = 0; r.status = status; r.word = word; r.want_begin = 0; r.want_cigar = 0;
+			r.rev_score = 0; r.cigar_off = 0;
+			if (status == 0 && bv > 0) {
+				r.score1 = bv; r.ref_end1 = bc; r.read_end1 = br < len - 1 ? br : len - 1;
+				if (maskLen >= 15) { r.score2 = s2; r.ref_end2 = s2 > 0 ? i2 : 0; }
+				else { r.score2 = 0; r.ref_end2 = -1; }
+			}
+			a.res[(int64_t)q * a.res_nt + (t - a.tfirst)] = r;
+		}
+		wave_lds_fence();
+	}
+}
+
+/* ================================================================================================
  * k_reduce: one workgroup per pair; both queries of the pair.
  * ================================================================================================ */
 SSW_DEV int half16(u32 w, int hi) { return (int)((hi ? (w >> 16) : w) & 0xffffu); }
@@ -729,6 +919,214 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 }
 
 /* ================================================================================================
+ * k_literal: the reference's two SSE2 kernels re-enacted lane for lane (see ssw_dev.h).  One DPP row = one __m128i;
+ * 4 alignments per wavefront run in lockstep under per-row predicates.  Only used when gapO <= gapE.
+ * Per alignment scratch (HBM, L1/L2 resident): H buffers x2, E, Hmax as [segment][16] int16, read codes, maxColumn.
+ * ================================================================================================ */
+struct LitOut { int score, ref, read, score2, ref2; };
+
+SSW_DEV int lit_rowmax(int v)   /* maximum over the 16 lanes of a row, in every lane */
+{
+	u32 x = (u32)v;
+	u32 y = xl_row_ror<1>(x); x = (int)y > (int)x ? y : x;
+	y = xl_row_ror<2>(x); x = (int)y > (int)x ? y : x;
+	y = xl_row_ror<4>(x); x = (int)y > (int)x ? y : x;
+	y = xl_row_ror<8>(x); x = (int)y > (int)x ? y : x;
+	return (int)x;
+}
+SSW_DEV int lit_rowmin(int v) { return -lit_rowmax(-v); }
+
+/* one call == sw_sse2_byte (is_byte) / sw_sse2_word on one row of lanes; `on` = this row takes part */
+SSW_DEV void literal_fill(bool on, bool is_byte, const int8_t* ref, int ref_dir, int refLen, const int8_t* read, int readLen, int rev_read,
+                          const int8_t* mat, int n, int gapO, int gapE, int terminate, int bias, int maskLen,
+                          unsigned char* scratch, int tid, LitOut& out)
+{
+	const int l16 = tid & 15, grp = (tid & 63) >> 4;
+	const int L = is_byte ? 16 : 8;
+	const bool lane_on = on && l16 < L;
+	const int segLen = on ? (readLen + L - 1) / L : 0;
+	int16_t* Hbuf0 = (int16_t*)scratch;
+	int16_t* Hbuf1 = Hbuf0 + (size_t)segLen * 16;
+	int16_t* Eb = Hbuf1 + (size_t)segLen * 16;
+	int16_t* Hmx = Eb + (size_t)segLen * 16;
+	int8_t* code = (int8_t*)(Hmx + (size_t)segLen * 16);
+	uint16_t* mc = (uint16_t*)(code + (((size_t)segLen * 16 + 15) & ~(size_t)15));
+	/* uniform loop bounds for the 4 rows of the wavefront */
+	int maxseg = segLen, maxcol = on ? refLen : 0;
+#pragma unroll
+	for (int sh = 16; sh < 64; sh <<= 1) {
+		const int o1 = (int)xl_shfl((u32)maxseg, (tid + sh) & 63), o2 = (int)xl_shfl((u32)maxcol, (tid + sh) & 63);
+		maxseg = o1 > maxseg ? o1 : maxseg; maxcol = o2 > maxcol ? o2 : maxcol;
+	}
+	for (int j = 0; j < segLen; ++j) {
+		const int q = j + l16 * segLen;            /* striped layout: lane k holds rows k*segLen + j (ssw.c:169-186) */
+		Hbuf0[j * 16 + l16] = 0; Hbuf1[j * 16 + l16] = 0; Eb[j * 16 + l16] = 0; Hmx[j * 16 + l16] = 0;
+		code[j * 16 + l16] = (lane_on && q < readLen) ? (rev_read ? read[readLen - 1 - q] : read[q]) : (int8_t)-1;
+	}
+	for (int c = l16; c < (on ? refLen : 0); c += 16) mc[c] = 0;
+	dev_fence();
+
+	int max = 0, end_ref = is_byte ? -1 : 0, par = 0;
+	bool alive = on;
+	const int hi_sat = is_byte ? 255 : 32767;
+	for (int it = 0; it < maxcol; ++it) {
+		if (!wave_any(alive && it < refLen)) break;
+		const bool colact = alive && it < refLen;
+		const int i = ref_dir ? refLen - 1 - it : it;
+		int16_t* Hst = par ? Hbuf0 : Hbuf1;       /* after the swap of ssw.c:269-271 */
+		int16_t* Hld = par ? Hbuf1 : Hbuf0;
+		const int8_t* mrow = mat + (colact ? (int)ref[i] : 0) * n;
+		int prevlast = (colact && lane_on) ? (int)Hld[(segLen - 1) * 16 + l16] : 0;
+		int vH = (int)xl_row_shr1_zero((u32)prevlast);
+		int vF = 0, vMax = 0;
+		for (int j = 0; j < maxseg; ++j) {
+			const bool act = colact && lane_on && j < segLen;
+			if (act) {
+				const int cd = code[j * 16 + l16];
+				const int sc = cd >= 0 ? mrow[cd] : 0;
+				int h;
+				if (is_byte) { h = vH + sc + bias; if (h > 255) h = 255; h -= bias; if (h < 0) h = 0; }
+				else { h = vH + sc; if (h > 32767) h = 32767; if (h < -32768) h = -32768; }
+				int e = Eb[j * 16 + l16];
+				h = h > e ? h : e; h = h > vF ? h : vF;
+				vMax = vMax > h ? vMax : h;
+				Hst[j * 16 + l16] = (int16_t)h;
+				if (is_byte) { h = h - gapO; if (h < 0) h = 0; e = e - gapE; if (e < 0) e = 0; }
+				else { const unsigned uh = (uint16_t)h, ue = (uint16_t)e; h = (int16_t)(uint16_t)(uh > (unsigned)gapO ? uh - gapO : 0); e = (int16_t)(uint16_t)(ue > (unsigned)gapE ? ue - gapE : 0); }
+				e = e > h ? e : h;
+				Eb[j * 16 + l16] = (int16_t)e;
+				if (is_byte) { vF = vF - gapE; if (vF < 0) vF = 0; }
+				else { const unsigned uf = (uint16_t)vF; vF = (int16_t)(uint16_t)(uf > (unsigned)gapE ? uf - gapE : 0); }
+				vF = vF > h ? vF : h;
+				vH = Hld[j * 16 + l16];
+			}
+		}
+		/* lazy-F loop (ssw.c:302-315 / 509-520): stops as soon as no lane's F can still raise an H */
+		bool lazy = colact;
+		for (int k = 0; k < 16; ++k) {
+			if (!wave_any(lazy && k < L)) break;
+			const bool kact = lazy && k < L;
+			vF = (int)xl_row_shr1_zero((u32)vF);
+			for (int j = 0; j < maxseg; ++j) {
+				if (!wave_any(lazy && k < L && j < segLen)) break;
+				const bool act = kact && lazy && j < segLen;
+				bool more = false;
+				if (act && lane_on) {
+					int h = Hst[j * 16 + l16];
+					h = h > vF ? h : vF;
+					vMax = vMax > h ? vMax : h;
+					Hst[j * 16 + l16] = (int16_t)h;
+					if (is_byte) { h = h - gapO; if (h < 0) h = 0; vF = vF - gapE; if (vF < 0) vF = 0; }
+					else { const unsigned uh = (uint16_t)h, uf = (uint16_t)vF; h = (int16_t)(uint16_t)(uh > (unsigned)gapO ? uh - gapO : 0); vF = (int16_t)(uint16_t)(uf > (unsigned)gapE ? uf - gapE : 0); }
+					more = vF > h;
+				}
+				const unsigned long long b = wave_ballot(more);
+				if (act && ((b >> (16 * grp)) & 0xffffull) == 0) lazy = false;
+			}
+		}
+		(void)hi_sat;
+		const int cm = lit_rowmax(lane_on ? vMax : 0);
+		bool brk = false;
+		if (colact) {
+			if (cm > max) {
+				max = cm;
+				if (is_byte && max + bias >= 255) brk = true;
+				else {
+					end_ref = i;
+					for (int j = 0; j < segLen; ++j) Hmx[j * 16 + l16] = Hst[j * 16 + l16];
+				}
+			}
+			if (!brk) { if (l16 == 0) mc[i] = (uint16_t)cm; if (cm == terminate) brk = true; }
+			if (brk) alive = false;
+		}
+		par ^= 1;
+	}
+	dev_fence();
+	/* read end: smallest row holding the maximum in the saved column (ssw.c:342-351) */
+	int end_read = readLen - 1;
+	if (lane_on)
+		for (int j = 0; j < segLen; ++j)
+			if ((int)(is_byte ? (uint16_t)Hmx[j * 16 + l16] : Hmx[j * 16 + l16]) == max) { const int row = j + l16 * segLen; if (row < end_read) end_read = row; }
+	end_read = lit_rowmin(on ? end_read : 0x7fffffff);
+	/* second best (ssw.c:368-381 / 570-583) */
+	int s2 = 0, i2 = 0x7fffffff;
+	if (on) {
+		const int lo_edge = end_ref - maskLen > 0 ? end_ref - maskLen : 0;
+		const int hi_edge = end_ref + maskLen > refLen ? refLen : end_ref + maskLen;
+		const int up_from = is_byte ? hi_edge + 1 : hi_edge;
+		for (int c = l16; c < refLen; c += 16)
+			if (c < lo_edge || c >= up_from) { const int v = mc[c]; if (v > s2) { s2 = v; i2 = c; } }
+	}
+	const int s2m = lit_rowmax(s2);
+	const int i2m = lit_rowmin(s2 == s2m && s2m > 0 ? i2 : 0x7fffffff);
+	out.score = (is_byte && max + bias >= 255) ? 255 : max;
+	out.ref = end_ref; out.read = end_read; out.score2 = s2m; out.ref2 = s2m > 0 ? i2m : 0;
+}
+
+__global__ void __launch_bounds__(64) k_literal(ssw_literal_args a)
+{
+	const int tid = (int)threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+	const int job = (int)blockIdx.x * 4 + grp;
+	const int q = job < a.nq ? a.qlist[job] : -1;
+	unsigned char* scratch = a.scratch + (int64_t)(job < a.nq ? job : 0) * a.scratch_stride;
+	const int8_t* read = q >= 0 ? a.qcodes + a.qoff[q] : a.qcodes;
+	const int readLen = q >= 0 ? (int)(a.qoff[q + 1] - a.qoff[q]) : 0;
+	const int maskLen = a.maskLen >= 0 ? a.maskLen : readLen / 2;
+	const bool have_byte = a.score_size == 0 || a.score_size == 2, have_word = a.score_size == 1 || a.score_size == 2;
+	LitOut o;
+	if (a.pass == 0) {
+		ssw_dres r;
+		r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = 0; r.read_begin1 = -1; r.read_end1 = 0;
+		r.ref_end2 = 0; r.cigarLen = 0; r.flag = 0; r.status = 0; r.word = 0; r.want_begin = 0; r.want_cigar = 0;
+		r.rev_score = 0; r.cigar_off = 0;
+		bool need_word = q >= 0 && !have_byte;
+		bool done = q < 0;
+		if (wave_any(q >= 0 && have_byte)) {
+			literal_fill(q >= 0 && have_byte, true, a.tgt, 0, a.refLen, read, readLen, 0, a.mat, a.n, a.gapO, a.gapE, 255, a.bias, maskLen,
+			             scratch, tid, o);
+			if (q >= 0 && have_byte) {
+				if (o.score == 255) { if (have_word) need_word = true; else { r.status = 1; done = true; } }
+			}
+		}
+		if (wave_any(need_word)) {
+			LitOut w;
+			literal_fill(need_word, false, a.tgt, 0, a.refLen, read, readLen, 0, a.mat, a.n, a.gapO, a.gapE, 65535, 0, maskLen, scratch, tid, w);
+			if (need_word) { o = w; r.word = 1; }
+		}
+		if (q >= 0 && !done && o.score > 0) {
+			r.score1 = o.score; r.ref_end1 = o.ref; r.read_end1 = o.read;
+			if (maskLen >= 15) { r.score2 = o.score2; r.ref_end2 = o.ref2; } else { r.score2 = 0; r.ref_end2 = -1; }
+			r.want_begin = !(a.flag == 0 || (a.flag == 2 && o.score < a.filters));
+		}
+		if (q >= 0 && l16 == 0) a.res[q] = r;
+	} else {
+		ssw_dres r;
+		bool act = false;
+		if (q >= 0) { r = a.res[q]; act = r.status == 0 && r.score1 > 0 && r.want_begin != 0; }
+		const bool actb = act && !r.word, actw = act && r.word;
+		const int plen = act ? r.read_end1 + 1 : 0, cols = act ? r.ref_end1 + 1 : 0;
+		if (wave_any(actb)) {
+			LitOut w;
+			literal_fill(actb, true, a.tgt, 1, cols, read, plen, 1, a.mat, a.n, a.gapO, a.gapE, r.score1 & 0xff, a.bias, maskLen, scratch, tid, w);
+			if (actb) o = w;
+		}
+		if (wave_any(actw)) {
+			LitOut w;
+			literal_fill(actw, false, a.tgt, 1, cols, read, plen, 1, a.mat, a.n, a.gapO, a.gapE, r.score1 & 0xffff, 0, maskLen, scratch, tid, w);
+			if (actw) o = w;
+		}
+		if (act && l16 == 0) {
+			const int rb = o.ref, qb = r.read_end1 - o.read;
+			a.res[q].ref_begin1 = rb; a.res[q].read_begin1 = qb; a.res[q].rev_score = o.score;
+			if (r.score1 > o.score) a.res[q].flag = 2;
+			const int skip = (7 & a.flag) == 0 || ((2 & a.flag) != 0 && r.score1 < a.filters) ||
+			                 ((4 & a.flag) != 0 && (r.ref_end1 - rb > a.filterd || r.read_end1 - qb > a.filterd));
+			a.res[q].want_cigar = !skip;
+		}
+	}
+}
+
+/* ================================================================================================
  * k_trace: banded_sw + cigar re-score + band retry, one thread per alignment (scalar int32, exactly the
  * reference's control flow; the band of short reads is a handful of cells wide).
  * ================================================================================================ */
@@ -966,6 +1364,21 @@ extern "C" int ssw_shim_fill_resident_blocks(int R, int n)
 #endif
 }
 
+extern "C" int ssw_shim_launch_filldb(int R, const ssw_filldb_args* a, void* stream)
+{
+	ssw_filldb_args args = *a;
+	const int64_t grid = (int64_t)args.npairs * ((args.ntl + 15) / 16);
+	if (grid <= 0) return 0;
+	switch (R) {
+#define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
+		SSW_LAUNCH(k_filldb<r>, ssw_filldb_args, args, grid, 256, ldsb, stream); } break;
+		FOR_EACH_R(X)
+#undef X
+		default: return -2;
+	}
+	return SSW_LAUNCH_OK();
+}
+
 extern "C" int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream)
 {
 	ssw_reduce_args args = *a;
@@ -1002,6 +1415,14 @@ extern "C" int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args*
 #undef X
 		default: return -2;
 	}
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream)
+{
+	ssw_literal_args args = *a;
+	if (args.nq <= 0) return 0;
+	SSW_LAUNCH(k_literal, ssw_literal_args, args, (args.nq + 3) / 4, 64, 0, stream);
 	return SSW_LAUNCH_OK();
 }
 

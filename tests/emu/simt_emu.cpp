@@ -58,7 +58,7 @@ static void fiber_main()
 	Fiber* f = cur;
 	f->done = 1; ++progress;
 	Wave* w = f->wave;
-	w->slot[0][f->lane] = 0; w->slot[1][f->lane] = 0;
+	w->finished |= 1ull << f->lane;   /* its exchange slots stay readable: slower lanes may still be about to read them */
 	w->live--;
 	if (w->live > 0 && w->arrived >= w->live) { w->arrived = 0; w->gen++; }
 	blk.live--;
@@ -83,7 +83,7 @@ void launch(kernel_thunk fn, void* args, unsigned grid, unsigned block, size_t l
 		memset(lds_base, 0xCD, lds_bytes);   /* poison: uninitialised LDS must not matter */
 		blk.live = (int)block; blk.arrived = 0; blk.gen = 0; blk.lds = lds_base; blk.lds_bytes = lds_bytes;
 		for (unsigned w = 0; w < nw; ++w) {
-			waves[w].arrived = 0; waves[w].gen = 0;
+			waves[w].arrived = 0; waves[w].gen = 0; waves[w].finished = 0;
 			waves[w].live = (int)((w + 1) * 64 <= block ? 64 : block - w * 64);
 			memset(waves[w].slot, 0, sizeof(waves[w].slot));
 		}

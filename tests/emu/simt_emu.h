@@ -36,6 +36,7 @@ struct dim3_t { unsigned x, y, z; };
 
 struct Wave {
 	int live, arrived, gen;
+	unsigned long long finished;   /* lanes whose kernel body has returned: ignored by votes */
 	uint32_t slot[2][64];
 };
 
@@ -109,12 +110,21 @@ SSW_DEV bool wave_any(bool p)
 	int g = w->gen & 1;
 	w->slot[g][emu::cur->lane] = p ? 1u : 0u;
 	emu::wave_sync();
-	/* finished lanes left stale slots: only count lanes of this wave that are still alive via their own writes */
 	bool r = false;
-	for (int i = 0; i < 64; ++i) r = r || (w->slot[g][i] & 1u);
+	for (int i = 0; i < 64; ++i) r = r || ((w->slot[g][i] & 1u) && !((w->finished >> i) & 1ull));
 	return r;
 }
 SSW_DEV bool wave_all(bool p) { return !wave_any(!p); }
+SSW_DEV unsigned long long wave_ballot(bool p)
+{
+	emu::Wave* w = emu::cur->wave;
+	int g = w->gen & 1;
+	w->slot[g][emu::cur->lane] = p ? 1u : 0u;
+	emu::wave_sync();
+	unsigned long long m = 0;
+	for (int i = 0; i < 64; ++i) if ((w->slot[g][i] & 1u) && !((w->finished >> i) & 1ull)) m |= 1ull << i;
+	return m;
+}
 SSW_DEV void wave_lds_fence() { emu::wave_sync(); }
 
 static inline void emu_lds_check(u32 off, u32 bytes, u32 align, const char* what)

@@ -74,6 +74,34 @@ def test_multiple_targets_and_8bit_overflow_null(ectx):
     _run(ectx, reads, refs, dna_matrix(2, 2), 5, flag=1, ss=1)
 
 
+def test_long_queries_row_strips(ectx):
+    """queries above 384 residues: row strips with boundary hand-off (k_chainx), also tiled and with padded lengths"""
+    rng = np.random.default_rng(8)
+    ref = random_ref(1500, 14, 4, 0.005)
+    reads = make_reads(rng, ref, 5, [400, 500, 385, 777, 1000], 4, sub=0.03, ins=0.01, dele=0.01)
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
+    reads = make_reads(rng, ref, 6, [401, 402, 403, 409, 410, 416], 4, sub=0.03, ins=0.01, dele=0.01)
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=1, maskLen=15)
+    ref = random_ref(30000, 15, 4)
+    reads = make_reads(rng, ref, 3, [400, 450, 390], 4, sub=0.03, ins=0.005, dele=0.005, frac_random=0.0)
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
+
+
+def test_database_search_fused_kernel(ectx):
+    """flag 0 against several short targets takes the fused k_filldb path (one launch per bucket and target chunk)"""
+    rng = np.random.default_rng(9)
+    bg = rng.integers(0, 20, size=3000, dtype=np.int8)
+    refs = [bg[o:o + int(L)].copy() for o, L in zip(rng.integers(0, 2000, size=21), rng.integers(1, 400, size=21))]
+    reads = make_reads(rng, bg, 7, [60, 100, 33, 129, 17, 200, 61], 20, sub=0.1, frac_random=0.0)
+    _run(ectx, reads, refs, blosum50(), 24, flag=0)
+    assert ectx.timing()["fill_launches"] <= 8          # not 21 x buckets
+    dref = random_ref(2500, 16, 4)
+    drefs = [dref[o:o + int(L)].copy() for o, L in zip(rng.integers(0, 2000, size=18), rng.integers(20, 400, size=18))]
+    dreads = make_reads(rng, dref, 5, [150, 150, 145, 33, 20], 4, sub=0.02, frac_random=0.0)
+    _run(ectx, dreads, drefs, dna_matrix(2, 2), 5, flag=0, maskLen=15, ss=1)
+    res = _run(ectx, dreads, drefs, dna_matrix(2, 2), 5, flag=0, ss=0)
+
+
 def test_randomised_parameters(ectx):
     rng = np.random.default_rng(6)
     for _ in range(25):
@@ -112,11 +140,34 @@ def test_golden_small_through_emulated_library(ectx):
             assert [int(x) for x in cig[int(g["cigar_off"]):int(g["cigar_off"]) + int(g["cigarLen"])]] == c["cigar"] or c["expect"]["cigarLen"] == 0
 
 
-def test_unsupported_parameters_fail_loudly(ectx):
+def test_layout_dependent_gap_regime(ectx):
+    """gapO <= gapE: the reference's answer depends on its stripe layout and lazy-F exit; the lane-model kernel
+    (k_literal) re-enacts both SSE2 kernels, so every parameter combination is covered (checked against the
+    compiled reference / lane-model oracle)"""
+    rng = np.random.default_rng(10)
+    for _ in range(12):
+        kind = "dna" if rng.random() < 0.7 else "aa"
+        nq = int(rng.integers(1, 9)); refLen = int(rng.integers(10, 400))
+        if kind == "dna":
+            n, nc, mat = 5, 4, dna_matrix(int(rng.integers(1, 4)), int(rng.integers(1, 6)))
+            ref = random_ref(refLen, int(rng.integers(1 << 30)), 4, 0.02)
+        else:
+            n, nc, mat = 24, 20, blosum50()
+            ref = rng.integers(0, 20, size=refLen, dtype=np.int8)
+        gapO = int(rng.integers(0, 5)); gapE = gapO + int(rng.integers(0, 4))
+        reads = make_reads(rng, ref, nq, rng.integers(1, 200, size=nq), nc)
+        _run(ectx, reads, [ref], mat, n, gapO, gapE, flag=int(rng.choice([0, 1, 2, 8, 9, 15, 4, 6, 3])),
+             filters=int(rng.choice([0, 0, 30, 80])), filterd=int(rng.choice([0, 20, 1000])),
+             maskLen=int(rng.choice([-1, -1, 15, 10, 40])), ss=int(rng.choice([2, 2, 2, 0, 1])))
+
+
+def test_bad_arguments_fail_loudly(ectx):
     ref = random_ref(100, 1, 4)
     Q = ectx.upload([ref[:30]]); T = ectx.upload([ref])
-    with pytest.raises(RuntimeError, match="gap open > gap extension"):
-        ectx.align_batch(Q, T, dna_matrix(2, 2), 5, 1, 1)
+    with pytest.raises(RuntimeError, match="alphabet size"):
+        ectx.align_batch(Q, T, np.zeros(40 * 40, dtype=np.int8), 40, 3, 1)
+    with pytest.raises(RuntimeError, match="score_size"):
+        ectx.align_batch(Q, T, dna_matrix(2, 2), 5, 3, 1, score_size=3)
     Q.free(); T.free()
 
 
