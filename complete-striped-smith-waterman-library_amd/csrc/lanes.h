@@ -45,6 +45,8 @@ SSW_DEV u32 lds_ld32(const unsigned char* lds, u32 off) { return *(const u32*)(l
 SSW_DEV u32 lds_ld16(const unsigned char* lds, u32 off) { return *(const uint16_t*)(lds + off); }
 SSW_DEV void lds_st32(unsigned char* lds, u32 off, u32 v) { *(u32*)(lds + off) = v; }
 SSW_DEV void lds_st128(unsigned char* lds, u32 off, u32x4 v) { *(u32x4*)(lds + off) = v; }
+/* orders this wavefront's own global-memory traffic (row arrays re-read by other lanes of the same wave) */
+SSW_DEV void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 SSW_DEV void dev_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); }
 SSW_DEV void lds_st16(unsigned char* lds, u32 off, u32 v) { *(uint16_t*)(lds + off) = (uint16_t)v; }
 #endif

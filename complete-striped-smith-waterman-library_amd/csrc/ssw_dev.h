@@ -187,7 +187,7 @@ typedef struct {
 	int64_t scratch_stride;
 	uint32_t* cigar;         /* nq regions of cigar_stride words */
 	int64_t cigar_stride;
-	int32_t* need;           /* per query: 0 done, otherwise bytes of scratch that were needed */
+	int32_t* need;           /* per job: 0 done, -1 CIGAR slot too small, otherwise scratch that was needed in 4-KiB units */
 } ssw_trace_args;
 
 /* compaction of the per-query CIGAR slots into one pool */
@@ -233,6 +233,7 @@ int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* stream);
 int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args* a, void* stream);
 int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream);
 int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);
+int ssw_shim_launch_trace_wave(const ssw_trace_args* a, void* stream);   /* one wavefront per alignment (long reads) */
 int ssw_shim_launch_gather(const ssw_gather_args* a, void* stream);
 int ssw_shim_launch_selftest(const ssw_selftest_args* a, int blocks, void* stream);
 

@@ -494,50 +494,59 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 			int32_t* d_need = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * (size_t)nq);
 			if (!d_cig || !d_need) goto done;
 			int64_t sstride = ((int64_t)3 * (2 * 16 + 8) * 4 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;
-			int32_t* list = order; int32_t nlist = nq;      /* `order` already uploaded as d_qlist */
-			int32_t* retry = 0;
-			for (int attempt = 0; attempt < 6 && nlist > 0; ++attempt) {
-				int64_t per_launch = (int64_t)((size_t)16 << 30) / sstride;
-				if (per_launch < 1) { fail(c, "traceback scratch for one alignment exceeds 16 GiB%s", ""); free(retry); goto done; }
-				int32_t* d_list = d_qlist;
-				if (attempt > 0) {
-					if (ssw_shim_h2d(d_qlist, list, sizeof(int32_t) * (size_t)nlist, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); free(retry); goto done; }
-				}
-				int64_t maxneed = 0; int32_t nretry = 0;
-				int32_t* nextlist = (int32_t*)malloc(sizeof(int32_t) * (size_t)nlist);
-				for (int32_t q0 = 0; q0 < nlist; q0 += (int32_t)per_launch) {
-					const int32_t cnt_l = nlist - q0 < per_launch ? nlist - q0 : (int32_t)per_launch;
-					uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)(sstride * cnt_l));
-					if (!d_scr) { free(nextlist); free(retry); goto done; }
-					ssw_trace_args ta;
-					ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_list + q0; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
-					ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = sstride;
-					/* the CIGAR slot of an alignment is addressed by its position in the FIRST list (== position in `order`) */
-					ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need + q0;
-					if (attempt > 0) { ta.cigar = d_cig; }
-					if (ssw_shim_launch_trace(&ta, c->stream) ||
-					    ssw_shim_d2h(hneed + q0, d_need + q0, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
-					    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); free(nextlist); free(retry); goto done; }
-					for (int32_t k = 0; k < cnt_l; ++k)
-						if (hneed[q0 + k] != 0) {
-							if (hneed[q0 + k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); free(nextlist); free(retry); goto done; }
-							if (hneed[q0 + k] > maxneed) maxneed = hneed[q0 + k];
-							nextlist[nretry++] = list[q0 + k];
-						}
+			/* long reads: one wavefront per alignment (wide bands, 10^4 rows); short reads: one thread per alignment */
+			const char* tw = getenv("SSW_GPU_TRACE_WAVE");
+			const int use_wave = tw ? tw[0] == '1' : maxlen > 1024;
+			/* round 0: every alignment with a small scratch (band <= 16).  Alignments whose band had to grow report what
+			   they needed; later rounds run them in classes of similar need (x4 per class) with 4x headroom. */
+			keyed* pend = (keyed*)malloc(sizeof(keyed) * (size_t)nq);     /* key = need in 4-KiB units, q = query */
+			int32_t* lst = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
+			int32_t npend = nq;
+			for (int32_t k = 0; k < nq; ++k) { pend[k].key = 0; pend[k].q = order[k]; }
+			const int64_t full = (int64_t)maxlen + (halo_max < refLen ? halo_max : refLen);
+			const int64_t worst = (3 * (2 * full + 8) * 4 + (2 * full + 1) * (int64_t)maxlen * 3 + 64 + 15) / 16 * 16;
+			int trace_ok = 1;
+			for (int round = 0; round < 10 && npend > 0 && trace_ok; ++round) {
+				keyed* nextp = (keyed*)malloc(sizeof(keyed) * (size_t)npend);
+				int32_t nnext = 0;
+				if (round > 0) qsort(pend, (size_t)npend, sizeof(keyed), keyed_cmp);
+				for (int32_t g0 = 0; g0 < npend && trace_ok; ) {
+					/* one class: needs within a factor 4 of the class' smallest */
+					int32_t g1 = g0; int64_t cls_max = pend[g0].key;
+					while (g1 < npend && (round == 0 || (int64_t)pend[g1].key <= (int64_t)pend[g0].key * 4)) { if (pend[g1].key > cls_max) cls_max = pend[g1].key; ++g1; }
+					int64_t stride_c = round == 0 ? sstride : (cls_max * 4096 * 4 + 15) / 16 * 16;
+					if (stride_c > worst) stride_c = worst;
+					int64_t per_launch = (int64_t)((size_t)32 << 30) / stride_c;
+					if (per_launch < 1) { fail(c, "traceback scratch for one alignment exceeds 32 GiB%s", ""); trace_ok = 0; break; }
+					for (int32_t q0 = g0; q0 < g1 && trace_ok; q0 += (int32_t)per_launch) {
+						const int32_t cnt_l = g1 - q0 < per_launch ? g1 - q0 : (int32_t)per_launch;
+						for (int32_t k = 0; k < cnt_l; ++k) lst[k] = pend[q0 + k].q;
+						uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)(stride_c * cnt_l));
+						if (!d_scr) { trace_ok = 0; break; }
+						ssw_trace_args ta;
+						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
+						ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = stride_c;
+						ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;     /* CIGAR slots are indexed by query */
+						if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
+						    (use_wave ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
+						    ssw_shim_d2h(hneed, d_need, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
+						    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
+						for (int32_t k = 0; k < cnt_l; ++k)
+							if (hneed[k] != 0) {
+								if (hneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
+								nextp[nnext].key = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
+							}
+						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, scratch %lld B each, %d pending so far\n",
+						                                     round, cnt_l, (long long)stride_c, nnext);
+					}
+					g0 = g1;
 				}
 				did_trace = 1;
-				if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace attempt %d: %d alignments, scratch %lld B each, %d need more (max %lld B)\n",
-				                                     attempt, nlist, (long long)sstride, nretry, (long long)maxneed);
-				free(retry); retry = nextlist; list = retry; nlist = nretry;
-				if (nlist > 0) {
-					/* jump straight to the worst case of the remaining alignments' full band */
-					int64_t full = (int64_t)maxlen + (halo_max < refLen ? halo_max : refLen);
-					int64_t worst = (3 * (2 * full + 8) * 4 + (2 * full + 1) * (int64_t)maxlen * 3 + 64 + 15) / 16 * 16;
-					sstride = attempt == 0 && maxneed * 4 < worst ? (maxneed * 4 + 15) / 16 * 16 : worst;
-				}
+				free(pend); pend = nextp; npend = nnext;
 			}
-			if (nlist > 0) { fail(c, "internal error: traceback scratch negotiation did not converge%s", ""); free(retry); goto done; }
-			free(retry);
+			free(pend); free(lst);
+			if (!trace_ok) goto done;
+			if (npend > 0) { fail(c, "internal error: traceback scratch negotiation did not converge%s", ""); goto done; }
 			if (did_trace && ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nq, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
 		}
 		ssw_shim_event_record(c->ev_c, c->stream);

@@ -1219,6 +1219,170 @@ SSW_DEV int cigar_score(const u32* cig, int n_ops, const int8_t* ref, const int8
 	return score;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * trace_wave: the same banded_sw, one WAVEFRONT per alignment (long reads: bands of hundreds of cells, 10^4 rows).
+ * The cells of a band row are spread over the 64 lanes in chunks; E and the diagonal term only need the previous
+ * row; the horizontal dependency F[u] = max(h[u-1] - gapO, F[u-1] - gapE) with h = max(e, dia, 0, F) unrolls to the
+ * max-plus recurrence F[u] = max(A[u-1] - gapO, F[u-1] - min(gapO, gapE)), A = max(e, dia, 0), which is a prefix scan
+ * (6 shuffle steps per chunk).  All values are the reference's exact integers, so every direction byte, the running
+ * best cell (row-major, strict >) and hence the CIGAR are identical to the scalar walk.
+ * ------------------------------------------------------------------------------------------------ */
+SSW_DEV int wave_bcast(int v, int src) { return (int)xl_shfl((u32)v, src); }
+
+SSW_DEV int trace_wave(const int8_t* ref, const int8_t* read, int refLen, int readLen, int score, int gapO, int gapE,
+                       int band_width, const int8_t* mat, int n, unsigned char* scratch, int64_t cap,
+                       u32* cig, int cigcap, int64_t* need, int lane)
+{
+	const int NEG = -1073741824;
+	const int len = refLen > readLen ? refLen : readLen;
+	const int m = gapO < gapE ? gapO : gapE;
+	int best = 0, best_i = 0, best_j = 0, width, width_d;
+	int *hb, *eb, *hc; int8_t* dir;
+	do {
+		width = band_width * 2 + 3; width_d = band_width * 2 + 1;
+		const int64_t rowbytes = (((int64_t)width + 1) * 4 + 15) & ~(int64_t)15;
+		const int64_t want = 3 * rowbytes + (int64_t)width_d * readLen * 3 + 16;
+		if (want > cap) { *need = want; return -2; }
+		hb = (int*)scratch; eb = (int*)(scratch + rowbytes); hc = (int*)(scratch + 2 * rowbytes);
+		dir = (int8_t*)(scratch + 3 * rowbytes);
+		for (int j = 1 + lane; j < width - 1; j += 64) hb[j] = 0;
+		wg_fence();
+		for (int i = 0; i < readLen; ++i) {
+			const int xi = i - band_width > 0 ? i - band_width : 0;
+			const int xp = i - 1 - band_width > 0 ? i - 1 - band_width : 0;
+			const int sft = xi - xp;                                   /* 0 or 1: how far the band slid against the previous row */
+			const int beg = xi;
+			const int end = i + band_width < refLen - 1 ? i + band_width : refLen - 1;
+			const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+			const int ncell = end - beg + 1;
+			int8_t* line = dir + (int64_t)width_d * i * 3;
+			if (lane == 0) { hb[0] = 0; hb[edge] = 0; hc[0] = 0; eb[0] = NEG; eb[edge] = NEG; }
+			wg_fence();
+			const int rd = read[i];
+			int carryF = NEG, carryA = 0, carryH = 0;                  /* F, A and h of the cell left of the chunk (h_c[0] = 0) */
+			for (int c0 = 1; c0 <= ncell; c0 += 64) {
+				const int u = c0 + lane;
+				const bool ok = u <= ncell;
+				const int j = beg + u - 1;
+				int e = NEG, dia = NEG; int8_t de = 2;
+				if (ok) {
+					const int up = u + sft;
+					const int open = i == 0 ? -gapO : hb[up] - gapO;
+					const int ext = i == 0 ? NEG : eb[up] - gapE;
+					e = open > ext ? open : ext; de = open > ext ? 3 : 2;
+					dia = hb[up - 1] + mat[(int)ref[j] * n + rd];
+				}
+				int A = e > dia ? e : dia; if (A < 0) A = 0;
+				const int Aleft = wave_bcast(A, (lane + 63) & 63);
+				const int cl = (lane == 0 ? carryA : Aleft) - gapO;
+				/* inclusive max-plus scan of c with decay m per cell */
+				int t = cl;
+#pragma unroll
+				for (int d = 1; d < 64; d <<= 1) {
+					const int o = wave_bcast(t, (lane - d) & 63);
+					if (lane >= d) { const int v = o - d * m; t = v > t ? v : t; }
+				}
+				const int fc = carryF - (lane + 1) * m;
+				const int F = fc > t ? fc : t;
+				const int e1 = e > 0 ? e : 0, f1 = F > 0 ? F : 0;
+				const int gap = e1 > f1 ? e1 : f1;
+				const int h = gap > dia ? gap : dia;
+				/* direction of F: needs h and F of the cell to the left */
+				const int hl0 = wave_bcast(h, (lane + 63) & 63), Fl0 = wave_bcast(F, (lane + 63) & 63);
+				const int hleft = lane == 0 ? carryH : hl0, Fleft = lane == 0 ? carryF : Fl0;
+				const int8_t df = (hleft - gapO) > (Fleft - gapE) ? 5 : 4;
+				if (ok) {
+					eb[u] = e; hc[u] = h;
+					line[(u - 1) * 3 + 0] = de;
+					line[(u - 1) * 3 + 1] = df;
+					line[(u - 1) * 3 + 2] = gap <= dia ? (int8_t)1 : (e1 > f1 ? de : df);
+				}
+				/* best cell of the chunk: highest h, then leftmost */
+				int bh = ok ? h : NEG, bl = lane;
+#pragma unroll
+				for (int d = 32; d > 0; d >>= 1) {
+					const int oh = wave_bcast(bh, lane ^ d), ol = wave_bcast(bl, lane ^ d);
+					if (oh > bh || (oh == bh && ol < bl)) { bh = oh; bl = ol; }
+				}
+				if (bh > best) { best = bh; best_i = i; best_j = beg + c0 + bl - 1; }
+				const int last = ncell - c0 < 63 ? ncell - c0 : 63;     /* lane holding the chunk's last valid cell */
+				carryF = wave_bcast(F, last); carryA = wave_bcast(A, last); carryH = wave_bcast(h, last);
+			}
+			wg_fence();
+			for (int u = 1 + lane; u <= ncell; u += 64) hb[u] = hc[u];
+			wg_fence();
+		}
+		band_width *= 2;
+	} while (best < score && band_width <= len);
+	band_width /= 2;
+
+	wg_fence();
+	int nops = 0;
+	if (lane == 0) {
+		int run = 0, state = 2, cur = 0, prev = 0, i = best_i, j = best_j, failed = 0;
+		while (i >= 0 && j > 0) {
+			const int8_t d = dir[(int64_t)width_d * i * 3 + band_d(band_width, i, j, state)];
+			if (d == 1) { --i; --j; state = 2; cur = 0; }
+			else if (d == 2) { --i; state = 0; cur = 1; }
+			else if (d == 3) { --i; state = 2; cur = 1; }
+			else if (d == 4) { --j; state = 1; cur = 2; }
+			else if (d == 5) { --j; state = 2; cur = 2; }
+			else { failed = 1; break; }
+			if (cur == prev) ++run;
+			else { if (nops < cigcap) cig[nops] = ((u32)run << 4) | (u32)prev; ++nops; prev = cur; run = 1; }
+		}
+		if (failed) nops = -1;
+		else {
+			if (cur == 0) { if (nops < cigcap) cig[nops] = ((u32)(run + 1) << 4); ++nops; }
+			else {
+				if (nops < cigcap) cig[nops] = ((u32)run << 4) | (u32)cur; ++nops;
+				if (nops < cigcap) cig[nops] = (1u << 4); ++nops;
+			}
+			if (nops > cigcap) { *need = -(int64_t)nops; nops = -2; }
+			else for (int x = 0, y = nops - 1; x < y; ++x, --y) { const u32 t = cig[x]; cig[x] = cig[y]; cig[y] = t; }
+		}
+	}
+	wg_fence();
+	return wave_bcast(nops, 0);
+}
+
+/* one wavefront per alignment; same contract as k_trace */
+__global__ void __launch_bounds__(64) k_trace_wave(ssw_trace_args a)
+{
+	const int job = (int)blockIdx.x, lane = (int)threadIdx.x;
+	const int q = a.qlist[job];
+	ssw_dres r = a.res[q];
+	if (lane == 0) a.need[job] = 0;
+	if (!r.want_cigar || r.status != 0) return;
+	const int8_t* ref = a.tgt + r.ref_begin1;
+	const int8_t* read = a.qcodes + a.qoff[q] + r.read_begin1;
+	const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
+	const int d = refLen - readLen;
+	int band = (d < 0 ? -d : d) + 1;
+	const int full = refLen > readLen ? refLen : readLen;
+	u32* cig = a.cigar + (int64_t)q * a.cigar_stride;
+	unsigned char* scratch = a.scratch + (int64_t)job * a.scratch_stride;
+	int nops;
+	for (;;) {
+		int64_t need = 0;
+		nops = trace_wave(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, band, a.mat, a.n, scratch, a.scratch_stride,
+		                  cig, (int)a.cigar_stride, &need, lane);
+		const int64_t need0 = ((int64_t)wave_bcast((int)(need >> 32), 0) << 32) | (u32)wave_bcast((int)(need & 0xffffffff), 0);
+		if (nops == -2) { if (lane == 0) a.need[job] = need0 > 0 ? (int)((need0 + 4095) >> 12) : -1; return; }
+		if (nops < 0) break;
+		int sc = 0;
+		if (lane == 0) sc = cigar_score(cig, nops, ref, read, a.mat, a.n, a.gapO, a.gapE);
+		sc = wave_bcast(sc, 0);
+		if (sc == r.score1) break;
+		if (band >= full) { nops = -1; break; }
+		band = full;
+	}
+	if (lane == 0) {
+		if (nops < 0) { a.res[q].flag = 1; a.res[q].cigarLen = 0; }
+		else { a.res[q].cigarLen = nops; a.res[q].cigar_off = (int64_t)q * a.cigar_stride; }
+	}
+}
+
 __global__ void __launch_bounds__(64) k_trace(ssw_trace_args a)
 {
 	const int job = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -1240,7 +1404,7 @@ __global__ void __launch_bounds__(64) k_trace(ssw_trace_args a)
 		int64_t need = 0;
 		nops = trace_one(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, band, a.mat, a.n, scratch, a.scratch_stride,
 		                 cig, (int)a.cigar_stride, &need);
-		if (nops == -2) { a.need[job] = need > 0 ? (int)(need > 0x7fffffff ? 0x7fffffff : need) : -1; return; }
+		if (nops == -2) { a.need[job] = need > 0 ? (int)((need + 4095) >> 12) : -1; return; }   /* in 4-KiB units */
 		if (nops < 0) break;
 		if (cigar_score(cig, nops, ref, read, a.mat, a.n, a.gapO, a.gapE) == r.score1) break;
 		if (band >= full) { nops = -1; break; }
@@ -1431,6 +1595,14 @@ extern "C" int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream)
 	ssw_trace_args args = *a;
 	if (args.nq <= 0) return 0;
 	SSW_LAUNCH(k_trace, ssw_trace_args, args, (args.nq + 63) / 64, 64, 0, stream);
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_launch_trace_wave(const ssw_trace_args* a, void* stream)
+{
+	ssw_trace_args args = *a;
+	if (args.nq <= 0) return 0;
+	SSW_LAUNCH(k_trace_wave, ssw_trace_args, args, args.nq, 64, 0, stream);
 	return SSW_LAUNCH_OK();
 }
 

@@ -141,6 +141,7 @@ SSW_DEV u32 lds_ld16(const unsigned char* lds, u32 off) { emu_lds_check(off, 2, 
 SSW_DEV void lds_st32(unsigned char* lds, u32 off, u32 v) { emu_lds_check(off, 4, 4, "st32"); memcpy(lds + off, &v, 4); }
 SSW_DEV void lds_st128(unsigned char* lds, u32 off, u32x4 v) { emu_lds_check(off, 16, 16, "st128"); memcpy(lds + off, &v, 16); }
 SSW_DEV void dev_fence() { emu::wave_sync(); }
+SSW_DEV void wg_fence() { emu::wave_sync(); }
 SSW_DEV void lds_st16(unsigned char* lds, u32 off, u32 v) { emu_lds_check(off, 2, 2, "st16"); uint16_t h = (uint16_t)v; memcpy(lds + off, &h, 2); }
 
 #endif /* SIMT_EMU_H */

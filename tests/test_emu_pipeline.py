@@ -102,6 +102,22 @@ def test_database_search_fused_kernel(ectx):
     res = _run(ectx, dreads, drefs, dna_matrix(2, 2), 5, flag=0, ss=0)
 
 
+@pytest.mark.parametrize("wave", ["0", "1"])
+def test_traceback_band_growth_and_both_kernels(ectx, wave, monkeypatch):
+    """alignments with long gaps force the band to double past the first scratch class (negotiation rounds); checked with
+    the per-thread (k_trace) and the per-wavefront (k_trace_wave) traceback"""
+    monkeypatch.setenv("SSW_GPU_TRACE_WAVE", wave)
+    rng = np.random.default_rng(12)
+    ref = random_ref(900, 17, 4)
+    reads = [np.concatenate([ref[100:200], ref[260:360]]),            # 60-base deletion
+             np.concatenate([ref[400:470], rng.integers(0, 4, size=45, dtype=np.int8), ref[470:560]]),   # 45-base insertion
+             np.concatenate([ref[600:640], ref[700:760], ref[790:850]]),
+             ref[20:150].copy()]
+    reads += make_reads(rng, ref, 4, [150, 90, 200, 33], 4, sub=0.05, ins=0.03, dele=0.03)
+    for flag in (1, 2):
+        _run(ectx, [np.ascontiguousarray(r, dtype=np.int8) for r in reads], [ref], dna_matrix(2, 2), 5, flag=flag)
+
+
 def test_randomised_parameters(ectx):
     rng = np.random.default_rng(6)
     for _ in range(25):

@@ -265,3 +265,21 @@ def test_layout_dependent_gap_regime(gpu_ctx):
         _run(gpu_ctx, reads, [ref], mat, n, gapO, gapE, flag=int(rng.choice([0, 1, 2, 8, 9, 15, 4, 6, 3])),
              filters=int(rng.choice([0, 0, 30, 80])), filterd=int(rng.choice([0, 20, 1000])),
              maskLen=int(rng.choice([-1, -1, 15, 10, 40])), ss=int(rng.choice([2, 2, 2, 0, 1])))
+
+
+@pytest.mark.parametrize("wave", ["0", "1"])
+def test_traceback_kernels_and_band_growth(gpu_ctx, wave, monkeypatch):
+    """per-thread and per-wavefront banded traceback, including alignments whose band must double many times"""
+    monkeypatch.setenv("SSW_GPU_TRACE_WAVE", wave)
+    rng = np.random.default_rng(51)
+    ref = random_ref(20000, 52, 4)
+    reads = []
+    for k in range(12):
+        o = int(rng.integers(0, 15000)); g = int(rng.integers(20, 400)); a = int(rng.integers(80, 400)); b = int(rng.integers(80, 400))
+        if k % 2:
+            reads.append(np.concatenate([ref[o:o + a], ref[o + a + g:o + a + g + b]]))                       # deletion of g bases
+        else:
+            reads.append(np.concatenate([ref[o:o + a], rng.integers(0, 4, size=g // 4, dtype=np.int8), ref[o + a:o + a + b]]))
+    reads += make_reads(rng, ref, 40, rng.integers(30, 1200, size=40), 4, sub=0.04, ins=0.02, dele=0.02)
+    _run(gpu_ctx, [np.ascontiguousarray(r, dtype=np.int8) for r in reads], [ref], dna_matrix(2, 2), 5, flag=2)
+    _run(gpu_ctx, [np.ascontiguousarray(r, dtype=np.int8) for r in reads[:20]], [ref], dna_matrix(1, 3), 5, 2, 2, flag=1)
