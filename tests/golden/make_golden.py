@@ -147,5 +147,34 @@ def main():
     print("chr3_1M.npz: target", len(tcodes), "reads", len(reads))
 
 
+def cli_goldens():
+    """stdout of the reference's own ssw_test (built out-of-tree from /root/reference/src) on BASELINE config 1 and on
+    the protein demo: committed so that the batched CLI can be diffed against it on the GPU box."""
+    import shutil
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    exe = os.path.join(tmp, "ssw_test_ref")
+    subprocess.run(["gcc", "-O2", "-I/root/reference/src", "/root/reference/src/main.c", "/root/reference/src/ssw.c", "-o", exe, "-lz", "-lm"],
+                   check=True, stderr=subprocess.DEVNULL)
+    out = os.path.join(HERE, "cli")
+    os.makedirs(out, exist_ok=True)
+    for f in ("target.fastq", "query.fastq", "protein1.fa", "protein2.fa", "r1.fa", "r1_query.fq", "1k.fa"):
+        shutil.copy(os.path.join(DEMO, f), os.path.join(out, f))
+    runs = {"config1_c": ["-c", "target.fastq", "query.fastq"], "config1_csh": ["-c", "-s", "-h", "target.fastq", "query.fastq"],
+            "config1_plain": ["target.fastq", "query.fastq"], "config1_cr": ["-c", "-r", "target.fastq", "query.fastq"],
+            "protein_pc": ["-p", "-c", "protein1.fa", "protein2.fa"], "r1_cr": ["-c", "-r", "r1.fa", "r1_query.fq"],
+            "r1_csr": ["-c", "-s", "-r", "r1.fa", "r1_query.fq"], "readme_1k_cs": ["-c", "-s", "1k.fa", "query.fastq"],
+            "config1_f15": ["-c", "-f", "15", "target.fastq", "query.fastq"]}
+    for name, args in runs.items():
+        r = subprocess.run([exe] + args, cwd=out, capture_output=True, text=True)
+        with open(os.path.join(out, name + ".stdout"), "w") as f:
+            f.write(r.stdout)
+        with open(os.path.join(out, name + ".args"), "w") as f:
+            f.write(" ".join(args))
+    print("cli goldens:", len(runs))
+
+
 if __name__ == "__main__":
+    cli_goldens()
     main()
