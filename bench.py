@@ -50,6 +50,88 @@ def make_reads_fast(ref, nreads, length, seed, sub=0.03, ins=0.005, dele=0.005, 
     return np.ascontiguousarray(reads, dtype=np.int8)
 
 
+def bench_db(args, rank, world, local_rank, dist):
+    """BASELINE config 5 shape: every protein query (len ~ N(300, 60) clipped to [50, 1000], background residue
+    frequencies, 1 % planted homologs) against every DB entry, BLOSUM50, gaps 3/1, score-only (fused k_filldb path)."""
+    import ctypes as C
+    import ssw_amd
+    from sswutil import blosum50, mutate, ref_lib, _ptr, i8p, i32p, i64p
+    lib = ssw_amd.load(args.lib)
+    ctx = ssw_amd.Context(local_rank % max(1, lib.ssw_gpu_device_count()), lib)
+    rng = np.random.default_rng(4 + rank)
+    freq = np.array([8.3, 5.5, 4.1, 5.5, 1.4, 3.9, 6.8, 7.1, 2.3, 5.9, 9.7, 5.8, 2.4, 3.9, 4.7, 6.6, 5.3, 1.1, 2.9, 6.9]); freq /= freq.sum()
+    def seqs(count):
+        lens = np.clip(rng.normal(300, 60, size=count), 50, 1000).astype(np.int64)
+        return [rng.choice(20, size=int(L), p=freq).astype(np.int8) for L in lens]
+    db = seqs(args.db_targets)
+    qs = seqs(args.reads)
+    for i in range(0, args.reads, 100):          # planted homologs: 1 % of the queries are mutated copies of a DB entry
+        src = db[int(rng.integers(0, len(db)))]
+        m = mutate(src, rng, 0.15, 0.02, 0.02, 20)
+        if len(m) >= 50:
+            qs[i] = m[:1000]
+    mat = blosum50()
+    Q = ctx.upload(qs); T = ctx.upload(db)
+    def step():
+        return ctx.align_batch(Q, T, mat, 24, 3, 1, 0, 0, 0, -1, 2, want_cigar=False)
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    fill_ms = 0.0
+    for _ in range(args.steps):
+        res, _ = step()
+        fill_ms += ctx.timing()["fill_ms"]
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tm = ctx.timing()
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    cells = float(tm["cells"])
+    out = None
+    if rank == 0:
+        out = {"metric": "GCUPS", "value": round(cells * args.steps * world / dt / 1e9, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "int16x2 (packed; reference u8/int16 semantics)", "data": "synthetic",
+               "config": {"workload": "BASELINE config 5 shape: %d protein queries (~300 aa) x %d DB entries per GPU, BLOSUM50, 3/1, score-only"
+                                      % (args.reads, args.db_targets)},
+               "alignments_per_step": args.reads * args.db_targets,
+               "mix": {"word_rules": int(tm["n_word"]), "byte_rules": int(tm["n_byte"])},
+               "phases_ms_per_step": {"fill(k_filldb/k_chainx)": round(fill_ms / args.steps, 3), "other": round((dt * 1e3 - fill_ms) / args.steps, 3)},
+               "fill_gcups_padded": round(tm["fill_cells"] / (tm["fill_ms"] * 1e-3) / 1e9, 1) if tm["fill_ms"] > 0 else 0.0}
+        R = ref_lib()
+        if world == 1 and args.cpu_sample != 0 and R is not None:
+            cores = os.cpu_count() or 1
+            ns = min(args.reads, max(cores, 512)); ntc = min(args.db_targets, 8)
+            codes = np.concatenate(qs[:ns]).astype(np.int8); off = np.zeros(ns + 1, dtype=np.int64)
+            off[1:] = np.cumsum([len(x) for x in qs[:ns]])
+            secs = 0.0; mism = 0; ccells = 0
+            for t in range(ntc):
+                cres = np.zeros((ns, 10), dtype=np.int32)
+                tg = np.ascontiguousarray(db[t])
+                secs += R.refwrap_bench(_ptr(codes, i8p), _ptr(off, i64p), ns, _ptr(tg, i8p), len(tg), _ptr(mat, i8p), 24, 3, 1, 0, 0, 0, -1, cores,
+                                        _ptr(cres, i32p))
+                g = res[:ns, t]
+                got = np.stack([g["score1"], g["score2"], g["ref_begin1"], g["ref_end1"], g["read_begin1"], g["read_end1"], g["ref_end2"]], axis=1).astype(np.int32)
+                mism += int((got != cres[:, :7]).any(axis=1).sum())
+                ccells += int(off[ns]) * len(tg)
+            out["cpu_baseline"] = {"value": round(ccells / secs / 1e9, 2), "unit": "GCUPS", "cores": cores, "kind": "reference",
+                                   "sample": "first %d queries x first %d DB entries through the reference C API, one thread per core, %.2f s" % (ns, ntc, secs)}
+            out["parity"] = {"sample": ns * ntc, "mismatching_alignments": mism}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    Q.free(); T.free(); ctx.close()
+    return out, res
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +145,8 @@ def parse_args(argv=None):
     ap.add_argument("--sub", type=float, default=0.03, help="substitution rate of the synthetic reads")
     ap.add_argument("--indel", type=float, default=0.005, help="insertion rate = deletion rate of the synthetic reads")
     ap.add_argument("--mask-len", type=int, default=-1, help="maskLen (-1: readLen/2 per read, like the reference CLI)")
+    ap.add_argument("--db-targets", type=int, default=0,
+                    help="> 0: BASELINE config 5 shape instead -- --reads protein queries (~300 aa) against this many DB entries, BLOSUM50")
     ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)   # tests point this at the emulated library
     return ap.parse_args(argv)
 
@@ -93,6 +177,8 @@ def main(argv=None):
 
     import ssw_amd
     from sswutil import dna_matrix, random_ref
+    if args.db_targets > 0:
+        return bench_db(args, rank, world, local_rank, dist)
     lib = ssw_amd.load(args.lib)
     if lib.ssw_gpu_device_count() < 1:
         raise RuntimeError("bench.py: no HIP device visible; libssw.so has no CPU path")

@@ -140,6 +140,8 @@ typedef struct {
 	/* capture mode */
 	const int32_t* qlist;
 	int32_t reverse;
+	int32_t window_extra;    /* reverse pass: >= 0 caps the window at rows + rows/4 + window_extra columns (retry uncapped if missed) */
+	int32_t* retry_count;    /* incremented for every alignment whose capped window missed */
 	int32_t flag, filters, filterd;
 	ssw_dres* res;
 	/* strip boundary hand-off: njobs regions of bnd_stride records of 4 words (H, F, colmax16, colmax8) */
@@ -188,6 +190,7 @@ typedef struct {
 	uint32_t* cigar;         /* nq regions of cigar_stride words */
 	int64_t cigar_stride;
 	int32_t* need;           /* per job: 0 done, -1 CIGAR slot too small, otherwise scratch that was needed in 4-KiB units */
+	const int64_t* soff;     /* optional: job j owns scratch[soff[j] .. soff[j+1]) instead of a uniform stride */
 } ssw_trace_args;
 
 /* compaction of the per-query CIGAR slots into one pool */

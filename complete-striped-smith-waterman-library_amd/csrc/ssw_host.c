@@ -183,7 +183,7 @@ static int tkey_cmp(const void* a, const void* b)
 
 static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
                     const ssw_gpu_params* prm, ssw_gpu_result* results, const bucket* bk, int nb, const ssw_pair* d_pairs,
-                    const int8_t* d_mat, int32_t bias, int32_t maxtlen)
+                    const int8_t* d_mat, int32_t bias, int32_t maxtlen, const uint8_t* qdone)
 {
 	const int32_t nq = Q->count, n = prm->n;
 	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
@@ -210,6 +210,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		    ssw_shim_h2d(d_tl, tl, sizeof(int32_t) * (size_t)nz, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
 		for (int b = 0; b < nb && nz > 0; ++b) {
 			const bucket* B = &bk[b];
+			if (B->strips > 1) continue;     /* long queries go through the per-target strip path */
 			int64_t per = (int64_t)(c->cm_budget / 2) / (8 * stride * (int64_t)B->npairs);   /* targets per launch */
 			per = per / 16 * 16; if (per < 16) per = 16;
 			int64_t cap = per < nz ? per : nz;
@@ -235,7 +236,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 			fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
 		}
 		for (int32_t q = 0; q < nq; ++q)
-			for (int32_t k = 0; k < nt; ++k) {
+			for (int32_t k = 0; k < nt && qdone[q]; ++k) {
 				const ssw_dres* r = &hres[(int64_t)q * nt + k];
 				ssw_gpu_result* o = &results[(int64_t)q * tcount + t0 + k];
 				o->score1 = (uint16_t)r->score1; o->score2 = (uint16_t)r->score2; o->ref_begin1 = -1; o->ref_end1 = r->ref_end1;
@@ -273,6 +274,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 
 	/* bucket the queries by chain geometry, pair neighbours inside a bucket */
 	int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
+	uint8_t* qdone = (uint8_t*)calloc((size_t)nq, 1);   /* queries whose records came out of the fused database-search path */
 	ssw_pair* pairs = (ssw_pair*)malloc(sizeof(ssw_pair) * ((size_t)nq + 1));
 	keyed* keys = (keyed*)malloc(sizeof(keyed) * (size_t)nq);
 	bucket* bk = 0; int nb = 0;
@@ -280,7 +282,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 	for (int32_t q = 0; q < nq; ++q) {
 		int64_t len = Q->h_off[q + 1] - Q->h_off[q];
 		if (len < 1 || len > 0x3fffff00) {
-			free(order); free(pairs); free(keys);
+			free(order); free(pairs); free(keys); free(qdone);
 			return fail(c, "align_batch: empty (or absurdly long) query%s", "");
 		}
 		if (len > maxlen) maxlen = (int32_t)len;
@@ -332,22 +334,27 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
 	double fill_ms = 0, reduce_ms = 0, locate_ms = 0, trace_ms = 0;
 
-	{   /* database search: scores only, several short targets, short queries -> fused kernel */
-		int all_short = 1; int64_t maxt = 0;
-		for (int b = 0; b < nb; ++b) if (bk[b].strips > 1) all_short = 0;
+	{   /* database search: scores only, several short targets -> fused kernel for the short-query buckets */
+		int any_short = 0, any_long = 0; int64_t maxt = 0;
+		for (int b = 0; b < nb; ++b) { if (bk[b].strips > 1) any_long = 1; else any_short = 1; }
 		for (int32_t ti = 0; ti < tcount; ++ti) { int64_t L = T->h_off[tfirst + ti + 1] - T->h_off[tfirst + ti]; if (L > maxt) maxt = L; }
 		const char* dis = getenv("SSW_GPU_NO_DB");
-		if (!literal && prm->flag == 0 && tcount >= 4 && all_short && maxt <= 65536 && !(dis && dis[0] == '1')) {
-			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt)) goto done;
-			ssw_shim_event_record(c->ev_d, c->stream);
-			if (ssw_shim_stream_sync(c->stream)) { fail(c, "stream sync failed: %s", ssw_shim_last_error()); goto done; }
-			for (int e = 0; e + 1 < c->nev; e += 2) fill_ms += ssw_shim_event_elapsed_ms(c->ev[e], c->ev[e + 1]);
-			c->tm.total_ms = ssw_shim_event_elapsed_ms(c->ev_t0, c->ev_d); c->tm.fill_ms = fill_ms;
-			c->tm.reduce_ms = c->tm.total_ms - fill_ms; if (c->tm.reduce_ms < 0) c->tm.reduce_ms = 0;
-			rc = 0;
-			goto done;
+		if (!literal && prm->flag == 0 && tcount >= 4 && any_short && maxt <= 65536 && !(dis && dis[0] == '1')) {
+			for (int b = 0; b < nb; ++b) if (bk[b].strips == 1) for (int32_t k = 0; k < bk[b].nq; ++k) qdone[order[bk[b].first_q + k]] = 1;
+			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone)) goto done;
+			if (!any_long) {
+				ssw_shim_event_record(c->ev_d, c->stream);
+				if (ssw_shim_stream_sync(c->stream)) { fail(c, "stream sync failed: %s", ssw_shim_last_error()); goto done; }
+				for (int e = 0; e + 1 < c->nev; e += 2) fill_ms += ssw_shim_event_elapsed_ms(c->ev[e], c->ev[e + 1]);
+				c->tm.total_ms = ssw_shim_event_elapsed_ms(c->ev_t0, c->ev_d); c->tm.fill_ms = fill_ms;
+				c->tm.reduce_ms = c->tm.total_ms - fill_ms; if (c->tm.reduce_ms < 0) c->tm.reduce_ms = 0;
+				rc = 0;
+				goto done;
+			}
 		}
 	}
+	const int ev_base = c->nev;
+	(void)ev_base;
 
 	for (int32_t ti = 0; ti < tcount; ++ti) {
 		const int32_t t = tfirst + ti;
@@ -385,6 +392,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 			const int64_t stride = ((int64_t)refLen + 15) / 16 * 16 + 16;
 			for (int b = 0; b < nb; ++b) {
 				const bucket* B = &bk[b];
+				if (qdone[order[B->first_q]]) continue;     /* bucket already answered by the database-search path */
 				const int32_t P = B->P16, halo_full = halo_for(P, maxmat, prm->gapE);
 				const int use_x = B->strips > 1;     /* long queries: strip kernel, one job per chain */
 				const int gran = use_x ? 1 : 16;     /* k_fill: one workgroup = 16 tiles of one pair */
@@ -456,6 +464,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 			for (int pass = 0; pass < (prm->flag != 0 ? 2 : 1); ++pass)
 				for (int b = 0; b < nb; ++b) {
 					const bucket* B = &bk[b];
+					if (qdone[order[B->first_q]]) continue;
 					if (B->strips > 1) {
 						const int32_t hw = halo_for(B->P16, maxmat, prm->gapE);
 						const int64_t wcols = (((int64_t)(hw < refLen ? hw : refLen) + 1) + 31) / 16 * 16;
@@ -469,7 +478,21 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 							xa.gapO2 = gapO2; xa.gapE2 = gapE2; xa.gapE = prm->gapE; xa.maxmat = maxmat; xa.njobs = cnt_q;
 							xa.qlist = d_qlist + B->first_q + q0; xa.reverse = pass; xa.flag = prm->flag; xa.filters = prm->filters;
 							xa.filterd = prm->filterd; xa.res = d_res; xa.bnd = d_bnd; xa.bnd_stride = wcols;
-							if (ssw_shim_launch_chainx(B->R, 1, &xa, c->stream)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
+							/* reverse pass: a window of rows + 25 % almost always contains the whole alignment; the exact
+							   halo bound (3x the rows for DNA defaults) is only paid by the alignments that miss */
+							int32_t* d_retry = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * (size_t)nq);
+							if (!d_retry) goto done;
+							int32_t missed = 0;
+							xa.window_extra = pass ? 64 : -1; xa.retry_count = d_retry;
+							if (ssw_shim_memset(d_retry, 0, sizeof(int32_t), c->stream) ||
+							    ssw_shim_launch_chainx(B->R, 1, &xa, c->stream)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
+							if (pass) {
+								if (ssw_shim_d2h(&missed, d_retry, sizeof(int32_t), c->stream) || ssw_shim_stream_sync(c->stream)) { fail(c, "download failed: %s", ssw_shim_last_error()); goto done; }
+								if (missed > 0) {
+									xa.window_extra = -1;
+									if (ssw_shim_launch_chainx(B->R, 1, &xa, c->stream)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
+								}
+							}
 						}
 						continue;
 					}
@@ -510,22 +533,16 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 				keyed* nextp = (keyed*)malloc(sizeof(keyed) * (size_t)npend);
 				int32_t nnext = 0;
 				if (round > 0) qsort(pend, (size_t)npend, sizeof(keyed), keyed_cmp);
-				for (int32_t g0 = 0; g0 < npend && trace_ok; ) {
-					/* one class: needs within a factor 4 of the class' smallest */
-					int32_t g1 = g0; int64_t cls_max = pend[g0].key;
-					while (g1 < npend && (round == 0 || (int64_t)pend[g1].key <= (int64_t)pend[g0].key * 4)) { if (pend[g1].key > cls_max) cls_max = pend[g1].key; ++g1; }
-					int64_t stride_c = round == 0 ? sstride : (cls_max * 4096 * 4 + 15) / 16 * 16;
-					if (stride_c > worst) stride_c = worst;
-					int64_t per_launch = (int64_t)((size_t)32 << 30) / stride_c;
-					if (per_launch < 1) { fail(c, "traceback scratch for one alignment exceeds 32 GiB%s", ""); trace_ok = 0; break; }
-					for (int32_t q0 = g0; q0 < g1 && trace_ok; q0 += (int32_t)per_launch) {
-						const int32_t cnt_l = g1 - q0 < per_launch ? g1 - q0 : (int32_t)per_launch;
+				if (round == 0) {
+					int64_t per_launch = (int64_t)((size_t)32 << 30) / sstride; if (per_launch < 1) per_launch = 1;
+					for (int32_t q0 = 0; q0 < npend && trace_ok; q0 += (int32_t)per_launch) {
+						const int32_t cnt_l = npend - q0 < per_launch ? npend - q0 : (int32_t)per_launch;
 						for (int32_t k = 0; k < cnt_l; ++k) lst[k] = pend[q0 + k].q;
-						uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)(stride_c * cnt_l));
+						uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)(sstride * cnt_l));
 						if (!d_scr) { trace_ok = 0; break; }
 						ssw_trace_args ta;
 						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
-						ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = stride_c;
+						ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = sstride; ta.soff = 0;
 						ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;     /* CIGAR slots are indexed by query */
 						if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
 						    (use_wave ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
@@ -536,10 +553,47 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 								if (hneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
 								nextp[nnext].key = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
 							}
-						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, scratch %lld B each, %d pending so far\n",
-						                                     round, cnt_l, (long long)stride_c, nnext);
+						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round 0: %d alignments, scratch %lld B each, %d pending so far\n",
+						                                     cnt_l, (long long)sstride, nnext);
 					}
-					g0 = g1;
+				} else {
+					/* every pending alignment gets twice what it last needed (one more band doubling), all in as few launches
+					   as the HBM budget allows: the wide bands are few, so they must run side by side to fill the device */
+					int64_t* hoff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)npend + 1));
+					const int64_t budget = (int64_t)c->cm_budget * 2;
+					for (int32_t g0 = 0; g0 < npend && trace_ok; ) {
+						int32_t g1 = g0; int64_t total = 0;
+						hoff[0] = 0;
+						while (g1 < npend) {
+							int64_t cap_i = ((int64_t)pend[g1].key * 4096 * 2 + 65536 + 15) / 16 * 16;
+							if (cap_i > worst) cap_i = worst;
+							if (g1 > g0 && total + cap_i > budget) break;
+							total += cap_i; hoff[g1 - g0 + 1] = total; ++g1;
+						}
+						const int32_t cnt_l = g1 - g0;
+						for (int32_t k = 0; k < cnt_l; ++k) lst[k] = pend[g0 + k].q;
+						uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)total);
+						int64_t* d_soff = (int64_t*)ensure(c, &c->goff, sizeof(int64_t) * ((size_t)cnt_l + 1));
+						if (!d_scr || !d_soff) { trace_ok = 0; break; }
+						ssw_trace_args ta;
+						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
+						ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = 0; ta.soff = d_soff;
+						ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;
+						if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
+						    ssw_shim_h2d(d_soff, hoff, sizeof(int64_t) * ((size_t)cnt_l + 1), c->stream) ||
+						    (use_wave ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
+						    ssw_shim_d2h(hneed, d_need, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
+						    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
+						for (int32_t k = 0; k < cnt_l; ++k)
+							if (hneed[k] != 0) {
+								if (hneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
+								nextp[nnext].key = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
+							}
+						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, %lld B of scratch in total, %d pending so far\n",
+						                                     round, cnt_l, (long long)total, nnext);
+						g0 = g1;
+					}
+					free(hoff);
 				}
 				did_trace = 1;
 				free(pend); pend = nextp; npend = nnext;
@@ -577,6 +631,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 		for (int32_t q = 0; q < nq; ++q) {
 			const ssw_dres* r = &hres[q];
 			ssw_gpu_result* o = &results[(int64_t)q * tcount + ti];
+			if (qdone[q]) continue;
 			if (r->status >= 2) { fail(c, "internal error: window pass did not reproduce the forward score%s", ""); free(goffs); goto done; }
 			o->score1 = (uint16_t)r->score1; o->score2 = (uint16_t)r->score2;
 			o->ref_begin1 = r->ref_begin1; o->ref_end1 = r->ref_end1; o->read_begin1 = r->read_begin1; o->read_end1 = r->read_end1;
@@ -608,7 +663,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 	if (cigar_words) *cigar_words = pool_words;
 	rc = 0;
 done:
-	free(pool); free(order); free(pairs); free(hres); free(hneed); free(bk);
+	free(pool); free(order); free(pairs); free(hres); free(hneed); free(bk); free(qdone);
 	return rc;
 }
 

@@ -824,7 +824,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 
 	const int8_t *qa = a.qcodes, *qb = 0;
 	int lena = 0, lenb = 0, rev = 0, rows_total = 0, p8a = 0, p8b = 0, q = -1, qlen = 0;
-	bool active = false;
+	bool active = false, capped = false;
 	ssw_dres r;
 	x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0;
 	if (!CAPTURE) {
@@ -843,7 +843,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 		}
 	} else {
 		q = valid ? a.qlist[job] : -1;
-		if (q >= 0) { r = a.res[q]; active = r.status == 0 && r.score1 > 0 && (a.reverse ? r.want_begin != 0 : 1); }
+		if (q >= 0) { r = a.res[q]; active = r.status == 0 && r.score1 > 0 && (a.reverse ? r.want_begin == 1 : 1); }
 		if (active) {
 			qa = a.qcodes + a.qoff[q];
 			qlen = (int)(a.qoff[q + 1] - a.qoff[q]);
@@ -852,6 +852,10 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 			rows_total = (lena + 15) & ~15;
 			long long w = (long long)rows_total + ((long long)rows_total * (a.maxmat > 0 ? a.maxmat : 0) + a.gapE - 1) / (a.gapE > 0 ? a.gapE : 1) + 1;
 			if (a.gapE <= 0 || w > r.ref_end1) w = r.ref_end1;
+			if (a.reverse && a.window_extra >= 0) {   /* first try: the alignment rarely spans more than its rows + 25 % */
+				const long long cap = (long long)rows_total + rows_total / 4 + a.window_extra;
+				if (cap < w) { w = cap; capped = true; }
+			}
 			x.ncols = (int)w + 1;
 			x.c_edge = a.reverse ? r.ref_end1 : r.ref_end1 - (int)w;
 			x.dirstep = a.reverse ? -1 : 1;
@@ -904,9 +908,11 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 				a.res[q].read_end1 = (bv == r.score1) ? (br < qlen - 1 ? br : qlen - 1) : -1;
 				if (bv != r.score1) a.res[q].status = 3;
 			} else {
-				if (bv != r.score1 && x.ncols <= r.ref_end1) a.res[q].status = 3;
+				if (bv != r.score1 && capped) { if (a.retry_count) atomicAdd(a.retry_count, 1); }   /* stays want_begin == 1: rerun uncapped */
+				else if (bv != r.score1 && x.ncols <= r.ref_end1) a.res[q].status = 3;
 				else {
 					const int rb = r.ref_end1 - bc, qbeg = r.read_end1 - (br < lena - 1 ? br : lena - 1);
+					a.res[q].want_begin = 2;   /* done */
 					a.res[q].ref_begin1 = rb; a.res[q].read_begin1 = qbeg; a.res[q].rev_score = bv;
 					if (r.score1 > bv) a.res[q].flag = 2;
 					const int skip = (7 & a.flag) == 0 || ((2 & a.flag) != 0 && r.score1 < a.filters) ||
@@ -1361,11 +1367,12 @@ __global__ void __launch_bounds__(64) k_trace_wave(ssw_trace_args a)
 	int band = (d < 0 ? -d : d) + 1;
 	const int full = refLen > readLen ? refLen : readLen;
 	u32* cig = a.cigar + (int64_t)q * a.cigar_stride;
-	unsigned char* scratch = a.scratch + (int64_t)job * a.scratch_stride;
+	unsigned char* scratch = a.soff ? a.scratch + a.soff[job] : a.scratch + (int64_t)job * a.scratch_stride;
+	const int64_t scap = a.soff ? a.soff[job + 1] - a.soff[job] : a.scratch_stride;
 	int nops;
 	for (;;) {
 		int64_t need = 0;
-		nops = trace_wave(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, band, a.mat, a.n, scratch, a.scratch_stride,
+		nops = trace_wave(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, band, a.mat, a.n, scratch, scap,
 		                  cig, (int)a.cigar_stride, &need, lane);
 		const int64_t need0 = ((int64_t)wave_bcast((int)(need >> 32), 0) << 32) | (u32)wave_bcast((int)(need & 0xffffffff), 0);
 		if (nops == -2) { if (lane == 0) a.need[job] = need0 > 0 ? (int)((need0 + 4095) >> 12) : -1; return; }
@@ -1398,11 +1405,12 @@ __global__ void __launch_bounds__(64) k_trace(ssw_trace_args a)
 	int band = (d < 0 ? -d : d) + 1;
 	const int full = refLen > readLen ? refLen : readLen;
 	u32* cig = a.cigar + (int64_t)q * a.cigar_stride;   /* CIGAR slots are indexed by query, scratch by launch position */
-	unsigned char* scratch = a.scratch + (int64_t)job * a.scratch_stride;
+	unsigned char* scratch = a.soff ? a.scratch + a.soff[job] : a.scratch + (int64_t)job * a.scratch_stride;
+	const int64_t scap = a.soff ? a.soff[job + 1] - a.soff[job] : a.scratch_stride;
 	int nops;
 	for (;;) {   /* ssw.c:945-957 */
 		int64_t need = 0;
-		nops = trace_one(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, band, a.mat, a.n, scratch, a.scratch_stride,
+		nops = trace_one(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, band, a.mat, a.n, scratch, scap,
 		                 cig, (int)a.cigar_stride, &need);
 		if (nops == -2) { a.need[job] = need > 0 ? (int)((need + 4095) >> 12) : -1; return; }   /* in 4-KiB units */
 		if (nops < 0) break;

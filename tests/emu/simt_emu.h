@@ -144,4 +144,6 @@ SSW_DEV void dev_fence() { emu::wave_sync(); }
 SSW_DEV void wg_fence() { emu::wave_sync(); }
 SSW_DEV void lds_st16(unsigned char* lds, u32 off, u32 v) { emu_lds_check(off, 2, 2, "st16"); uint16_t h = (uint16_t)v; memcpy(lds + off, &h, 2); }
 
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+
 #endif /* SIMT_EMU_H */

@@ -85,6 +85,10 @@ def test_long_queries_row_strips(ectx):
     ref = random_ref(30000, 15, 4)
     reads = make_reads(rng, ref, 3, [400, 450, 390], 4, sub=0.03, ins=0.005, dele=0.005, frac_random=0.0)
     _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
+    # an alignment whose target span exceeds rows + 25 %: the capped reverse window misses and is rerun uncapped
+    ref = random_ref(4000, 18, 4)
+    reads = [np.ascontiguousarray(np.concatenate([ref[500:750], ref[1050:1300]])), ref[2000:2450].copy()]
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
 
 
 def test_database_search_fused_kernel(ectx):
