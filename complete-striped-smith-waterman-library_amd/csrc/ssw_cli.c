@@ -336,14 +336,19 @@ int main(int argc, char* const argv[])
 		ssw_gpu_result* res = (ssw_gpu_result*)malloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1));
 		ssw_gpu_result* res_rc = reverse ? (ssw_gpu_result*)malloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1)) : 0;
 		uint32_t *pool = 0, *pool_rc = 0; int64_t words = 0;
-		ssw_gpu_seqs* Qs = ssw_gpu_seqs_upload(g, qcodes, qoff, nr);
+		/* residue translation and (with -r) the reverse complement run on the device; the host copies made
+		   above are only used for printing (SAM needs the codes for mark_mismatch) */
+		char* qtext = (char*)malloc((size_t)total + 1);
+		for (int32_t q = 0; q < nr; ++q) memcpy(qtext + qoff[q], reads[q].seq, (size_t)reads[q].len);
+		ssw_gpu_seqs* Qs = ssw_gpu_seqs_upload_ascii(g, qtext, qoff, nr, table);
+		free(qtext);
 		if (!Qs || ssw_gpu_align_batch(g, Qs, T, 0, nt, &p, res, &pool, &words)) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
-		ssw_gpu_seqs_free(Qs);
 		if (reverse) {
-			ssw_gpu_seqs* Qr = ssw_gpu_seqs_upload(g, rcodes, qoff, nr);
+			ssw_gpu_seqs* Qr = ssw_gpu_seqs_revcomp(g, Qs);
 			if (!Qr || ssw_gpu_align_batch(g, Qr, T, 0, nt, &p, res_rc, &pool_rc, &words)) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
 			ssw_gpu_seqs_free(Qr);
 		}
+		ssw_gpu_seqs_free(Qs);
 		for (int32_t q = 0; q < nr; ++q)
 			for (int32_t t = 0; t < nt; ++t) {
 				const ssw_gpu_result* r = &res[(int64_t)q * nt + t];

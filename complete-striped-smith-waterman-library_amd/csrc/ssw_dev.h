@@ -202,6 +202,18 @@ typedef struct {
 	int32_t nq;
 } ssw_gather_args;
 
+/* sequence preparation on the device: ASCII -> residue codes, reverse complement of code sequences */
+typedef struct {
+	const uint8_t* text;     /* mode 0: ASCII residues */
+	const int8_t* codes_in;  /* mode 1: codes to reverse-complement */
+	const int8_t* table;     /* mode 0: 128-entry translation table */
+	const int64_t* off;      /* sequence offsets (count + 1) */
+	int32_t count;
+	int64_t total;
+	int8_t* out;
+	int32_t mode;
+} ssw_prep_args;
+
 /* device self-test: cross-lane primitive semantics + packed-int16 VALU issue-rate probe */
 typedef struct {
 	uint32_t* lanes_out;     /* 9 x 64 words, may be NULL */
@@ -238,6 +250,7 @@ int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream);
 int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);
 int ssw_shim_launch_trace_wave(const ssw_trace_args* a, void* stream);   /* one wavefront per alignment (long reads) */
 int ssw_shim_launch_gather(const ssw_gather_args* a, void* stream);
+int ssw_shim_launch_prep(const ssw_prep_args* a, void* stream);
 int ssw_shim_launch_selftest(const ssw_selftest_args* a, int blocks, void* stream);
 
 #ifdef __cplusplus

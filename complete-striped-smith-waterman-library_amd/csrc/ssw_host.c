@@ -134,6 +134,61 @@ void ssw_gpu_seqs_free(ssw_gpu_seqs* s)
 	ssw_shim_free(s->d_codes); ssw_shim_free(s->d_off); free(s->h_off); free(s);
 }
 
+ssw_gpu_seqs* ssw_gpu_seqs_upload_ascii(ssw_gpu_ctx* c, const char* text, const int64_t* offsets, int32_t count, const int8_t* table128)
+{
+	if (!c || count < 0 || !offsets || !table128) { fail(c, "seqs_upload_ascii: bad arguments%s", ""); return 0; }
+	ssw_shim_set_device(c->device);
+	ssw_gpu_seqs* s = (ssw_gpu_seqs*)calloc(1, sizeof(*s));
+	s->ctx = c; s->count = count; s->total = offsets[count] - offsets[0];
+	s->h_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)count + 1));
+	for (int32_t i = 0; i <= count; ++i) s->h_off[i] = offsets[i] - offsets[0];
+	s->d_codes = (int8_t*)ssw_shim_malloc((size_t)s->total + 64);
+	s->d_off = (int64_t*)ssw_shim_malloc(sizeof(int64_t) * ((size_t)count + 1));
+	uint8_t* d_text = (uint8_t*)ssw_shim_malloc((size_t)s->total + 64);
+	int8_t* d_tab = (int8_t*)ssw_shim_malloc(128);
+	int ok = s->d_codes && s->d_off && d_text && d_tab;
+	if (ok) {
+		ssw_prep_args pa; memset(&pa, 0, sizeof pa);
+		pa.text = d_text; pa.table = d_tab; pa.off = s->d_off; pa.count = count; pa.total = s->total; pa.out = s->d_codes; pa.mode = 0;
+		ok = !(ssw_shim_h2d(d_text, text + offsets[0], (size_t)s->total, c->stream) || ssw_shim_h2d(d_tab, table128, 128, c->stream) ||
+		       ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * ((size_t)count + 1), c->stream) ||
+		       ssw_shim_launch_prep(&pa, c->stream) || ssw_shim_stream_sync(c->stream));
+	}
+	ssw_shim_free(d_text); ssw_shim_free(d_tab);
+	if (!ok) { fail(c, "ascii upload failed: %s", ssw_shim_last_error()); ssw_gpu_seqs_free(s); return 0; }
+	return s;
+}
+
+ssw_gpu_seqs* ssw_gpu_seqs_revcomp(ssw_gpu_ctx* c, const ssw_gpu_seqs* in)
+{
+	if (!c || !in || in->ctx != c) { fail(c, "seqs_revcomp: bad arguments%s", ""); return 0; }
+	ssw_shim_set_device(c->device);
+	ssw_gpu_seqs* s = (ssw_gpu_seqs*)calloc(1, sizeof(*s));
+	s->ctx = c; s->count = in->count; s->total = in->total;
+	s->h_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)in->count + 1));
+	memcpy(s->h_off, in->h_off, sizeof(int64_t) * ((size_t)in->count + 1));
+	s->d_codes = (int8_t*)ssw_shim_malloc((size_t)s->total + 64);
+	s->d_off = (int64_t*)ssw_shim_malloc(sizeof(int64_t) * ((size_t)in->count + 1));
+	int ok = s->d_codes && s->d_off;
+	if (ok) {
+		ssw_prep_args pa; memset(&pa, 0, sizeof pa);
+		pa.codes_in = in->d_codes; pa.off = in->d_off; pa.count = in->count; pa.total = in->total; pa.out = s->d_codes; pa.mode = 1;
+		ok = !(ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * ((size_t)in->count + 1), c->stream) ||
+		       ssw_shim_launch_prep(&pa, c->stream) || ssw_shim_stream_sync(c->stream));
+	}
+	if (!ok) { fail(c, "revcomp failed: %s", ssw_shim_last_error()); ssw_gpu_seqs_free(s); return 0; }
+	return s;
+}
+
+/* copies the residue codes of a device-resident set back to the host (tests, debugging) */
+int ssw_gpu_seqs_download(ssw_gpu_ctx* c, const ssw_gpu_seqs* s, int8_t* codes_out)
+{
+	if (!c || !s || !codes_out) return -1;
+	ssw_shim_set_device(c->device);
+	if (ssw_shim_d2h(codes_out, s->d_codes, (size_t)s->total, c->stream) || ssw_shim_stream_sync(c->stream)) return fail(c, "download failed: %s", ssw_shim_last_error());
+	return 0;
+}
+
 int32_t ssw_gpu_seqs_count(const ssw_gpu_seqs* s) { return s ? s->count : 0; }
 
 int ssw_gpu_last_timing(const ssw_gpu_ctx* c, ssw_gpu_timing* out) { if (!c || !out) return -1; *out = c->tm; return 0; }
@@ -342,6 +397,8 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 		if (!literal && prm->flag == 0 && tcount >= 4 && any_short && maxt <= 65536 && !(dis && dis[0] == '1')) {
 			for (int b = 0; b < nb; ++b) if (bk[b].strips == 1) for (int32_t k = 0; k < bk[b].nq; ++k) qdone[order[bk[b].first_q + k]] = 1;
 			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone)) goto done;
+			d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq);   /* align_db may have regrown the record buffer */
+			if (!d_res) goto done;
 			if (!any_long) {
 				ssw_shim_event_record(c->ev_d, c->stream);
 				if (ssw_shim_stream_sync(c->stream)) { fail(c, "stream sync failed: %s", ssw_shim_last_error()); goto done; }

@@ -1422,6 +1422,21 @@ __global__ void __launch_bounds__(64) k_trace(ssw_trace_args a)
 	else { a.res[q].cigarLen = nops; a.res[q].cigar_off = (int64_t)q * a.cigar_stride; }
 }
 
+/* sequence preparation (reference src/main.c:84-116, 476-481, 504): mode 0 translates ASCII through the caller's
+   128-entry table; mode 1 writes the reverse complement of every code sequence (codes 0..3 -> 3 - code, others unchanged:
+   what the reference's rc_table + nt_table produce together) */
+__global__ void __launch_bounds__(256) k_prep(ssw_prep_args a)
+{
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= a.total) return;
+	if (a.mode == 0) { a.out[i] = a.table[a.text[i] & 127]; return; }
+	int lo = 0, hi = a.count;                      /* sequence s with off[s] <= i < off[s+1] */
+	while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.off[mid] <= i) lo = mid; else hi = mid; }
+	const int64_t b = a.off[lo], e = a.off[lo + 1];
+	const int8_t c = a.codes_in[i];
+	a.out[b + (e - 1 - i)] = (c >= 0 && c < 4) ? (int8_t)(3 - c) : c;
+}
+
 /* pack the used part of every CIGAR slot into one contiguous pool (one thread per query) */
 __global__ void __launch_bounds__(256) k_gather(ssw_gather_args a)
 {
@@ -1618,6 +1633,14 @@ extern "C" int ssw_shim_launch_selftest(const ssw_selftest_args* a, int blocks, 
 {
 	ssw_selftest_args args = *a;
 	SSW_LAUNCH(k_selftest, ssw_selftest_args, args, blocks, 256, 0, stream);
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_launch_prep(const ssw_prep_args* a, void* stream)
+{
+	ssw_prep_args args = *a;
+	if (args.total <= 0) return 0;
+	SSW_LAUNCH(k_prep, ssw_prep_args, args, (args.total + 255) / 256, 256, 0, stream);
 	return SSW_LAUNCH_OK();
 }
 

@@ -82,6 +82,12 @@ def load(path=None):
     L.ssw_gpu_last_error.restype = C.c_char_p
     L.ssw_gpu_seqs_upload.argtypes = [C.c_void_p, _i8p, _i64p, C.c_int32]
     L.ssw_gpu_seqs_upload.restype = C.c_void_p
+    L.ssw_gpu_seqs_upload_ascii.argtypes = [C.c_void_p, C.c_char_p, _i64p, C.c_int32, _i8p]
+    L.ssw_gpu_seqs_upload_ascii.restype = C.c_void_p
+    L.ssw_gpu_seqs_revcomp.argtypes = [C.c_void_p, C.c_void_p]
+    L.ssw_gpu_seqs_revcomp.restype = C.c_void_p
+    L.ssw_gpu_seqs_download.argtypes = [C.c_void_p, C.c_void_p, _i8p]
+    L.ssw_gpu_seqs_download.restype = C.c_int
     L.ssw_gpu_seqs_free.argtypes = [C.c_void_p]
     L.ssw_gpu_seqs_free.restype = None
     L.ssw_gpu_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Params),

@@ -78,6 +78,14 @@ const char* ssw_gpu_last_error(const ssw_gpu_ctx* ctx);   /* ctx may be NULL: er
 
 /* Upload `count` sequences: codes of sequence i are codes[offsets[i] .. offsets[i+1]). */
 ssw_gpu_seqs* ssw_gpu_seqs_upload(ssw_gpu_ctx* ctx, const int8_t* codes, const int64_t* offsets, int32_t count);
+/* Same, from ASCII residues: the translation through `table128` (e.g. the reference's nt_table / aa_table,
+   src/main.c:72-93, applied per read at src/main.c:476, 504) runs on the device. */
+ssw_gpu_seqs* ssw_gpu_seqs_upload_ascii(ssw_gpu_ctx* ctx, const char* text, const int64_t* offsets, int32_t count,
+                                        const int8_t* table128);
+/* Reverse complement of every sequence of a DNA code set (0..3 -> 3 - code, other codes kept), computed on the device:
+   what `ssw_test -r` builds per read on the host (reference src/main.c:95-116, 478-481). */
+ssw_gpu_seqs* ssw_gpu_seqs_revcomp(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* s);
+int ssw_gpu_seqs_download(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* s, int8_t* codes_out);
 void ssw_gpu_seqs_free(ssw_gpu_seqs* s);
 int32_t ssw_gpu_seqs_count(const ssw_gpu_seqs* s);
 
