@@ -34,7 +34,7 @@ struct ssw_gpu_ctx {
 	void* stream;
 	char err[512];
 	ssw_gpu_timing tm;
-	dbuf mat, pairs, qlist, res, cm16, cm8, scratch, cigar, need, goff, gpool, bnd, tlist;
+	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, scratch, cigar, need, goff, gpool, bnd, tlist;
 	void** ev; int nev, capev;          /* event pairs around fill launches */
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
@@ -99,7 +99,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_set_device(c->device);
 	ssw_shim_stream_sync(c->stream);
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
-	dbuf_free(&c->cm8); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist);
+	dbuf_free(&c->cm8); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
 	free(c->ev);
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
@@ -247,6 +247,39 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 	tkey* tk = (tkey*)malloc(sizeof(tkey) * (size_t)tcount);
 	int32_t* tl = (int32_t*)malloc(sizeof(int32_t) * (size_t)tcount);
 	ssw_dres* hres = 0;
+	/* queries of 385..640 residues: size classes R' in {28, 32, 36, 40} (k_filldb<R', masked>), paired by length */
+	bucket mid[4]; int nmid = 0;
+	ssw_pair* midpairs = 0; const ssw_pair* d_midpairs = 0;
+	{
+		int32_t nm = 0;
+		for (int32_t q = 0; q < nq; ++q) { const int64_t L = Q->h_off[q + 1] - Q->h_off[q]; if (L > 16 * SSW_RMAX && L <= 640) ++nm; }
+		if (nm > 0) {
+			keyed* mk = (keyed*)malloc(sizeof(keyed) * (size_t)nm);
+			midpairs = (ssw_pair*)malloc(sizeof(ssw_pair) * (size_t)nm);
+			int32_t k = 0, np = 0;
+			for (int32_t q = 0; q < nq; ++q) { const int64_t L = Q->h_off[q + 1] - Q->h_off[q]; if (L > 16 * SSW_RMAX && L <= 640) { mk[k].key = (int32_t)L; mk[k].q = q; ++k; } }
+			qsort(mk, (size_t)nm, sizeof(keyed), keyed_cmp);
+			for (int cls = 28; cls <= 40; cls += 4) {
+				bucket b; b.R = cls; b.strips = 1; b.P16 = 16 * cls; b.first_pair = np; b.first_q = 0; b.nq = 0;
+				int32_t i = 0;
+				while (i < nm) {                   /* queries whose ceil(len/16) falls into (cls-4, cls] */
+					const int r = (mk[i].key + 15) / 16;
+					if (r > cls - 4 && r <= cls) {
+						midpairs[np].qa = mk[i].q; midpairs[np].qb = -1; ++b.nq;
+						if (i + 1 < nm && (mk[i + 1].key + 15) / 16 <= cls) { midpairs[np].qb = mk[i + 1].q; ++b.nq; ++i; }
+						++np;
+					}
+					++i;
+				}
+				b.npairs = np - b.first_pair;
+				if (b.npairs > 0) mid[nmid++] = b;
+			}
+			free(mk);
+			ssw_pair* dmp = (ssw_pair*)ensure(c, &c->pairs2, sizeof(ssw_pair) * (size_t)np);
+			if (!dmp || ssw_shim_h2d(dmp, midpairs, sizeof(ssw_pair) * (size_t)np, c->stream)) { free(midpairs); free(tk); free(tl); return fail(c, "upload failed: %s", ssw_shim_last_error()); }
+			d_midpairs = dmp;
+		}
+	}
 	/* result records of a sub-batch of targets stay in HBM until the sub-batch is done */
 	int64_t tsub = (int64_t)(c->cm_budget / 2) / ((int64_t)nq * (int64_t)sizeof(ssw_dres));
 	if (tsub < 16) tsub = 16;
@@ -263,9 +296,12 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		if (!d_res || !d_tl) goto done;
 		if (ssw_shim_memset(d_res, 0, sizeof(ssw_dres) * (size_t)nq * (size_t)nt, c->stream) ||
 		    ssw_shim_h2d(d_tl, tl, sizeof(int32_t) * (size_t)nz, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
-		for (int b = 0; b < nb && nz > 0; ++b) {
-			const bucket* B = &bk[b];
-			if (B->strips > 1) continue;     /* long queries go through the per-target strip path */
+		for (int b = 0; b < nb + nmid && nz > 0; ++b) {
+			bucket midb;
+			const bucket* B = b < nb ? &bk[b] : &midb;
+			const ssw_pair* bpairs = d_pairs;
+			if (b >= nb) { midb = mid[b - nb]; bpairs = d_midpairs; }
+			if (B->strips > 1) continue;     /* long queries go through the per-target strip path (or the size classes below) */
 			int64_t per = (int64_t)(c->cm_budget / 2) / (8 * stride * (int64_t)B->npairs);   /* targets per launch */
 			per = per / 16 * 16; if (per < 16) per = 16;
 			int64_t cap = per < nz ? per : nz;
@@ -275,7 +311,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 			for (int32_t k0 = 0; k0 < nz; k0 += (int32_t)per) {
 				ssw_filldb_args fa;
 				fa.tcodes = T->d_codes; fa.toff = T->d_off; fa.tlist = d_tl + k0; fa.ntl = nz - k0 < per ? nz - k0 : (int32_t)per;
-				fa.tfirst = tfirst + t0; fa.res_nt = nt; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off; fa.pairs = d_pairs + B->first_pair;
+				fa.tfirst = tfirst + t0; fa.res_nt = nt; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off; fa.pairs = bpairs + B->first_pair;
 				fa.npairs = B->npairs; fa.mat = d_mat; fa.n = n; fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.cm16 = d_cm16; fa.cm8 = d_cm8;
 				fa.cm_stride = stride; fa.maskLen = prm->maskLen; fa.bias = bias; fa.score_size = prm->score_size; fa.res = d_res;
 				void* e0 = next_event(c); void* e1 = next_event(c);
@@ -303,7 +339,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 	}
 	rc = 0;
 done:
-	free(tk); free(tl); free(hres);
+	free(tk); free(tl); free(hres); free(midpairs);
 	return rc;
 }
 
@@ -391,11 +427,11 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 
 	{   /* database search: scores only, several short targets -> fused kernel for the short-query buckets */
 		int any_short = 0, any_long = 0; int64_t maxt = 0;
-		for (int b = 0; b < nb; ++b) { if (bk[b].strips > 1) any_long = 1; else any_short = 1; }
+		for (int b = 0; b < nb; ++b) { if (bk[b].strips > 1 && bk[b].P16 > 640) any_long = 1; else any_short = 1; }
 		for (int32_t ti = 0; ti < tcount; ++ti) { int64_t L = T->h_off[tfirst + ti + 1] - T->h_off[tfirst + ti]; if (L > maxt) maxt = L; }
 		const char* dis = getenv("SSW_GPU_NO_DB");
 		if (!literal && prm->flag == 0 && tcount >= 4 && any_short && maxt <= 65536 && !(dis && dis[0] == '1')) {
-			for (int b = 0; b < nb; ++b) if (bk[b].strips == 1) for (int32_t k = 0; k < bk[b].nq; ++k) qdone[order[bk[b].first_q + k]] = 1;
+			for (int b = 0; b < nb; ++b) if (bk[b].strips == 1 || bk[b].P16 <= 640) for (int32_t k = 0; k < bk[b].nq; ++k) qdone[order[bk[b].first_q + k]] = 1;
 			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone)) goto done;
 			d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq);   /* align_db may have regrown the record buffer */
 			if (!d_res) goto done;

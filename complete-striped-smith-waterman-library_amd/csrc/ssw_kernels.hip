@@ -51,7 +51,7 @@ template <int R>
 SSW_DEV void build_profile(unsigned char* lds, u32 base, int first, int nthreads,
                            const int8_t* mat, int n,
                            const int8_t* qa, int lena, int reva,
-                           const int8_t* qb, int lenb)
+                           const int8_t* qb, int lenb, int p16a = 0x7fffffff, int p16b = 0x7fffffff)
 {
 	constexpr int C = ChainGeom<R>::C;
 	const int total = (n + 1) * C * 64;
@@ -63,7 +63,7 @@ SSW_DEV void build_profile(unsigned char* lds, u32 base, int first, int nthreads
 		if (b == n) v = DEAD2;
 		else if (r >= R) v = 0;
 		else {
-			int lo = 0, hi = 0;
+			int lo = row < p16a ? 0 : -32768, hi = row < p16b ? 0 : -32768;   /* rows below a padded query are dead */
 			if (row < lena) lo = mat[b * n + (reva ? qa[lena - 1 - row] : qa[row])];
 			if (qb && row < lenb) hi = mat[b * n + qb[row]];
 			v = pk_make(lo, hi);
@@ -89,6 +89,27 @@ SSW_DEV void chain_rows(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f
 		E[r] = pk_max(pk_subu(E[r], gapE2), t0);
 		f = pk_max(pk_subu(f, gapE2), t0);
 		cm = pk_max(cm, h);
+		H[r] = h;
+		d = hold;
+	}
+}
+
+/* same, for chains whose 16R rows exceed the padded query: the 16-bit-rule maximum (rows < P8) is a second, masked chain */
+template <int R>
+SSW_DEV void chain_rows_masked(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f, u32& cm, u32& cm8, const u32 (&m8)[R],
+                               u32 gapO2, u32 gapE2)
+{
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		const u32 hold = H[r];
+		const u32 s = sc[r >> 2][r & 3];
+		const u32 h0 = pk_max(pk_adds(d, s), E[r]);
+		const u32 h = pk_max(h0, f);
+		const u32 t0 = pk_subu(h0, gapO2);
+		E[r] = pk_max(pk_subu(E[r], gapE2), t0);
+		f = pk_max(pk_subu(f, gapE2), t0);
+		cm = pk_max(cm, h);
+		cm8 = pk_max(cm8, h & m8[r]);
 		H[r] = h;
 		d = hold;
 	}
@@ -214,7 +235,7 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
  * own column maxima afterwards: score1 / ref_end1 / read_end1 / score2 / ref_end2 come out of ONE launch.
  * grid = npairs * ceil(ntl / 16) workgroups of 256 threads.
  * ================================================================================================ */
-template <int R>
+template <int R, bool MASKED>
 __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 {
 	typedef ChainGeom<R> G;
@@ -229,8 +250,19 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 	const ssw_pair pr = a.pairs[pair];
 	const int lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
 	const int lenb = pr.qb >= 0 ? (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]) : 0;
+	/* MASKED: 16R rows may exceed the padded queries (R is a size class, not ceil(len/16)): dead rows + masked 16-bit maximum */
+	const int p16a = MASKED ? (lena + 15) & ~15 : 0x7fffffff, p16b = MASKED ? (lenb + 15) & ~15 : 0x7fffffff;
 	build_profile<R>(lds, 0, tid, 256, a.mat, a.n, a.qcodes + a.qoff[pr.qa], lena, 0,
-	                 pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0, lenb);
+	                 pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0, lenb, p16a, p16b);
+	u32 m8[MASKED ? R : 1];
+	if (MASKED) {
+		const int p8a = (lena + 7) & ~7, p8b = (lenb + 7) & ~7;
+#pragma unroll
+		for (int k = 0; k < (MASKED ? R : 1); ++k) {
+			const int row = l16 * R + k;
+			m8[k] = (row < p8a ? 0xffffu : 0u) | (row < p8b ? 0xffff0000u : 0u);
+		}
+	} else m8[0] = 0;
 
 	const int slot = tchunk * 16 + grp;
 	const bool active = slot < a.ntl;
@@ -287,7 +319,7 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			const int tc = s0 - 32 + l16;
 			if (tc < ncols) {
 				o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
-				o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
+				o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (MASKED ? 0 : 15 - G::TAP)) & 63));
 			}
 		}
 		wave_lds_fence();
@@ -303,14 +335,15 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			const u32 hin = xl_row_shr1_zero(Hlast);
 			u32 f = xl_row_shr1_zero(Fout);
 			const u32 x = xl_row_ror<1>(cmout);
-			const u32 x8 = xl_row_ror<16 - G::TAP>(ck);
-			u32 cm = x;
+			const u32 x8 = MASKED ? xl_row_ror<1>(ck) : xl_row_ror<16 - G::TAP>(ck);   /* MASKED: ck carries the masked chain */
+			u32 cm = x, cm8 = x8;
 			if (l16 == 0) {
 				lds_st32(lds, ob16 + 4u * j, x);
 				lds_st32(lds, ob8 + 4u * j, x8);
-				cm = 0;
+				cm = 0; cm8 = 0;
 			}
-			chain_rows<R, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);
+			if (MASKED) { chain_rows_masked<R>(sc, H, E, hsave, f, cm, cm8, (const u32(&)[R])m8, a.gapO2, a.gapE2); ck = cm8; }
+			else chain_rows<R, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
 			/* best cell: the first lane (top-down) whose running maximum reaches a new high holds its smallest row */
 			const u32 nb = pk_max(best, cm);
@@ -333,7 +366,7 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 		const int tc = base + l16;
 		if (tc >= 0 && tc < ncols) {
 			o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
-			o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
+			o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (MASKED ? 0 : 15 - G::TAP)) & 63));
 		}
 	}
 	dev_fence();   /* the chain re-reads its own column maxima below */
@@ -1558,9 +1591,14 @@ extern "C" int ssw_shim_launch_filldb(int R, const ssw_filldb_args* a, void* str
 	if (grid <= 0) return 0;
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
-		SSW_LAUNCH(k_filldb<r>, ssw_filldb_args, args, grid, 256, ldsb, stream); } break;
+		SSW_LAUNCH((k_filldb<r, false>), ssw_filldb_args, args, grid, 256, ldsb, stream); } break;
 		FOR_EACH_R(X)
 #undef X
+	/* size classes for queries of 385..640 residues: rows beyond the padded query are dead, 16-bit maxima masked */
+#define XM(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
+		SSW_LAUNCH((k_filldb<r, true>), ssw_filldb_args, args, grid, 256, ldsb, stream); } break;
+		XM(28) XM(32) XM(36) XM(40)
+#undef XM
 		default: return -2;
 	}
 	return SSW_LAUNCH_OK();

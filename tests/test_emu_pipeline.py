@@ -104,6 +104,13 @@ def test_database_search_fused_kernel(ectx):
     dreads = make_reads(rng, dref, 5, [150, 150, 145, 33, 20], 4, sub=0.02, frac_random=0.0)
     _run(ectx, dreads, drefs, dna_matrix(2, 2), 5, flag=0, maskLen=15, ss=1)
     res = _run(ectx, dreads, drefs, dna_matrix(2, 2), 5, flag=0, ss=0)
+    # queries of 385..640 residues use masked size classes of the fused kernel; longer ones the per-target strip path
+    preads = make_reads(rng, bg, 9, [60, 400, 33, 500, 17, 200, 390, 640, 433], 20, sub=0.1, frac_random=0.0)
+    _run(ectx, preads, refs[:9], blosum50(), 24, flag=0)
+    dreads = make_reads(rng, dref, 6, [385, 401, 408, 409, 639, 150], 4, sub=0.02, frac_random=0.0)
+    _run(ectx, dreads, drefs[:7], dna_matrix(2, 2), 5, flag=0, maskLen=15)
+    preads = make_reads(rng, bg, 4, [700, 450, 100, 641], 20, sub=0.1, frac_random=0.0)
+    _run(ectx, preads, refs[:5], blosum50(), 24, flag=0)
 
 
 @pytest.mark.parametrize("wave", ["0", "1"])

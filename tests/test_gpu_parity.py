@@ -246,6 +246,11 @@ def test_database_search_fused_kernel(gpu_ctx):
     _run(gpu_ctx, dreads, drefs, dna_matrix(2, 2), 5, flag=0, maskLen=15, ss=1)
     res, _ = _run(gpu_ctx, dreads, drefs, dna_matrix(2, 2), 5, flag=0, ss=0)
     assert (res["status"] == 1).any()
+    # BASELINE config 5 length range: N(300, 60) clipped to [50, 1000] -> 385..640 in masked size classes, beyond per target
+    preads = make_reads(rng, bg, 48, list(rng.integers(385, 641, size=40)) + [700, 999, 1000, 641, 50, 384, 385, 640], 20, sub=0.15, frac_random=0.2)
+    _run(gpu_ctx, preads, refs[:40], blosum50(), 24, flag=0)
+    dreads = make_reads(rng, dref, 24, [385, 401, 408, 409, 639, 640, 500, 433], 4, sub=0.02, frac_random=0.0)
+    _run(gpu_ctx, dreads, drefs[:24], dna_matrix(2, 2), 5, flag=0, maskLen=15)
 
 
 def test_layout_dependent_gap_regime(gpu_ctx):
