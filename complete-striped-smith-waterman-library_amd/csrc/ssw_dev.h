@@ -33,6 +33,7 @@ typedef struct {
 	int32_t want_begin;  /* phases still to run for this alignment (set by the reduce kernel) */
 	int32_t want_cigar;
 	int32_t rev_score;   /* best score seen by the reverse pass */
+	int32_t loc_done;    /* read_end1 already known (tracked by the fill kernel): no locate pass */
 	int64_t cigar_off;   /* word offset of this alignment's CIGAR in the device CIGAR pool */
 } ssw_dres;
 
@@ -56,6 +57,14 @@ typedef struct {
 	int64_t cm_stride;
 } ssw_fill_args;
 
+/* byte-for-byte the layout of ssw_gpu_result (include/ssw_gpu.h); checked by a static assertion in ssw_host.c */
+struct ssw_out_rec {
+	uint16_t score1, score2;
+	int32_t ref_begin1, ref_end1, read_begin1, read_end1, ref_end2, cigarLen;
+	int64_t cigar_off;
+	uint16_t flag, status;
+};
+
 /*
  * database search (many short targets, scores + end positions only): one workgroup = one query pair against 16
  * targets; the chain also tracks the best cell and reduces its own column maxima, so one launch produces final records.
@@ -78,7 +87,9 @@ typedef struct {
 	uint32_t* cm8;
 	int64_t cm_stride;
 	int32_t maskLen, bias, score_size;
-	ssw_dres* res;           /* [query][res_nt] */
+	ssw_dres* res;           /* [query][res_nt] (NULL when `out` is used) */
+	struct ssw_out_rec* out; /* optional: final ssw_gpu_result-layout records [query][res_nt], downloaded as they are */
+	int32_t* counters;       /* optional: [0] alignments decided under 16-bit rules, [1] under 8-bit rules */
 } ssw_filldb_args;
 
 /* reduction of the column maxima into score1 / ref_end1 / score2 / ref_end2 */
@@ -95,6 +106,8 @@ typedef struct {
 	int32_t score_size;
 	int32_t flag, filters;
 	ssw_dres* res;           /* indexed by query */
+	const int32_t* cand;     /* optional: best cell tracked by the fill, [pair * ntiles + tile][half][4] = value, column, row, - */
+	int32_t tile, ntiles;
 } ssw_reduce_args;
 
 /* locate (read_end1) and reverse (begin position) passes: one 16-lane chain per alignment */
@@ -147,6 +160,7 @@ typedef struct {
 	/* strip boundary hand-off: njobs regions of bnd_stride records of 4 words (H, F, colmax16, colmax8) */
 	uint32_t* bnd;
 	int64_t bnd_stride;
+	int32_t* cand;           /* fill mode, optional: best cell of every job, [job][half][4] = value, column, row, - */
 } ssw_chainx_args;
 
 /*

@@ -19,6 +19,8 @@
 #include "ssw_gpu.h"
 #include "ssw_dev.h"
 
+_Static_assert(sizeof(struct ssw_out_rec) == sizeof(ssw_gpu_result), "device record layout must equal ssw_gpu_result");
+
 struct _profile {
 	const int8_t* read;    /* borrowed, like the reference (src/ssw.c:842-843) */
 	const int8_t* mat;     /* borrowed */
@@ -34,7 +36,7 @@ struct ssw_gpu_ctx {
 	void* stream;
 	char err[512];
 	ssw_gpu_timing tm;
-	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, scratch, cigar, need, goff, gpool, bnd, tlist;
+	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, scratch, cigar, need, goff, gpool, bnd, tlist, cand;
 	void** ev; int nev, capev;          /* event pairs around fill launches */
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
@@ -99,7 +101,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_set_device(c->device);
 	ssw_shim_stream_sync(c->stream);
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
-	dbuf_free(&c->cm8); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2);
+	dbuf_free(&c->cm8); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
 	free(c->ev);
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
@@ -291,11 +293,24 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		qsort(tk, (size_t)nt, sizeof(tkey), tkey_cmp);
 		int32_t nz = 0;
 		for (int32_t k = 0; k < nt; ++k) if (tk[k].len > 0) tl[nz++] = tk[k].t;      /* empty targets keep their zeroed records */
-		ssw_dres* d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq * (size_t)nt);
+		/* one sub-batch covering every target and every query handled here: the kernel writes final-layout records that are
+		   downloaded straight into the caller's array (no host-side conversion pass over nq x nt records) */
+		int direct = nt == tcount;
+		for (int32_t q = 0; q < nq && direct; ++q) if (!qdone[q]) direct = 0;
+		ssw_dres* d_res = 0; struct ssw_out_rec* d_out = 0; int32_t* d_cnt = 0;
+		if (direct) {
+			d_out = (struct ssw_out_rec*)ensure(c, &c->res, sizeof(struct ssw_out_rec) * (size_t)nq * (size_t)nt);
+			d_cnt = (int32_t*)ensure(c, &c->need, 2 * sizeof(int32_t));
+			if (!d_out || !d_cnt) goto done;
+			/* all-zero bytes are not a valid empty record (begins are -1): empty targets are patched on the host below */
+			if (ssw_shim_memset(d_out, 0, sizeof(struct ssw_out_rec) * (size_t)nq * (size_t)nt, c->stream) ||
+			    ssw_shim_memset(d_cnt, 0, 2 * sizeof(int32_t), c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
+		} else {
+			d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq * (size_t)nt);
+			if (!d_res || ssw_shim_memset(d_res, 0, sizeof(ssw_dres) * (size_t)nq * (size_t)nt, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
+		}
 		int32_t* d_tl = (int32_t*)ensure(c, &c->tlist, sizeof(int32_t) * (size_t)(nz > 0 ? nz : 1));
-		if (!d_res || !d_tl) goto done;
-		if (ssw_shim_memset(d_res, 0, sizeof(ssw_dres) * (size_t)nq * (size_t)nt, c->stream) ||
-		    ssw_shim_h2d(d_tl, tl, sizeof(int32_t) * (size_t)nz, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
+		if (!d_tl || ssw_shim_h2d(d_tl, tl, sizeof(int32_t) * (size_t)nz, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
 		for (int b = 0; b < nb + nmid && nz > 0; ++b) {
 			bucket midb;
 			const bucket* B = b < nb ? &bk[b] : &midb;
@@ -313,7 +328,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 				fa.tcodes = T->d_codes; fa.toff = T->d_off; fa.tlist = d_tl + k0; fa.ntl = nz - k0 < per ? nz - k0 : (int32_t)per;
 				fa.tfirst = tfirst + t0; fa.res_nt = nt; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off; fa.pairs = bpairs + B->first_pair;
 				fa.npairs = B->npairs; fa.mat = d_mat; fa.n = n; fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.cm16 = d_cm16; fa.cm8 = d_cm8;
-				fa.cm_stride = stride; fa.maskLen = prm->maskLen; fa.bias = bias; fa.score_size = prm->score_size; fa.res = d_res;
+				fa.cm_stride = stride; fa.maskLen = prm->maskLen; fa.bias = bias; fa.score_size = prm->score_size; fa.res = d_res; fa.out = d_out; fa.counters = d_cnt;
 				void* e0 = next_event(c); void* e1 = next_event(c);
 				ssw_shim_event_record(e0, c->stream);
 				if (ssw_shim_launch_filldb(B->R, &fa, c->stream)) { fail(c, "filldb launch failed: %s", ssw_shim_last_error()); goto done; }
@@ -322,6 +337,21 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 				for (int32_t k = 0; k < fa.ntl; ++k)
 					c->tm.fill_cells += (T->h_off[tl[k0 + k] + 1] - T->h_off[tl[k0 + k]]) * (int64_t)B->P16 * 2 * B->npairs;
 			}
+		}
+		if (direct) {
+			int32_t cnt[2] = { 0, 0 };
+			if (ssw_shim_d2h(results, d_out, sizeof(struct ssw_out_rec) * (size_t)nq * (size_t)nt, c->stream) ||
+			    ssw_shim_d2h(cnt, d_cnt, sizeof cnt, c->stream) || ssw_shim_stream_sync(c->stream)) {
+				fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
+			}
+			c->tm.n_word += cnt[0]; c->tm.n_byte += cnt[1];
+			int64_t qsum = Q->h_off[nq] - Q->h_off[0];
+			for (int32_t k = 0; k < nt; ++k) {
+				const int64_t L = T->h_off[tfirst + k + 1] - T->h_off[tfirst + k];
+				c->tm.cells += qsum * L;
+				if (L == 0) for (int32_t q = 0; q < nq; ++q) { ssw_gpu_result* o = &results[(int64_t)q * tcount + k]; o->ref_begin1 = -1; o->read_begin1 = -1; o->cigar_off = -1; }
+			}
+			continue;
 		}
 		if (ssw_shim_d2h(hres, d_res, sizeof(ssw_dres) * (size_t)nq * (size_t)nt, c->stream) || ssw_shim_stream_sync(c->stream)) {
 			fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
@@ -509,8 +539,12 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 					const int64_t resident = ssw_shim_fill_resident_blocks(B->R, n), bpp = (ntiles + 15) / 16;
 					if (resident > 0 && chunk < B->npairs && chunk * bpp >= resident) chunk = (chunk * bpp / resident) * resident / bpp;
 				}
-				uint32_t* d_bnd = 0;
-				if (use_x) { d_bnd = (uint32_t*)ensure(c, &c->bnd, (size_t)(16 * maxcols * ntiles * chunk)); if (!d_bnd) goto done; }
+				uint32_t* d_bnd = 0; int32_t* d_cand = 0;
+				if (use_x) {
+					d_bnd = (uint32_t*)ensure(c, &c->bnd, (size_t)(16 * maxcols * ntiles * chunk));
+					d_cand = (int32_t*)ensure(c, &c->cand, (size_t)(32 * ntiles * chunk));   /* 2 halves x 4 ints per job */
+					if (!d_bnd || !d_cand) goto done;
+				}
 				uint32_t* d_cm16 = (uint32_t*)ensure(c, &c->cm16, (size_t)(4 * stride * chunk));
 				uint32_t* d_cm8 = (uint32_t*)ensure(c, &c->cm8, (size_t)(4 * stride * chunk));
 				if (!d_cm16 || !d_cm8) goto done;
@@ -528,7 +562,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 						xa.tgt = d_tgt; xa.refLen = refLen; xa.qcodes = Q->d_codes; xa.qoff = Q->d_off; xa.mat = d_mat; xa.n = n;
 						xa.gapO2 = gapO2; xa.gapE2 = gapE2; xa.gapE = prm->gapE; xa.maxmat = maxmat; xa.njobs = np * ntiles;
 						xa.pairs = fa.pairs; xa.tile = tile; xa.halo = halo; xa.ntiles = ntiles; xa.cm16 = d_cm16; xa.cm8 = d_cm8;
-						xa.cm_stride = stride; xa.bnd = d_bnd; xa.bnd_stride = maxcols;
+						xa.cm_stride = stride; xa.bnd = d_bnd; xa.bnd_stride = maxcols; xa.cand = d_cand;
 						if (ssw_shim_launch_chainx(B->R, 0, &xa, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
 					} else
 					if (ssw_shim_launch_fill(B->R, &fa, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
@@ -546,7 +580,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 					ssw_reduce_args ra;
 					ra.cm16 = d_cm16; ra.cm8 = d_cm8; ra.cm_stride = stride; ra.refLen = refLen; ra.pairs = fa.pairs; ra.npairs = np;
 					ra.qoff = Q->d_off; ra.maskLen = prm->maskLen; ra.bias = bias; ra.score_size = prm->score_size;
-					ra.flag = prm->flag; ra.filters = prm->filters; ra.res = d_res;
+					ra.flag = prm->flag; ra.filters = prm->filters; ra.res = d_res; ra.cand = d_cand; ra.tile = tile; ra.ntiles = ntiles;
 					if (ssw_shim_launch_reduce(&ra, c->stream)) { fail(c, "reduce launch failed: %s", ssw_shim_last_error()); goto done; }
 				}
 			}

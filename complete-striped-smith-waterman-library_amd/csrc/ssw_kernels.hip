@@ -419,13 +419,19 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			ssw_dres r;
 			r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = 0; r.read_begin1 = -1; r.read_end1 = 0;
 			r.ref_end2 = 0; r.cigarLen = 0; r.flag = 0; r.status = status; r.word = word; r.want_begin = 0; r.want_cigar = 0;
-			r.rev_score = 0; r.cigar_off = 0;
+			r.rev_score = 0; r.loc_done = 0; r.cigar_off = 0;
 			if (status == 0 && bv > 0) {
 				r.score1 = bv; r.ref_end1 = bc; r.read_end1 = br < len - 1 ? br : len - 1;
 				if (maskLen >= 15) { r.score2 = s2; r.ref_end2 = s2 > 0 ? i2 : 0; }
 				else { r.score2 = 0; r.ref_end2 = -1; }
 			}
-			a.res[(int64_t)q * a.res_nt + (t - a.tfirst)] = r;
+			if (a.out) {
+				ssw_out_rec o;
+				o.score1 = (uint16_t)r.score1; o.score2 = (uint16_t)r.score2; o.ref_begin1 = -1; o.ref_end1 = r.ref_end1; o.read_begin1 = -1;
+				o.read_end1 = r.read_end1; o.ref_end2 = r.ref_end2; o.cigarLen = 0; o.cigar_off = -1; o.flag = 0; o.status = (uint16_t)r.status;
+				a.out[(int64_t)q * a.res_nt + (t - a.tfirst)] = o;
+				if (a.counters && r.status == 0 && r.score1 > 0) atomicAdd(a.counters + (r.word ? 0 : 1), 1);
+			} else a.res[(int64_t)q * a.res_nt + (t - a.tfirst)] = r;
 		}
 		wave_lds_fence();
 	}
@@ -487,7 +493,7 @@ __global__ void __launch_bounds__(256) k_reduce(ssw_reduce_args a)
 		ssw_dres& x = r[h];
 		x.score1 = 0; x.score2 = 0; x.ref_begin1 = -1; x.ref_end1 = 0; x.read_begin1 = -1; x.read_end1 = 0;
 		x.ref_end2 = 0; x.cigarLen = 0; x.flag = 0; x.status = 0; x.word = 0; x.want_begin = 0; x.want_cigar = 0;
-		x.rev_score = 0; x.cigar_off = 0;
+		x.rev_score = 0; x.loc_done = 0; x.cigar_off = 0;
 		if (q < 0) continue;
 		const int len = (int)(a.qoff[q + 1] - a.qoff[q]);
 		const bool padded = (len & 15) >= 1 && (len & 15) <= 8;      /* 16-bit rules see 8 rows fewer */
@@ -537,6 +543,14 @@ __global__ void __launch_bounds__(256) k_reduce(ssw_reduce_args a)
 				if (mlen[h] >= 15) { r[h].score2 = s2[h]; r[h].ref_end2 = s2[h] > 0 ? i2[h] : 0; }
 				else { r[h].score2 = 0; r[h].ref_end2 = -1; }
 				r[h].want_begin = !(a.flag == 0 || (a.flag == 2 && best[h] < a.filters));   /* ssw.c:916 */
+				if (a.cand) {   /* the fill tracked its best cell: the tile that owns ref_end1 knows the row */
+					const int32_t* cd = a.cand + (((int64_t)pair * a.ntiles + bidx[h] / a.tile) * 2 + h) * 4;
+					if (cd[0] == best[h] && cd[1] == bidx[h]) {
+						const int len = (int)(a.qoff[q + 1] - a.qoff[q]);
+						r[h].read_end1 = cd[2] < len - 1 ? cd[2] : len - 1;
+						r[h].loc_done = 1;
+					}
+				}
 			}
 			a.res[q] = r[h];
 		}
@@ -564,7 +578,7 @@ __global__ void __launch_bounds__(64) k_capture(ssw_capture_args a)
 
 	ssw_dres r;
 	bool active = false;
-	if (q >= 0) { r = a.res[q]; active = r.status == 0 && r.score1 > 0 && (a.reverse ? r.want_begin != 0 : 1); }
+	if (q >= 0) { r = a.res[q]; active = r.status == 0 && r.score1 > 0 && (a.reverse ? r.want_begin != 0 : !r.loc_done); }
 	int qlen = 0, plen = 0, c_edge = 0, ncols = 0, P = 16;
 	const int8_t* qc = a.qcodes;
 	if (active) {
@@ -710,6 +724,8 @@ template <int R> struct ChainState {
 	u32 H[R], E[R];
 	u32 Hlast, Fout, cmout, cm8out, hsave;
 	int best, btc, brow;
+	/* fill mode: best cell seen by this lane, per query half (value, first column, smallest row) */
+	int tv[2], ttc[2], trow[2];
 };
 
 struct StripCtx {
@@ -759,6 +775,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	for (int r = 0; r < R; ++r) { st.H[r] = 0; st.E[r] = 0; }
 	st.Hlast = 0; st.Fout = 0; st.cmout = 0; st.cm8out = 0; st.hsave = 0;
 	const u32 lane_prof = x.prof + (u32)l16 * 16u;
+	u32 sbest = 0; int stc[2] = { 0x7fffffff, 0x7fffffff }, srow[2] = { 0x7fffffff, 0x7fffffff };   /* this strip's tracking */
 	wave_lds_fence();
 
 	for (int s0 = 0; s0 < x.nsteps; s0 += 16) {
@@ -814,6 +831,21 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 				d = hold;
 			}
 			st.hsave = hin; st.Hlast = st.H[R - 1]; st.Fout = f; st.cmout = cm; st.cm8out = MASK8 ? cm8 : cm;
+			if (!CAPTURE) {   /* the first lane (top-down) whose running maximum reaches a new high holds its smallest row */
+				const u32 nb = pk_max(sbest, cm);
+				if (nb != sbest && x.mine && tc >= 0 && tc < x.ncols) {
+#pragma unroll
+					for (int h = 0; h < 2; ++h) {
+						const int nv = (int)((nb >> (16 * h)) & 0xffffu), ov = (int)((sbest >> (16 * h)) & 0xffffu);
+						if (nv > ov) {
+							stc[h] = tc; srow[h] = 0x7fffffff;
+#pragma unroll
+							for (int k = R - 1; k >= 0; --k) if ((int)((st.H[k] >> (16 * h)) & 0xffffu) == nv) srow[h] = x.row0 + l16 * R + k;
+						}
+					}
+					sbest = nb;
+				}
+			}
 			if (l16 == 15) {
 				const u32x4 o = { st.Hlast, st.Fout, st.cmout, st.cm8out };
 				lds_st128(lds, x.bout + 16u * ((s - 15) & 63), o);
@@ -835,6 +867,15 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			const u32x4 rec = lds_ld128(lds, x.bout + 16u * (tc & 63));
 			if (!x.last) *(u32x4*)(x.bnd + 4 * (int64_t)tc) = rec;
 			else if (!CAPTURE && tc >= x.store_from) { x.o16[tc] = rec[2]; x.o8[tc] = rec[3]; }
+		}
+	}
+	if (!CAPTURE) {   /* merge the strip's best cell into the lane's: higher value, then earlier column, then smaller row */
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int v = (int)((sbest >> (16 * h)) & 0xffffu);
+			if (v > st.tv[h] || (v == st.tv[h] && v > 0 && (stc[h] < st.ttc[h] || (stc[h] == st.ttc[h] && srow[h] < st.trow[h])))) {
+				st.tv[h] = v; st.ttc[h] = stc[h]; st.trow[h] = srow[h];
+			}
 		}
 	}
 	dev_fence();   /* the next strip of this chain re-reads the boundary records through HBM */
@@ -876,7 +917,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 		}
 	} else {
 		q = valid ? a.qlist[job] : -1;
-		if (q >= 0) { r = a.res[q]; active = r.status == 0 && r.score1 > 0 && (a.reverse ? r.want_begin == 1 : 1); }
+		if (q >= 0) { r = a.res[q]; active = r.status == 0 && r.score1 > 0 && (a.reverse ? r.want_begin == 1 : !r.loc_done); }
 		if (active) {
 			qa = a.qcodes + a.qoff[q];
 			qlen = (int)(a.qoff[q + 1] - a.qoff[q]);
@@ -906,6 +947,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 
 	ChainState<R> st;
 	st.best = 0; st.btc = 0x7fffffff; st.brow = 0;
+	st.tv[0] = st.tv[1] = 0; st.ttc[0] = st.ttc[1] = 0x7fffffff; st.trow[0] = st.trow[1] = 0x7fffffff;
 	u32 m8[R];
 	for (int sidx = 0; sidx < maxS; ++sidx) {
 		x.mine = sidx < S; x.first = sidx == 0; x.last = sidx == S - 1; x.row0 = sidx * 16 * R;
@@ -926,6 +968,24 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 		else run_strip<R, CAPTURE, false>(lds, x, st, m8);
 	}
 
+	if (!CAPTURE && a.cand) {   /* best cell of this (pair, tile) job per query, for k_reduce (saves the locate pass) */
+		for (int h = 0; h < 2; ++h) {
+			lds_st32(lds, red + 12u * l16, (u32)st.tv[h]);
+			lds_st32(lds, red + 12u * l16 + 4, (u32)st.ttc[h]);
+			lds_st32(lds, red + 12u * l16 + 8, (u32)st.trow[h]);
+			wave_lds_fence();
+			if (l16 == 0 && valid) {
+				int bv = 0, bc = 0x7fffffff, br = 0x7fffffff;
+				for (int k = 0; k < 16; ++k) {
+					const int v = (int)lds_ld32(lds, red + 12u * k), c = (int)lds_ld32(lds, red + 12u * k + 4), w = (int)lds_ld32(lds, red + 12u * k + 8);
+					if (v > bv || (v == bv && v > 0 && (c < bc || (c == bc && w < br)))) { bv = v; bc = c; br = w; }
+				}
+				int32_t* cd = a.cand + ((int64_t)job * 2 + h) * 4;
+				cd[0] = bv; cd[1] = bv > 0 ? x.c_edge + bc : -1; cd[2] = br; cd[3] = 0;
+			}
+			wave_lds_fence();
+		}
+	}
 	if (CAPTURE) {
 		lds_st32(lds, red + 12u * l16, (u32)st.best);
 		lds_st32(lds, red + 12u * l16 + 4, (u32)st.btc);
@@ -1117,7 +1177,7 @@ __global__ void __launch_bounds__(64) k_literal(ssw_literal_args a)
 		ssw_dres r;
 		r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = 0; r.read_begin1 = -1; r.read_end1 = 0;
 		r.ref_end2 = 0; r.cigarLen = 0; r.flag = 0; r.status = 0; r.word = 0; r.want_begin = 0; r.want_cigar = 0;
-		r.rev_score = 0; r.cigar_off = 0;
+		r.rev_score = 0; r.loc_done = 0; r.cigar_off = 0;
 		bool need_word = q >= 0 && !have_byte;
 		bool done = q < 0;
 		if (wave_any(q >= 0 && have_byte)) {
