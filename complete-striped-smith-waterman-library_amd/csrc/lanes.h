@@ -37,7 +37,11 @@ SSW_DEV u32 xl_shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 
 SSW_DEV bool wave_any(bool p) { return __any(p) != 0; }
 SSW_DEV bool wave_all(bool p) { return __all(p) != 0; }
 SSW_DEV unsigned long long wave_ballot(bool p) { return __ballot(p); }
-SSW_DEV void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+/* LDS hand-off between lanes of ONE wavefront (rings, small reductions): LDS operations of a wave execute in issue order,
+   so what is needed is (a) that the compiler does not move LDS accesses across this point -- a wavefront-scope fence turned
+   out NOT to stop it from hoisting a lane's loads of other lanes' slots above the stores (seen on gfx950, ROCm 7.2) -- and
+   (b) nothing more than lgkmcnt(0).  Global loads in flight are not waited for. */
+SSW_DEV void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 /* LDS accessors with byte offsets into the dynamic segment */
 SSW_DEV u32x4 lds_ld128(const unsigned char* lds, u32 off) { return *(const u32x4*)(lds + off); }

@@ -252,6 +252,7 @@ size_t ssw_shim_mem_free_bytes(void);
 void* ssw_shim_event_create(void);
 void  ssw_shim_event_destroy(void* ev);
 int   ssw_shim_event_record(void* ev, void* stream);
+int   ssw_shim_stream_wait_event(void* stream, void* ev);   /* later work on `stream` waits for `ev` */
 float ssw_shim_event_elapsed_ms(void* start, void* stop);   /* both must have completed */
 
 int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream);

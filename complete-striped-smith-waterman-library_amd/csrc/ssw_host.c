@@ -34,9 +34,11 @@ typedef struct { void* p; size_t cap; } dbuf;
 struct ssw_gpu_ctx {
 	int device;
 	void* stream;
+	void* stream2;                      /* reductions of chunk i overlap the fill of chunk i+1 */
+	void *ev_fill[2], *ev_red[2];
 	char err[512];
 	ssw_gpu_timing tm;
-	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, scratch, cigar, need, goff, gpool, bnd, tlist, cand;
+	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, need, goff, gpool, bnd, tlist, cand;
 	void** ev; int nev, capev;          /* event pairs around fill launches */
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
@@ -86,6 +88,8 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
 	ssw_gpu_ctx* c = (ssw_gpu_ctx*)calloc(1, sizeof(*c));
 	c->device = device;
 	c->stream = ssw_shim_stream_create();
+	c->stream2 = ssw_shim_stream_create();
+	for (int i = 0; i < 2; ++i) { c->ev_fill[i] = ssw_shim_event_create(); c->ev_red[i] = ssw_shim_event_create(); }
 	c->ev_t0 = ssw_shim_event_create(); c->ev_a = ssw_shim_event_create(); c->ev_b = ssw_shim_event_create();
 	c->ev_c = ssw_shim_event_create(); c->ev_d = ssw_shim_event_create();
 	if (!c->stream || !c->ev_t0 || !c->ev_d) { fail(0, "stream/event creation failed: %s", ssw_shim_last_error()); free(c); return 0; }
@@ -101,11 +105,13 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_set_device(c->device);
 	ssw_shim_stream_sync(c->stream);
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
-	dbuf_free(&c->cm8); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand);
+	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
 	free(c->ev);
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
 	ssw_shim_event_destroy(c->ev_c); ssw_shim_event_destroy(c->ev_d);
+	for (int i = 0; i < 2; ++i) { ssw_shim_event_destroy(c->ev_fill[i]); ssw_shim_event_destroy(c->ev_red[i]); }
+	ssw_shim_stream_destroy(c->stream2);
 	ssw_shim_stream_destroy(c->stream);
 	free(c);
 }
@@ -533,6 +539,12 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 				const int64_t maxcols = (((int64_t)tile + halo < refLen ? (int64_t)tile + halo : refLen) + 31) / 16 * 16;
 				int64_t per_pair = 8 * stride + (use_x ? 16 * maxcols * ntiles : 0);
 				int64_t chunk = (int64_t)(c->cm_budget / (size_t)per_pair);
+				/* optional: two column-maximum buffer sets so that k_reduce of chunk i runs on a second stream beside k_fill of chunk i+1 */
+				/* measured on MI355X (config 2): overlapping costs more than it saves -- the fill runs at ~100 % VALU issue, so the
+				   reduction's waves only take slots from it (2347 ms/step with, 2160 ms without); kept as an opt-in experiment */
+				const char* ov = getenv("SSW_GPU_OVERLAP");
+				const int dbl = !use_x && chunk < B->npairs && ov && ov[0] == '1';
+				if (dbl) chunk = (int64_t)((c->cm_budget / 2) / (size_t)per_pair);
 				if (chunk < 1) chunk = 1;
 				if (chunk > B->npairs) chunk = B->npairs;
 				if (!use_x) {   /* whole rounds of resident workgroups per launch (all workgroups of a launch take the same time) */
@@ -544,12 +556,19 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 					d_bnd = (uint32_t*)ensure(c, &c->bnd, (size_t)(16 * maxcols * ntiles * chunk));
 					d_cand = (int32_t*)ensure(c, &c->cand, (size_t)(32 * ntiles * chunk));   /* 2 halves x 4 ints per job */
 					if (!d_bnd || !d_cand) goto done;
+					{ const char* nt_ = getenv("SSW_GPU_NO_TRACK"); if (nt_ && nt_[0] == '1') d_cand = 0; }   /* diagnostic: always run the locate pass */
 				}
-				uint32_t* d_cm16 = (uint32_t*)ensure(c, &c->cm16, (size_t)(4 * stride * chunk));
-				uint32_t* d_cm8 = (uint32_t*)ensure(c, &c->cm8, (size_t)(4 * stride * chunk));
-				if (!d_cm16 || !d_cm8) goto done;
-				for (int32_t p0 = 0; p0 < B->npairs; p0 += (int32_t)chunk) {
+				uint32_t* d_cmA16 = (uint32_t*)ensure(c, &c->cm16, (size_t)(4 * stride * chunk));
+				uint32_t* d_cmA8 = (uint32_t*)ensure(c, &c->cm8, (size_t)(4 * stride * chunk));
+				uint32_t* d_cmB16 = dbl ? (uint32_t*)ensure(c, &c->cm16b, (size_t)(4 * stride * chunk)) : d_cmA16;
+				uint32_t* d_cmB8 = dbl ? (uint32_t*)ensure(c, &c->cm8b, (size_t)(4 * stride * chunk)) : d_cmA8;
+				if (!d_cmA16 || !d_cmA8 || !d_cmB16 || !d_cmB8) goto done;
+				int launch_i = 0;
+				for (int32_t p0 = 0; p0 < B->npairs; p0 += (int32_t)chunk, ++launch_i) {
 					const int32_t np = B->npairs - p0 < chunk ? B->npairs - p0 : (int32_t)chunk;
+					const int bi = dbl ? (launch_i & 1) : 0;
+					uint32_t* d_cm16 = bi ? d_cmB16 : d_cmA16; uint32_t* d_cm8 = bi ? d_cmB8 : d_cmA8;
+					if (dbl && launch_i >= 2) ssw_shim_stream_wait_event(c->stream, c->ev_red[bi]);    /* the buffer set is free again */
 					ssw_fill_args fa;
 					fa.tgt = d_tgt; fa.refLen = refLen; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off;
 					fa.pairs = d_pairs + B->first_pair + p0; fa.npairs = np; fa.mat = d_mat; fa.n = n;
@@ -581,7 +600,17 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 					ra.cm16 = d_cm16; ra.cm8 = d_cm8; ra.cm_stride = stride; ra.refLen = refLen; ra.pairs = fa.pairs; ra.npairs = np;
 					ra.qoff = Q->d_off; ra.maskLen = prm->maskLen; ra.bias = bias; ra.score_size = prm->score_size;
 					ra.flag = prm->flag; ra.filters = prm->filters; ra.res = d_res; ra.cand = d_cand; ra.tile = tile; ra.ntiles = ntiles;
+					if (dbl) {
+						ssw_shim_event_record(c->ev_fill[bi], c->stream);
+						ssw_shim_stream_wait_event(c->stream2, c->ev_fill[bi]);
+						if (ssw_shim_launch_reduce(&ra, c->stream2)) { fail(c, "reduce launch failed: %s", ssw_shim_last_error()); goto done; }
+						ssw_shim_event_record(c->ev_red[bi], c->stream2);
+					} else
 					if (ssw_shim_launch_reduce(&ra, c->stream)) { fail(c, "reduce launch failed: %s", ssw_shim_last_error()); goto done; }
+				}
+				if (dbl) {   /* everything later on the main stream sees all records of this bucket */
+					ssw_shim_stream_wait_event(c->stream, c->ev_red[0]);
+					if (launch_i > 1) ssw_shim_stream_wait_event(c->stream, c->ev_red[1]);
 				}
 			}
 		}

@@ -1792,6 +1792,7 @@ extern "C" void* ssw_shim_event_create(void)
 }
 extern "C" void ssw_shim_event_destroy(void* e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
 extern "C" int ssw_shim_event_record(void* e, void* s) { return shim_check(hipEventRecord((hipEvent_t)e, (hipStream_t)s), "hipEventRecord"); }
+extern "C" int ssw_shim_stream_wait_event(void* s, void* e) { return shim_check(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0), "hipStreamWaitEvent"); }
 extern "C" float ssw_shim_event_elapsed_ms(void* a, void* b)
 {
 	float ms = 0.f;

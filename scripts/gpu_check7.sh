@@ -1,0 +1,7 @@
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+timeout 600 python bench.py --reads 8192 --db-targets 2048 --steps 2 --warmup 1 > gpurun_out/bench_config5.log 2>&1; echo "rc=$?" >> gpurun_out/bench_config5.log
+timeout 600 python bench.py --reads 10000 --read-len 10000 --ref-len 100000 --flag 2 --sub 0.01 --indel 0.0025 --mask-len 5000 --steps 1 --warmup 0 --cpu-sample 128 > gpurun_out/bench_config4.log 2>&1; echo "rc=$?" >> gpurun_out/bench_config4.log

@@ -30,5 +30,6 @@ int ssw_shim_event_record(void* e, void*)
 	*(double*)e = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 	return 0;
 }
+int ssw_shim_stream_wait_event(void*, void*) { return 0; }
 float ssw_shim_event_elapsed_ms(void* a, void* b) { return (float)(*(double*)b - *(double*)a); }
 }
