@@ -27,7 +27,8 @@ sys.path.insert(0, os.path.join(ROOT, "complete-striped-smith-waterman-library_a
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec
-VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9    # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6e12 lane-ops/s (= the FP32 vector FMA rate)
+VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9    # packed 16-bit (VOP3P) instructions issue over 4 cycles per wave64: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
+                                            # = 39.3e12 packed lane-instr/s = 78.6e12 16-bit values/s, the same datapath rate as v_fma_f32 (profiles/round1_valu_rate_probe.txt)
 
 
 def make_reads_fast(ref, nreads, length, seed, sub=0.03, ins=0.005, dele=0.005, frac_random=0.05):
@@ -272,6 +273,7 @@ def main(argv=None):
             "roofline_valu": {"bound": "valu-int16x2", "achieved": round(achieved_valu / 1e12, 3), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
                               "unit": "T lane-op/s", "frac": round(achieved_valu / VALU_PEAK_LANEOPS, 4),
                               "measured_peak_probe": round(probe / 1e12, 2),
+                              "note": "packed-int16 instruction rate; VOP3P issues at 16 lanes/clk/SIMD (peak = 256 CU x 4 SIMD x 16 x 2.4 GHz), the probe is the same mix measured on this device",
                               "fill_gcups_padded": round(fill_cells / (fill_ms * 1e-3) / 1e9, 1) if fill_ms > 0 else 0.0},
         }
         # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) ----
