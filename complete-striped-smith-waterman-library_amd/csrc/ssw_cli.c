@@ -114,7 +114,7 @@ static void free_record(record* r) { free(r->name); free(r->seq); free(r->qual);
 
 /* ---------------------------------------------------------------- output (reference src/main.c:118-245) */
 static void write_alignment(const s_align* a0, const record* ref, const record* read, const char* read_seq, const int8_t* ref_num,
-                            const int8_t* read_num, const int8_t* table, int strand, int sam)
+                            const int8_t* read_num, const int8_t* table, int strand, int sam, int32_t nm_dev)
 {
 	s_align* a = (s_align*)a0;
 	if (!sam) {
@@ -178,7 +178,8 @@ static void write_alignment(const s_align* a0, const record* ref, const record* 
 	mapq = mapq < 254 ? mapq : 254;
 	fprintf(stdout, strand ? "16\t" : "0\t");
 	fprintf(stdout, "%s\t%d\t%d\t", ref->name, a->ref_begin1 + 1, mapq);
-	const int32_t nm = mark_mismatch(a->ref_begin1, a->read_begin1, a->read_end1, ref_num, read_num, read->len, &a->cigar, &a->cigarLen);
+	/* nm_dev >= 0: the CIGAR was already rewritten ('=', 'X', soft clips) and counted on the device (ssw_gpu_params.mark_mismatch) */
+	const int32_t nm = nm_dev >= 0 ? nm_dev : mark_mismatch(a->ref_begin1, a->read_begin1, a->read_end1, ref_num, read_num, read->len, &a->cigar, &a->cigarLen);
 	for (c = 0; c < a->cigarLen; ++c) fprintf(stdout, "%lu%c", (unsigned long)cigar_int_to_len(a->cigar[c]), cigar_int_to_op(a->cigar[c]));
 	fprintf(stdout, "\t*\t0\t0\t%s\t", read_seq);
 	if (read->qual && strand) { for (p = read->len - 1; p >= 0; --p) fputc(read->qual[p], stdout); }
@@ -332,7 +333,7 @@ int main(int argc, char* const argv[])
 		}
 		ssw_gpu_params p;
 		p.mat = mat; p.n = n; p.gapO = (uint8_t)gap_open; p.gapE = (uint8_t)gap_ext; p.flag = path ? 2 : 0; p.filters = (uint16_t)filter;
-		p.filterd = 0; p.maskLen = -1; p.score_size = 2;
+		p.filterd = 0; p.maskLen = -1; p.score_size = 2; p.mark_mismatch = sam ? 1 : 0;
 		ssw_gpu_result* res = (ssw_gpu_result*)malloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1));
 		ssw_gpu_result* res_rc = reverse ? (ssw_gpu_result*)malloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1)) : 0;
 		uint32_t *pool = 0, *pool_rc = 0; int64_t words = 0;
@@ -360,12 +361,12 @@ int main(int argc, char* const argv[])
 				if (rr && rr->status == 0 && rr->score1 > r->score1 && rr->score1 >= filter) {
 					s_align* a = ssw_gpu_result_to_align(rr, pool_rc);
 					if (a->flag == 2) fprintf(stderr, "Warning: The reverse compliment alignment of the following sequences may miss a small part.\nref_seq: %s\nread_seq: %s\n\n", targets[t].name, reads[q].name);
-					write_alignment(a, &targets[t], &reads[q], rcseq[q], tcodes + toff[t], rcodes + qoff[q], table, 1, sam);
+					write_alignment(a, &targets[t], &reads[q], rcseq[q], tcodes + toff[t], rcodes + qoff[q], table, 1, sam, sam ? rr->edit_distance : -1);
 					align_destroy(a);
 				} else if (r->score1 > 0 && r->score1 >= filter) {
 					s_align* a = ssw_gpu_result_to_align(r, pool);
 					if (a->flag == 2) fprintf(stderr, "Warning: The alignment of the following sequences may miss a small part.\nref_seq: %s\nread_seq: %s\n\n", targets[t].name, reads[q].name);
-					write_alignment(a, &targets[t], &reads[q], reads[q].seq, tcodes + toff[t], qcodes + qoff[q], table, 0, sam);
+					write_alignment(a, &targets[t], &reads[q], reads[q].seq, tcodes + toff[t], qcodes + qoff[q], table, 0, sam, sam ? r->edit_distance : -1);
 					align_destroy(a);
 				} else if (r->score1 <= 0) {
 					fprintf(stderr, "There is no identical residue between the following reference and read seqeunces.\nref_name: %s\nread_name: %s\n\n", targets[t].name, reads[q].name);

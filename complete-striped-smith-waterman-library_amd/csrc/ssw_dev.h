@@ -34,6 +34,7 @@ typedef struct {
 	int32_t want_cigar;
 	int32_t rev_score;   /* best score seen by the reverse pass */
 	int32_t loc_done;    /* read_end1 already known (tracked by the fill kernel): no locate pass */
+	int32_t nm;          /* edit distance from the device-side mark_mismatch */
 	int64_t cigar_off;   /* word offset of this alignment's CIGAR in the device CIGAR pool */
 } ssw_dres;
 
@@ -60,7 +61,7 @@ typedef struct {
 /* byte-for-byte the layout of ssw_gpu_result (include/ssw_gpu.h); checked by a static assertion in ssw_host.c */
 struct ssw_out_rec {
 	uint16_t score1, score2;
-	int32_t ref_begin1, ref_end1, read_begin1, read_end1, ref_end2, cigarLen;
+	int32_t ref_begin1, ref_end1, read_begin1, read_end1, ref_end2, cigarLen, edit_distance;
 	int64_t cigar_off;
 	uint16_t flag, status;
 };
@@ -207,6 +208,18 @@ typedef struct {
 	const int64_t* soff;     /* optional: job j owns scratch[soff[j] .. soff[j+1]) instead of a uniform stride */
 } ssw_trace_args;
 
+/* device-side mark_mismatch: M -> '=' / 'X' runs, soft clips, edit distance */
+typedef struct {
+	const int8_t* tgt;
+	const int8_t* qcodes;
+	const int64_t* qoff;
+	int32_t nq;
+	ssw_dres* res;
+	const uint32_t* cigar;   /* slots written by the traceback (res[q].cigar_off) */
+	uint32_t* out;           /* nq slots of out_stride words */
+	int64_t out_stride;
+} ssw_mark_args;
+
 /* compaction of the per-query CIGAR slots into one pool */
 typedef struct {
 	const uint32_t* src;     /* CIGAR slots (res[q].cigar_off indexes into this) */
@@ -265,6 +278,7 @@ int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream);
 int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);
 int ssw_shim_launch_trace_wave(const ssw_trace_args* a, void* stream);   /* one wavefront per alignment (long reads) */
 int ssw_shim_launch_gather(const ssw_gather_args* a, void* stream);
+int ssw_shim_launch_mark(const ssw_mark_args* a, void* stream);
 int ssw_shim_launch_prep(const ssw_prep_args* a, void* stream);
 int ssw_shim_launch_selftest(const ssw_selftest_args* a, int blocks, void* stream);
 

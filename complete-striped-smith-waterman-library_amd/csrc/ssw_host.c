@@ -38,7 +38,7 @@ struct ssw_gpu_ctx {
 	void *ev_fill[2], *ev_red[2];
 	char err[512];
 	ssw_gpu_timing tm;
-	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, need, goff, gpool, bnd, tlist, cand;
+	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, cigar2, need, goff, gpool, bnd, tlist, cand;
 	void** ev; int nev, capev;          /* event pairs around fill launches */
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
@@ -105,7 +105,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_set_device(c->device);
 	ssw_shim_stream_sync(c->stream);
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
-	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand);
+	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->cigar2); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
 	free(c->ev);
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
@@ -367,7 +367,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 				const ssw_dres* r = &hres[(int64_t)q * nt + k];
 				ssw_gpu_result* o = &results[(int64_t)q * tcount + t0 + k];
 				o->score1 = (uint16_t)r->score1; o->score2 = (uint16_t)r->score2; o->ref_begin1 = -1; o->ref_end1 = r->ref_end1;
-				o->read_begin1 = -1; o->read_end1 = r->read_end1; o->ref_end2 = r->ref_end2; o->cigarLen = 0; o->cigar_off = -1;
+				o->read_begin1 = -1; o->read_end1 = r->read_end1; o->ref_end2 = r->ref_end2; o->cigarLen = 0; o->edit_distance = 0; o->cigar_off = -1;
 				o->flag = 0; o->status = (uint16_t)r->status;
 				if (r->status == 0 && r->score1 > 0) { if (r->word) c->tm.n_word++; else c->tm.n_byte++; }
 				c->tm.cells += (Q->h_off[q + 1] - Q->h_off[q]) * (T->h_off[tfirst + t0 + k + 1] - T->h_off[tfirst + t0 + k]);
@@ -759,6 +759,15 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 			if (npend > 0) { fail(c, "internal error: traceback scratch negotiation did not converge%s", ""); goto done; }
 			if (did_trace && ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nq, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
 		}
+		if (did_trace && prm->mark_mismatch) {   /* SAM-style CIGARs + edit distance, rewritten on the device */
+			const int64_t m_stride = (cig_stride + maxlen + 8 + 3) / 4 * 4;
+			uint32_t* d_cig2 = (uint32_t*)ensure(c, &c->cigar2, (size_t)(4 * m_stride * nq));
+			if (!d_cig2) goto done;
+			ssw_mark_args ma; ma.tgt = d_tgt; ma.qcodes = Q->d_codes; ma.qoff = Q->d_off; ma.nq = nq; ma.res = d_res; ma.cigar = d_cig;
+			ma.out = d_cig2; ma.out_stride = m_stride;
+			if (ssw_shim_launch_mark(&ma, c->stream)) { fail(c, "mark launch failed: %s", ssw_shim_last_error()); goto done; }
+			d_cig = d_cig2;
+		}
 		ssw_shim_event_record(c->ev_c, c->stream);
 
 		if (ssw_shim_d2h(hres, d_res, sizeof(ssw_dres) * (size_t)nq, c->stream) || ssw_shim_stream_sync(c->stream)) {
@@ -792,6 +801,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 			o->score1 = (uint16_t)r->score1; o->score2 = (uint16_t)r->score2;
 			o->ref_begin1 = r->ref_begin1; o->ref_end1 = r->ref_end1; o->read_begin1 = r->read_begin1; o->read_end1 = r->read_end1;
 			o->ref_end2 = r->ref_end2; o->cigarLen = r->cigarLen; o->cigar_off = -1; o->flag = (uint16_t)r->flag; o->status = (uint16_t)r->status;
+			o->edit_distance = r->nm;
 			if (r->score1 <= 0 && r->status == 0) { o->ref_begin1 = -1; o->read_begin1 = -1; }
 			if (r->cigarLen > 0 && r->status == 0) o->cigar_off = pool_words + goffs[q];
 			if (r->status == 0 && r->score1 > 0) { if (r->word) c->tm.n_word++; else c->tm.n_byte++; }
@@ -921,7 +931,7 @@ s_align* ssw_align(const s_profile* prof, const int8_t* ref, int32_t refLen, con
 	if (Q && T) {
 		ssw_gpu_params prm;
 		prm.mat = prof->mat; prm.n = prof->n; prm.gapO = weight_gapO; prm.gapE = weight_gapE; prm.flag = flag;
-		prm.filters = filters; prm.filterd = filterd; prm.maskLen = maskLen < 0 ? 0 : maskLen; prm.score_size = prof->score_size;
+		prm.filters = filters; prm.filterd = filterd; prm.maskLen = maskLen < 0 ? 0 : maskLen; prm.score_size = prof->score_size; prm.mark_mismatch = 0;
 		ssw_gpu_result r; uint32_t* pool = 0; int64_t words = 0;
 		if (ssw_gpu_align_batch(c, Q, T, 0, 1, &prm, &r, &pool, &words) == 0) {
 			if (r.status == 1)

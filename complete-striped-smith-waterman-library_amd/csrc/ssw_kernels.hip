@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			ssw_dres r;
 			r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = 0; r.read_begin1 = -1; r.read_end1 = 0;
 			r.ref_end2 = 0; r.cigarLen = 0; r.flag = 0; r.status = status; r.word = word; r.want_begin = 0; r.want_cigar = 0;
-			r.rev_score = 0; r.loc_done = 0; r.cigar_off = 0;
+			r.rev_score = 0; r.loc_done = 0; r.nm = 0; r.cigar_off = 0;
 			if (status == 0 && bv > 0) {
 				r.score1 = bv; r.ref_end1 = bc; r.read_end1 = br < len - 1 ? br : len - 1;
 				if (maskLen >= 15) { r.score2 = s2; r.ref_end2 = s2 > 0 ? i2 : 0; }
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			if (a.out) {
 				ssw_out_rec o;
 				o.score1 = (uint16_t)r.score1; o.score2 = (uint16_t)r.score2; o.ref_begin1 = -1; o.ref_end1 = r.ref_end1; o.read_begin1 = -1;
-				o.read_end1 = r.read_end1; o.ref_end2 = r.ref_end2; o.cigarLen = 0; o.cigar_off = -1; o.flag = 0; o.status = (uint16_t)r.status;
+				o.read_end1 = r.read_end1; o.ref_end2 = r.ref_end2; o.cigarLen = 0; o.edit_distance = 0; o.cigar_off = -1; o.flag = 0; o.status = (uint16_t)r.status;
 				a.out[(int64_t)q * a.res_nt + (t - a.tfirst)] = o;
 				if (a.counters && r.status == 0 && r.score1 > 0) atomicAdd(a.counters + (r.word ? 0 : 1), 1);
 			} else a.res[(int64_t)q * a.res_nt + (t - a.tfirst)] = r;
@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(256) k_reduce(ssw_reduce_args a)
 		ssw_dres& x = r[h];
 		x.score1 = 0; x.score2 = 0; x.ref_begin1 = -1; x.ref_end1 = 0; x.read_begin1 = -1; x.read_end1 = 0;
 		x.ref_end2 = 0; x.cigarLen = 0; x.flag = 0; x.status = 0; x.word = 0; x.want_begin = 0; x.want_cigar = 0;
-		x.rev_score = 0; x.loc_done = 0; x.cigar_off = 0;
+		x.rev_score = 0; x.loc_done = 0; x.nm = 0; x.cigar_off = 0;
 		if (q < 0) continue;
 		const int len = (int)(a.qoff[q + 1] - a.qoff[q]);
 		const bool padded = (len & 15) >= 1 && (len & 15) <= 8;      /* 16-bit rules see 8 rows fewer */
@@ -1177,7 +1177,7 @@ __global__ void __launch_bounds__(64) k_literal(ssw_literal_args a)
 		ssw_dres r;
 		r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = 0; r.read_begin1 = -1; r.read_end1 = 0;
 		r.ref_end2 = 0; r.cigarLen = 0; r.flag = 0; r.status = 0; r.word = 0; r.want_begin = 0; r.want_cigar = 0;
-		r.rev_score = 0; r.loc_done = 0; r.cigar_off = 0;
+		r.rev_score = 0; r.loc_done = 0; r.nm = 0; r.cigar_off = 0;
 		bool need_word = q >= 0 && !have_byte;
 		bool done = q < 0;
 		if (wave_any(q >= 0 && have_byte)) {
@@ -1530,6 +1530,40 @@ __global__ void __launch_bounds__(256) k_prep(ssw_prep_args a)
 	a.out[b + (e - 1 - i)] = (c >= 0 && c < 4) ? (int8_t)(3 - c) : c;
 }
 
+/* mark_mismatch on the device (reference src/ssw.c:1019-1074), one thread per alignment: leading soft clip, every M run split
+   into '=' (7) / 'X' (8) runs by comparing residue codes, I and D kept, trailing soft clip; nm = mismatches + gap bases */
+__global__ void __launch_bounds__(64) k_mark(ssw_mark_args a)
+{
+	const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (q >= a.nq) return;
+	ssw_dres r = a.res[q];
+	if (r.cigarLen <= 0 || r.status != 0) return;
+	const u32* cig = a.cigar + r.cigar_off;
+	u32* out = a.out + (int64_t)q * a.out_stride;
+	const int8_t* t = a.tgt + r.ref_begin1;
+	const int8_t* rd = a.qcodes + a.qoff[q] + r.read_begin1;
+	const int readLen = (int)(a.qoff[q + 1] - a.qoff[q]);
+	int p = 0, nm = 0; u32 eq = 0, ne = 0;
+	if (r.read_begin1 > 0) out[p++] = ((u32)r.read_begin1 << 4) | 4u;
+	for (int i = 0; i < r.cigarLen; ++i) {
+		const u32 len = cig[i] >> 4, op = cig[i] & 0xfu;
+		if (op == 0 || op > 8) {
+			for (u32 k = 0; k < len; ++k, ++t, ++rd) {
+				if (*t != *rd) { ++nm; if (eq) { out[p++] = (eq << 4) | 7u; eq = 0; } ++ne; }
+				else { if (ne) { out[p++] = (ne << 4) | 8u; ne = 0; } ++eq; }
+			}
+		} else if (op == 1 || op == 2) {
+			if (op == 1) rd += len; else t += len;
+			nm += (int)len;
+			if (eq) { out[p++] = (eq << 4) | 7u; eq = 0; } else if (ne) { out[p++] = (ne << 4) | 8u; ne = 0; }
+			out[p++] = (len << 4) | op;
+		}
+	}
+	if (eq) out[p++] = (eq << 4) | 7u; else if (ne) out[p++] = (ne << 4) | 8u;
+	if (readLen - r.read_end1 - 1 > 0) out[p++] = ((u32)(readLen - r.read_end1 - 1) << 4) | 4u;
+	a.res[q].cigarLen = p; a.res[q].cigar_off = (int64_t)q * a.out_stride; a.res[q].nm = nm;
+}
+
 /* pack the used part of every CIGAR slot into one contiguous pool (one thread per query) */
 __global__ void __launch_bounds__(256) k_gather(ssw_gather_args a)
 {
@@ -1739,6 +1773,14 @@ extern "C" int ssw_shim_launch_prep(const ssw_prep_args* a, void* stream)
 	ssw_prep_args args = *a;
 	if (args.total <= 0) return 0;
 	SSW_LAUNCH(k_prep, ssw_prep_args, args, (args.total + 255) / 256, 256, 0, stream);
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_launch_mark(const ssw_mark_args* a, void* stream)
+{
+	ssw_mark_args args = *a;
+	if (args.nq <= 0) return 0;
+	SSW_LAUNCH(k_mark, ssw_mark_args, args, (args.nq + 63) / 64, 64, 0, stream);
 	return SSW_LAUNCH_OK();
 }
 

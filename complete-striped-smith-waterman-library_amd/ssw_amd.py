@@ -33,14 +33,15 @@ class CAlignRes(C.Structure):
 class Params(C.Structure):
     """ssw_gpu_params (include/ssw_gpu.h)."""
     _fields_ = [("mat", _i8p), ("n", C.c_int32), ("gapO", C.c_uint8), ("gapE", C.c_uint8), ("flag", C.c_uint8),
-                ("filters", C.c_uint16), ("filterd", C.c_int32), ("maskLen", C.c_int32), ("score_size", C.c_int8)]
+                ("filters", C.c_uint16), ("filterd", C.c_int32), ("maskLen", C.c_int32), ("score_size", C.c_int8),
+                ("mark_mismatch", C.c_int8)]
 
 
 class Result(C.Structure):
     """ssw_gpu_result (include/ssw_gpu.h)."""
     _fields_ = [("score1", C.c_uint16), ("score2", C.c_uint16), ("ref_begin1", C.c_int32), ("ref_end1", C.c_int32),
                 ("read_begin1", C.c_int32), ("read_end1", C.c_int32), ("ref_end2", C.c_int32), ("cigarLen", C.c_int32),
-                ("cigar_off", C.c_int64), ("flag", C.c_uint16), ("status", C.c_uint16)]
+                ("edit_distance", C.c_int32), ("cigar_off", C.c_int64), ("flag", C.c_uint16), ("status", C.c_uint16)]
 
 
 class Timing(C.Structure):
@@ -52,7 +53,7 @@ class Timing(C.Structure):
 
 RESULT_DTYPE = np.dtype([("score1", "<u2"), ("score2", "<u2"), ("ref_begin1", "<i4"), ("ref_end1", "<i4"),
                          ("read_begin1", "<i4"), ("read_end1", "<i4"), ("ref_end2", "<i4"), ("cigarLen", "<i4"),
-                         ("cigar_off", "<i8"), ("flag", "<u2"), ("status", "<u2")], align=True)
+                         ("edit_distance", "<i4"), ("cigar_off", "<i8"), ("flag", "<u2"), ("status", "<u2")], align=True)
 assert RESULT_DTYPE.itemsize == C.sizeof(Result)
 
 
@@ -151,12 +152,12 @@ class Context(object):
         return Seqs(self, seqs)
 
     def align_batch(self, queries, targets, mat, n, gapO=3, gapE=1, flag=0, filters=0, filterd=0, maskLen=-1,
-                    score_size=2, target_first=0, target_count=None, want_cigar=True):
+                    score_size=2, target_first=0, target_count=None, want_cigar=True, mark_mismatch=False):
         """-> (numpy record array [nq, nt] of RESULT_DTYPE, numpy uint32 CIGAR pool)."""
         if target_count is None:
             target_count = targets.count - target_first
         mat = np.ascontiguousarray(mat, dtype=np.int8)
-        p = Params(mat.ctypes.data_as(_i8p), n, gapO, gapE, flag, filters, filterd, maskLen, score_size)
+        p = Params(mat.ctypes.data_as(_i8p), n, gapO, gapE, flag, filters, filterd, maskLen, score_size, 1 if mark_mismatch else 0)
         res = np.zeros((queries.count, target_count), dtype=RESULT_DTYPE)
         pool = _u32p()
         words = C.c_int64(0)

@@ -39,6 +39,8 @@ typedef struct {
 	int32_t filterd;
 	int32_t maskLen;     /* >= 0: used for every query; < 0: readLen/2 per query (reference src/main.c:464) */
 	int8_t score_size;   /* as ssw_init: 0, 1 or 2 */
+	int8_t mark_mismatch;/* != 0: every returned CIGAR is rewritten on the device the way mark_mismatch() does it (soft clips,
+	                        '=' / 'X' runs) and edit_distance receives its return value (reference src/ssw.c:1019-1074) */
 } ssw_gpu_params;
 
 /* One alignment: the fields of s_align (reference src/ssw.h:55-66) with the CIGAR
@@ -52,6 +54,7 @@ typedef struct {
 	int32_t read_end1;
 	int32_t ref_end2;
 	int32_t cigarLen;    /* 0: no path */
+	int32_t edit_distance; /* mark_mismatch()'s return value when params.mark_mismatch is set, else 0 */
 	int64_t cigar_off;   /* first word of this CIGAR in the pool returned by ssw_gpu_align_batch */
 	uint16_t flag;       /* as s_align.flag */
 	uint16_t status;     /* 0 ok; 1 the reference returns NULL here (8-bit overflow with score_size 0) */

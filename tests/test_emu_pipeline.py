@@ -212,3 +212,33 @@ def test_single_pair_abi_on_emulator(emu_lib_path):
     assert (s.nScore, s.nScore2, s.nRefBeg, s.nRefEnd, s.nQryBeg, s.nQryEnd, s.nRefEnd2, s.nCigarLen) == (21, 8, 8, 21, 0, 14, 4, 3)
     assert [s.sCigar[i] for i in range(3)] == [144, 17, 80]
     lib.align_destroy(a); lib.init_destroy(p)
+
+
+def test_device_mark_mismatch(ectx):
+    """ssw_gpu_params.mark_mismatch: '=' / 'X' / soft-clip CIGARs and the edit distance computed on the device equal what the
+    reference's mark_mismatch() makes of the raw CIGAR (oracle restatement, itself pinned to the reference)"""
+    import ctypes as C
+    from sswutil import _ptr, i8p, u32p, oracle_lib
+    O = oracle_lib()
+    rng = np.random.default_rng(14)
+    ref = random_ref(800, 19, 4, 0.01)
+    reads = make_reads(rng, ref, 10, rng.integers(20, 200, size=10), 4, sub=0.08, ins=0.03, dele=0.03, frac_random=0.1)
+    reads = [np.concatenate([rng.integers(0, 4, size=6, dtype=np.int8), r, rng.integers(0, 4, size=5, dtype=np.int8)]) for r in reads]
+    Q = ectx.upload(reads); T = ectx.upload([ref])
+    raw, rcig = ectx.align_batch(Q, T, dna_matrix(2, 2), 5, 3, 1, 2, 0, 0, -1, 2)
+    res, cig = ectx.align_batch(Q, T, dna_matrix(2, 2), 5, 3, 1, 2, 0, 0, -1, 2, mark_mismatch=True)
+    Q.free(); T.free()
+    checked = 0
+    for i, rd in enumerate(reads):
+        a, b = raw[i, 0], res[i, 0]
+        if a["cigarLen"] <= 0:
+            assert b["cigarLen"] <= 0
+            continue
+        c0 = np.ascontiguousarray(rcig[int(a["cigar_off"]):int(a["cigar_off"]) + int(a["cigarLen"])], dtype=np.uint32)
+        out = np.zeros(len(c0) + 2 * len(rd) + 4, dtype=np.uint32); olen = C.c_int32(0)
+        nm = O.orc_mark_mismatch(int(a["ref_begin1"]), int(a["read_begin1"]), int(a["read_end1"]), _ptr(ref, i8p), _ptr(rd, i8p), len(rd),
+                                 _ptr(c0, u32p), len(c0), _ptr(out, u32p), C.byref(olen))
+        got = cig[int(b["cigar_off"]):int(b["cigar_off"]) + int(b["cigarLen"])]
+        assert int(b["edit_distance"]) == nm and list(got) == list(out[:olen.value])
+        checked += 1
+    assert checked >= 6
