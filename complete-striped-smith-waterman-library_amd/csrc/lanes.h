@@ -33,6 +33,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 SSW_DEV u32 xl_row_shr1_zero(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x111, 0xf, 0xf, true); }
 SSW_DEV u32 xl_row_shr1_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x111, 0xf, 0xf, false); }
 template <int N> SSW_DEV u32 xl_row_ror(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x120 + N, 0xf, 0xf, true); }
+/* wave_shr:1 (0x138, GFX9 family only): lane i reads lane i-1 across the whole wavefront; lane 0 keeps `keep` */
+SSW_DEV u32 xl_wave_shr1_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x138, 0xf, 0xf, false); }
 SSW_DEV u32 xl_shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 64); }
 SSW_DEV bool wave_any(bool p) { return __any(p) != 0; }
 SSW_DEV bool wave_all(bool p) { return __all(p) != 0; }
@@ -54,6 +56,9 @@ SSW_DEV void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 SSW_DEV void dev_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); }
 SSW_DEV void lds_st16(unsigned char* lds, u32 off, u32 v) { *(uint16_t*)(lds + off) = (uint16_t)v; }
 #endif
+
+/* hand-off to the next lane of a chain of GL lanes (16: one DPP row, 64: the whole wavefront) */
+template <int GL> SSW_DEV u32 xl_chain_shr1_keep(u32 keep, u32 v) { return GL == 64 ? xl_wave_shr1_keep(keep, v) : xl_row_shr1_keep(keep, v); }
 
 /* packed 2 x int16 arithmetic (identical source for device and emulation) */
 SSW_DEV u32 pk_adds(u32 a, u32 b)   /* v_pk_add_i16 clamp: signed saturating add */

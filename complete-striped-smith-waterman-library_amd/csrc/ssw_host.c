@@ -222,8 +222,9 @@ static void* next_event(ssw_gpu_ctx* c)
 }
 
 /* queries that share a chain geometry: short queries (<= 384 residues) by R = ceil(len/16) rows per lane, one strip;
-   longer ones by their padded length P16, cut into `strips` row strips of 16*R rows (k_chainx) */
-typedef struct { int32_t R, strips, P16; int32_t first_pair, npairs; int32_t first_q, nq; } bucket;
+   longer ones by their padded length P16, cut into `strips` row strips of lanes*R rows (k_chainx; lanes = 64: the
+   wavefront is one chain, 16: four chains per wavefront) */
+typedef struct { int32_t R, strips, P16, lanes, use_x; int32_t first_pair, npairs; int32_t first_q, nq; } bucket;
 typedef struct { int32_t key, q; } keyed;
 static int keyed_cmp(const void* a, const void* b)
 {
@@ -268,7 +269,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 			for (int32_t q = 0; q < nq; ++q) { const int64_t L = Q->h_off[q + 1] - Q->h_off[q]; if (L > 16 * SSW_RMAX && L <= 640) { mk[k].key = (int32_t)L; mk[k].q = q; ++k; } }
 			qsort(mk, (size_t)nm, sizeof(keyed), keyed_cmp);
 			for (int cls = 28; cls <= 40; cls += 4) {
-				bucket b; b.R = cls; b.strips = 1; b.P16 = 16 * cls; b.first_pair = np; b.first_q = 0; b.nq = 0;
+				bucket b; b.R = cls; b.strips = 1; b.P16 = 16 * cls; b.lanes = 16; b.use_x = 0; b.first_pair = np; b.first_q = 0; b.nq = 0;
 				int32_t i = 0;
 				while (i < nm) {                   /* queries whose ceil(len/16) falls into (cls-4, cls] */
 					const int r = (mk[i].key + 15) / 16;
@@ -322,7 +323,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 			const bucket* B = b < nb ? &bk[b] : &midb;
 			const ssw_pair* bpairs = d_pairs;
 			if (b >= nb) { midb = mid[b - nb]; bpairs = d_midpairs; }
-			if (B->strips > 1) continue;     /* long queries go through the per-target strip path (or the size classes below) */
+			if (B->use_x) continue;     /* long queries go through the per-target strip path (or the size classes below) */
 			int64_t per = (int64_t)(c->cm_budget / 2) / (8 * stride * (int64_t)B->npairs);   /* targets per launch */
 			per = per / 16 * 16; if (per < 16) per = 16;
 			int64_t cap = per < nz ? per : nz;
@@ -417,16 +418,25 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 		keys[q].key = len <= 16 * SSW_RMAX ? (int32_t)((len + 15) / 16) : (int32_t)(SSW_RMAX + (len + 15) / 16);
 	}
 	qsort(keys, (size_t)nq, sizeof(keyed), keyed_cmp);
+	/* long queries: the wavefront is one chain of 64 lanes; rows per lane bounded so that one profile stays near 24 KiB
+	   of LDS (several waves per CU).  SSW_GPU_XLANES=16 / SSW_GPU_XR=<rows per lane> override (experiments). */
+	int32_t xlanes = 64, xrmax = 4 * (24 / (n + 1) < 1 ? 1 : 24 / (n + 1) > 3 ? 3 : 24 / (n + 1));
+	{
+		const char* e = getenv("SSW_GPU_XLANES"); if (e && atoi(e) == 16) xlanes = 16;
+		e = getenv("SSW_GPU_XR"); if (e && atoi(e) >= 1 && atoi(e) <= 16) xrmax = atoi(e);
+	}
 	for (int32_t i = 0; i < nq; ) {
 		int32_t j = i;
 		while (j < nq && keys[j].key == keys[i].key) ++j;
 		bk = (bucket*)realloc(bk, sizeof(bucket) * (size_t)(nb + 1));
 		bucket b;
-		if (keys[i].key <= SSW_RMAX) { b.R = keys[i].key; b.strips = 1; b.P16 = 16 * b.R; }
+		if (keys[i].key <= SSW_RMAX) { b.R = keys[i].key; b.strips = 1; b.P16 = 16 * b.R; b.lanes = 16; b.use_x = 0; }
 		else {
 			b.P16 = 16 * (keys[i].key - SSW_RMAX);
-			b.strips = (b.P16 + 16 * SSW_RMAX - 1) / (16 * SSW_RMAX);
-			b.R = (b.P16 + 16 * b.strips - 1) / (16 * b.strips);        /* balanced strips, R <= SSW_RMAX */
+			b.lanes = xlanes; b.use_x = 1;
+			const int32_t rows = b.lanes * (b.lanes == 64 ? xrmax : SSW_RMAX);
+			b.strips = (b.P16 + rows - 1) / rows;
+			b.R = (b.P16 + b.lanes * b.strips - 1) / (b.lanes * b.strips);        /* balanced strips */
 		}
 		b.first_q = i; b.nq = j - i; b.first_pair = npairs_total;
 		for (int32_t k = i; k < j; ++k) order[k] = keys[k].q;
@@ -463,11 +473,11 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 
 	{   /* database search: scores only, several short targets -> fused kernel for the short-query buckets */
 		int any_short = 0, any_long = 0; int64_t maxt = 0;
-		for (int b = 0; b < nb; ++b) { if (bk[b].strips > 1 && bk[b].P16 > 640) any_long = 1; else any_short = 1; }
+		for (int b = 0; b < nb; ++b) { if (bk[b].use_x && bk[b].P16 > 640) any_long = 1; else any_short = 1; }
 		for (int32_t ti = 0; ti < tcount; ++ti) { int64_t L = T->h_off[tfirst + ti + 1] - T->h_off[tfirst + ti]; if (L > maxt) maxt = L; }
 		const char* dis = getenv("SSW_GPU_NO_DB");
 		if (!literal && prm->flag == 0 && tcount >= 4 && any_short && maxt <= 65536 && !(dis && dis[0] == '1')) {
-			for (int b = 0; b < nb; ++b) if (bk[b].strips == 1 || bk[b].P16 <= 640) for (int32_t k = 0; k < bk[b].nq; ++k) qdone[order[bk[b].first_q + k]] = 1;
+			for (int b = 0; b < nb; ++b) if (!bk[b].use_x || bk[b].P16 <= 640) for (int32_t k = 0; k < bk[b].nq; ++k) qdone[order[bk[b].first_q + k]] = 1;
 			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone)) goto done;
 			d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq);   /* align_db may have regrown the record buffer */
 			if (!d_res) goto done;
@@ -523,7 +533,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 				const bucket* B = &bk[b];
 				if (qdone[order[B->first_q]]) continue;     /* bucket already answered by the database-search path */
 				const int32_t P = B->P16, halo_full = halo_for(P, maxmat, prm->gapE);
-				const int use_x = B->strips > 1;     /* long queries: strip kernel, one job per chain */
+				const int use_x = B->use_x;     /* long queries: strip kernel, one job per chain */
 				const int gran = use_x ? 1 : 16;     /* k_fill: one workgroup = 16 tiles of one pair */
 				int32_t tile, halo, ntiles;
 				if ((int64_t)halo_full * 8 * gran >= refLen) { ntiles = 1; tile = (refLen + 15) / 16 * 16; halo = 0; }
@@ -581,7 +591,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 						xa.tgt = d_tgt; xa.refLen = refLen; xa.qcodes = Q->d_codes; xa.qoff = Q->d_off; xa.mat = d_mat; xa.n = n;
 						xa.gapO2 = gapO2; xa.gapE2 = gapE2; xa.gapE = prm->gapE; xa.maxmat = maxmat; xa.njobs = np * ntiles;
 						xa.pairs = fa.pairs; xa.tile = tile; xa.halo = halo; xa.ntiles = ntiles; xa.cm16 = d_cm16; xa.cm8 = d_cm8;
-						xa.cm_stride = stride; xa.bnd = d_bnd; xa.bnd_stride = maxcols; xa.cand = d_cand;
+						xa.cm_stride = stride; xa.bnd = d_bnd; xa.bnd_stride = maxcols; xa.cand = d_cand; xa.lanes = B->lanes;
 						if (ssw_shim_launch_chainx(B->R, 0, &xa, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
 					} else
 					if (ssw_shim_launch_fill(B->R, &fa, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
@@ -594,7 +604,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 							int64_t cf = lo - halo > 0 ? lo - halo : 0;
 							cols += hi - cf;
 						}
-						c->tm.fill_cells += cols * (int64_t)(16 * B->R * B->strips) * 2 * np;
+						c->tm.fill_cells += cols * (int64_t)(B->lanes * B->R * B->strips) * 2 * np;
 					}
 					ssw_reduce_args ra;
 					ra.cm16 = d_cm16; ra.cm8 = d_cm8; ra.cm_stride = stride; ra.refLen = refLen; ra.pairs = fa.pairs; ra.npairs = np;
@@ -621,7 +631,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 				for (int b = 0; b < nb; ++b) {
 					const bucket* B = &bk[b];
 					if (qdone[order[B->first_q]]) continue;
-					if (B->strips > 1) {
+					if (B->use_x) {
 						const int32_t hw = halo_for(B->P16, maxmat, prm->gapE);
 						const int64_t wcols = (((int64_t)(hw < refLen ? hw : refLen) + 1) + 31) / 16 * 16;
 						int64_t per = (int64_t)(c->cm_budget / (size_t)(16 * wcols)); if (per < 1) per = 1;
@@ -633,7 +643,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 							xa.tgt = d_tgt; xa.refLen = refLen; xa.qcodes = Q->d_codes; xa.qoff = Q->d_off; xa.mat = d_mat; xa.n = n;
 							xa.gapO2 = gapO2; xa.gapE2 = gapE2; xa.gapE = prm->gapE; xa.maxmat = maxmat; xa.njobs = cnt_q;
 							xa.qlist = d_qlist + B->first_q + q0; xa.reverse = pass; xa.flag = prm->flag; xa.filters = prm->filters;
-							xa.filterd = prm->filterd; xa.res = d_res; xa.bnd = d_bnd; xa.bnd_stride = wcols;
+							xa.filterd = prm->filterd; xa.res = d_res; xa.bnd = d_bnd; xa.bnd_stride = wcols; xa.lanes = B->lanes;
 							/* reverse pass: a window of rows + 25 % almost always contains the whole alignment; the exact
 							   halo bound (3x the rows for DNA defaults) is only paid by the alignments that miss */
 							int32_t* d_retry = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * (size_t)nq);
@@ -833,14 +843,14 @@ done:
 	return rc;
 }
 
-int ssw_gpu_selftest_lanes(ssw_gpu_ctx* c, uint32_t* out576)
+int ssw_gpu_selftest_lanes(ssw_gpu_ctx* c, uint32_t* out640)
 {
-	if (!c || !out576) return -1;
+	if (!c || !out640) return -1;
 	ssw_shim_set_device(c->device);
-	uint32_t* d = (uint32_t*)ssw_shim_malloc(576 * 4);
+	uint32_t* d = (uint32_t*)ssw_shim_malloc(640 * 4);
 	if (!d) return fail(c, "device allocation failed: %s", ssw_shim_last_error());
 	ssw_selftest_args a; a.lanes_out = d; a.sink = 0; a.iters = 0; a.seed = 0;
-	int rc = ssw_shim_launch_selftest(&a, 1, c->stream) || ssw_shim_d2h(out576, d, 576 * 4, c->stream) || ssw_shim_stream_sync(c->stream);
+	int rc = ssw_shim_launch_selftest(&a, 1, c->stream) || ssw_shim_d2h(out640, d, 640 * 4, c->stream) || ssw_shim_stream_sync(c->stream);
 	ssw_shim_free(d);
 	return rc ? fail(c, "selftest failed: %s", ssw_shim_last_error()) : 0;
 }

@@ -690,22 +690,31 @@ __global__ void __launch_bounds__(64) k_capture(ssw_capture_args a)
 }
 
 /* ================================================================================================
- * k_chainx: generic chain kernel -- any query length (row strips), one profile per chain, 4 chains per 64-thread
- * workgroup.  CAPTURE = false: forward fill of (pair, tile) jobs, column maxima to cm16/cm8.
+ * k_chainx: generic chain kernel -- any query length (row strips), one profile per chain.  A chain is GL lanes:
+ * GL = 16: one DPP row, 4 chains (jobs) per 64-thread workgroup; GL = 64: the whole wavefront is ONE chain
+ * (hand-off with wave_shr:1), strips of 64*R rows -- 4x the waves for the same number of jobs and a quarter of the
+ * LDS per wave, which is what long-read batches (few, long queries) need to fill the device.  CAPTURE = false: forward fill of (pair, tile) jobs, column maxima to cm16/cm8.
  * CAPTURE = true: locate / reverse window of one query, best cell to the result record (same contract as k_capture).
  * ================================================================================================ */
 #define BND_RING_BYTES (64 * 16)
-#define CHAINX_BYTES (RING_BYTES + 2 * BND_RING_BYTES + 16 * 12)
+template <int R, int GL> struct StripGeom {
+	static constexpr int C = (R + 3) / 4;
+	static constexpr u32 CSTRIDE = (u32)GL * 16u;              /* one 16-byte chunk of every lane */
+	static constexpr u32 PSTRIDE = (u32)C * CSTRIDE;           /* one residue */
+	static constexpr int RB = GL == 64 ? 128 : 64;             /* target ring entries (> GL + 30), + 16 mirrored */
+	static constexpr u32 RINGB = (u32)(RB + 16) * 2u;
+	static constexpr u32 EXTRA = RINGB + 2 * BND_RING_BYTES + (u32)GL * 12u;
+};
 
-template <int R>
+template <int R, int GL>
 SSW_DEV void build_profile_strip(unsigned char* lds, u32 base, int first, int nthreads, const int8_t* mat, int n,
                                  const int8_t* qa, int lena, int reva, const int8_t* qb, int lenb, int row0, int rows_total)
 {
-	constexpr int C = ChainGeom<R>::C;
-	const int total = (n + 1) * C * 64;
+	constexpr int C = StripGeom<R, GL>::C;
+	const int total = (n + 1) * C * GL * 4;
 	for (int w = first; w < total; w += nthreads) {
-		const int b = w / (C * 64), rem = w - b * (C * 64);
-		const int c = rem >> 6, l = (rem & 63) >> 2, k = rem & 3;
+		const int b = w / (C * GL * 4), rem = w - b * (C * GL * 4);
+		const int c = rem / (GL * 4), l = (rem & (GL * 4 - 1)) >> 2, k = rem & 3;
 		const int r = c * 4 + k, row = row0 + l * R + r;
 		u32 v;
 		if (r >= R) v = 0;
@@ -739,31 +748,30 @@ struct StripCtx {
 	int n;
 };
 
-template <int R, bool CAPTURE, bool MASK8>
+template <int R, bool CAPTURE, bool MASK8, int GL>
 SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st, const u32 (&m8)[R])
 {
-	typedef ChainGeom<R> G;
-	constexpr int C = G::C;
-	const int l16 = x.l16;
-	/* rings: target columns -16..-1 null, 0..15 now, 16..31 in flight; boundary-in likewise */
-	lds_st16(lds, x.ring + 2u * (48 + l16), x.nulloff);
-	{
+	typedef StripGeom<R, GL> G;
+	constexpr int C = G::C, RB = G::RB;
+	const int l16 = x.l16;             /* lane within the chain (0..GL-1) */
+	const bool stg = l16 < 16;         /* the 16 lanes that stage the rings and flush the boundary records */
+	/* rings: target columns -GL..-1 null, 0..15 now, 16..31 in flight; boundary-in likewise */
+	lds_st16(lds, x.ring + 2u * (RB - GL + l16), x.nulloff);
+	u32 nxt = 0;
+	if (stg) {
 		int code = l16 < x.ncols ? x.tg[x.c_edge + x.dirstep * l16] : x.n;
 		if (code < 0 || code > x.n) code = x.n;
 		const u32 off = (u32)code * G::PSTRIDE;
 		lds_st16(lds, x.ring + 2u * l16, off);
-		lds_st16(lds, x.ring + 2u * (64 + l16), off);
-	}
-	u32 nxt;
-	{
+		lds_st16(lds, x.ring + 2u * (RB + l16), off);
 		const int tc = 16 + l16;
-		int code = tc < x.ncols ? x.tg[x.c_edge + x.dirstep * tc] : x.n;
+		code = tc < x.ncols ? x.tg[x.c_edge + x.dirstep * tc] : x.n;
 		if (code < 0 || code > x.n) code = x.n;
 		nxt = (u32)code * G::PSTRIDE;
 	}
 	const u32x4 zero4 = { 0u, 0u, 0u, 0u };
-	const bool take = !x.first && x.mine;
-	{
+	const bool take = !x.first && x.mine && stg;
+	if (stg) {
 		u32x4 rec = zero4;
 		if (take && l16 < x.ncols) rec = *(const u32x4*)(x.bnd + 4 * (int64_t)l16);
 		lds_st128(lds, x.bin + 16u * l16, rec);
@@ -779,11 +787,11 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	wave_lds_fence();
 
 	for (int s0 = 0; s0 < x.nsteps; s0 += 16) {
-		{   /* stage [s0+16, s0+32), prefetch [s0+32, s0+48) */
-			const int p = (s0 + 16 + l16) & 63;
+		if (stg) {   /* stage [s0+16, s0+32), prefetch [s0+32, s0+48) */
+			const int p = (s0 + 16 + l16) & (RB - 1);
 			lds_st16(lds, x.ring + 2u * p, nxt);
-			if (p < 16) lds_st16(lds, x.ring + 2u * (64 + p), nxt);
-			lds_st128(lds, x.bin + 16u * p, nb);
+			if (p < 16) lds_st16(lds, x.ring + 2u * (RB + p), nxt);
+			lds_st128(lds, x.bin + 16u * (p & 63), nb);
 			const int tc = s0 + 32 + l16;
 			int code = tc < x.ncols ? x.tg[x.c_edge + x.dirstep * tc] : x.n;
 			if (code < 0 || code > x.n) code = x.n;
@@ -792,8 +800,8 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			if (take && tc < x.ncols) nb = *(const u32x4*)(x.bnd + 4 * (int64_t)tc);
 		}
 		wave_lds_fence();
-		if (s0 >= 32) {   /* boundary-out records of columns [s0-32, s0-16) are complete */
-			const int tc = s0 - 32 + l16;
+		if (s0 >= GL + 16 && stg) {   /* boundary-out records of columns [s0-GL-16, s0-GL) are complete */
+			const int tc = s0 - GL - 16 + l16;
 			if (x.mine && tc < x.ncols) {
 				const u32x4 rec = lds_ld128(lds, x.bout + 16u * (tc & 63));
 				if (!x.last) *(u32x4*)(x.bnd + 4 * (int64_t)tc) = rec;
@@ -801,19 +809,19 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			}
 		}
 		wave_lds_fence();
-		const u32 rp = x.ring + 2u * (u32)((s0 - l16) & 63);
+		const u32 rp = x.ring + 2u * (u32)((s0 - l16) & (RB - 1));
 #pragma unroll 2
 		for (int j = 0; j < 16; ++j) {
 			const int s = s0 + j, tc = s - l16;
 			const u32 paddr = lds_ld16(lds, rp + 2u * j) + lane_prof;
 			u32x4 sc[C];
 #pragma unroll
-			for (int c = 0; c < C; ++c) sc[c] = lds_ld128(lds, paddr + 256u * c);
+			for (int c = 0; c < C; ++c) sc[c] = lds_ld128(lds, paddr + G::CSTRIDE * c);
 			const u32x4 rec = lds_ld128(lds, x.bin + 16u * (s & 63));       /* what lane 0 receives from the strip above */
-			const u32 hin = xl_row_shr1_keep(rec[0], st.Hlast);
-			u32 f = xl_row_shr1_keep(rec[1], st.Fout);
-			u32 cm = xl_row_shr1_keep(rec[2], st.cmout);
-			u32 cm8 = MASK8 ? xl_row_shr1_keep(rec[3], st.cm8out) : 0u;
+			const u32 hin = xl_chain_shr1_keep<GL>(rec[0], st.Hlast);
+			u32 f = xl_chain_shr1_keep<GL>(rec[1], st.Fout);
+			u32 cm = xl_chain_shr1_keep<GL>(rec[2], st.cmout);
+			u32 cm8 = MASK8 ? xl_chain_shr1_keep<GL>(rec[3], st.cm8out) : 0u;
 			u32 d = st.hsave;
 			u32 lm = 0;   /* capture: this lane's own maximum in this column */
 #pragma unroll
@@ -846,9 +854,9 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 					sbest = nb;
 				}
 			}
-			if (l16 == 15) {
+			if (l16 == GL - 1) {
 				const u32x4 o = { st.Hlast, st.Fout, st.cmout, st.cm8out };
-				lds_st128(lds, x.bout + 16u * ((s - 15) & 63), o);
+				lds_st128(lds, x.bout + 16u * ((s - (GL - 1)) & 63), o);
 			}
 			if (CAPTURE) {
 				const int m = (int)(lm & 0xffffu);
@@ -861,9 +869,9 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 		}
 	}
 	wave_lds_fence();
-	for (int base = x.nsteps - 32; base < x.nsteps; base += 16) {
+	for (int base = x.nsteps - GL - 16; base < x.nsteps - GL + 16; base += 16) {
 		const int tc = base + l16;
-		if (x.mine && tc >= 0 && tc < x.ncols) {
+		if (stg && x.mine && tc >= 0 && tc < x.ncols) {
 			const u32x4 rec = lds_ld128(lds, x.bout + 16u * (tc & 63));
 			if (!x.last) *(u32x4*)(x.bnd + 4 * (int64_t)tc) = rec;
 			else if (!CAPTURE && tc >= x.store_from) { x.o16[tc] = rec[2]; x.o8[tc] = rec[3]; }
@@ -881,19 +889,19 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	dev_fence();   /* the next strip of this chain re-reads the boundary records through HBM */
 }
 
-template <int R, bool CAPTURE>
+template <int R, bool CAPTURE, int GL>
 __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 {
-	typedef ChainGeom<R> G;
+	typedef StripGeom<R, GL> G;
 	SSW_DYN_LDS(lds);
-	const int tid = (int)threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+	const int tid = (int)threadIdx.x, l16 = tid & (GL - 1), grp = tid / GL;
 	const u32 prof_bytes = (u32)(a.n + 1) * G::PSTRIDE;
 	StripCtx x;
-	x.prof = (u32)grp * (prof_bytes + CHAINX_BYTES); x.ring = x.prof + prof_bytes; x.bin = x.ring + RING_BYTES;
+	x.prof = (u32)grp * (prof_bytes + G::EXTRA); x.ring = x.prof + prof_bytes; x.bin = x.ring + G::RINGB;
 	x.bout = x.bin + BND_RING_BYTES; x.nulloff = (u32)a.n * G::PSTRIDE;
 	const u32 red = x.bout + BND_RING_BYTES;
 	x.l16 = l16; x.gapO2 = a.gapO2; x.gapE2 = a.gapE2; x.n = a.n; x.tg = a.tgt;
-	const int job = (int)blockIdx.x * 4 + grp;
+	const int job = (int)blockIdx.x * (64 / GL) + grp;
 	const bool valid = job < a.njobs;
 
 	const int8_t *qa = a.qcodes, *qb = 0;
@@ -935,14 +943,14 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 			x.dirstep = a.reverse ? -1 : 1;
 		}
 	}
-	const int S = active ? (rows_total + 16 * R - 1) / (16 * R) : 0;
+	const int S = active ? (rows_total + GL * R - 1) / (GL * R) : 0;
 	int maxS = S, mc = x.ncols;
 #pragma unroll
-	for (int sh = 16; sh < 64; sh <<= 1) {
+	for (int sh = GL; sh < 64; sh <<= 1) {
 		const int o1 = (int)xl_shfl((u32)maxS, (tid + sh) & 63), o2 = (int)xl_shfl((u32)mc, (tid + sh) & 63);
 		maxS = o1 > maxS ? o1 : maxS; mc = o2 > mc ? o2 : mc;
 	}
-	x.nsteps = (mc + 16 + 15) & ~15;
+	x.nsteps = (mc + GL + 15) & ~15;
 	x.bnd = a.bnd + (int64_t)(valid ? job : 0) * a.bnd_stride * 4;
 
 	ChainState<R> st;
@@ -950,8 +958,8 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 	st.tv[0] = st.tv[1] = 0; st.ttc[0] = st.ttc[1] = 0x7fffffff; st.trow[0] = st.trow[1] = 0x7fffffff;
 	u32 m8[R];
 	for (int sidx = 0; sidx < maxS; ++sidx) {
-		x.mine = sidx < S; x.first = sidx == 0; x.last = sidx == S - 1; x.row0 = sidx * 16 * R;
-		build_profile_strip<R>(lds, x.prof, l16, 16, a.mat, a.n, qa, lena, rev, qb, lenb, x.row0, x.mine ? rows_total : 0);
+		x.mine = sidx < S; x.first = sidx == 0; x.last = sidx == S - 1; x.row0 = sidx * GL * R;
+		build_profile_strip<R, GL>(lds, x.prof, l16, GL, a.mat, a.n, qa, lena, rev, qb, lenb, x.row0, x.mine ? rows_total : 0);
 		bool need_mask = false;
 		if (!CAPTURE) {
 			need_mask = x.mine && x.last && (p8a < rows_total || p8b < rows_total);
@@ -964,8 +972,8 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 #pragma unroll
 			for (int k = 0; k < R; ++k) m8[k] = 0;
 		}
-		if (!CAPTURE && wave_any(need_mask)) run_strip<R, CAPTURE, true>(lds, x, st, m8);
-		else run_strip<R, CAPTURE, false>(lds, x, st, m8);
+		if (!CAPTURE && wave_any(need_mask)) run_strip<R, CAPTURE, true, GL>(lds, x, st, m8);
+		else run_strip<R, CAPTURE, false, GL>(lds, x, st, m8);
 	}
 
 	if (!CAPTURE && a.cand) {   /* best cell of this (pair, tile) job per query, for k_reduce (saves the locate pass) */
@@ -976,7 +984,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 			wave_lds_fence();
 			if (l16 == 0 && valid) {
 				int bv = 0, bc = 0x7fffffff, br = 0x7fffffff;
-				for (int k = 0; k < 16; ++k) {
+				for (int k = 0; k < GL; ++k) {
 					const int v = (int)lds_ld32(lds, red + 12u * k), c = (int)lds_ld32(lds, red + 12u * k + 4), w = (int)lds_ld32(lds, red + 12u * k + 8);
 					if (v > bv || (v == bv && v > 0 && (c < bc || (c == bc && w < br)))) { bv = v; bc = c; br = w; }
 				}
@@ -993,7 +1001,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 		wave_lds_fence();
 		if (l16 == 0 && active) {
 			int bv = 0, bc = 0x7fffffff, br = 0;
-			for (int k = 0; k < 16; ++k) {
+			for (int k = 0; k < GL; ++k) {
 				const int v = (int)lds_ld32(lds, red + 12u * k), c = (int)lds_ld32(lds, red + 12u * k + 4), w = (int)lds_ld32(lds, red + 12u * k + 8);
 				if (v > bv || (v == bv && v > 0 && (c < bc || (c == bc && w < br)))) { bv = v; bc = c; br = w; }
 			}
@@ -1595,6 +1603,7 @@ __global__ void __launch_bounds__(256) k_selftest(ssw_selftest_args a)
 		a.lanes_out[6 * 64 + tid] = pk_adds(pk_make(30000, -30000), pk_make((int)tid * 100, -(int)tid * 100));
 		a.lanes_out[7 * 64 + tid] = pk_subu(pk_make((int)tid, 5), pk_make(10, (int)tid));
 		a.lanes_out[8 * 64 + tid] = pk_max(pk_make((int)tid - 32, 3), pk_make(0, (int)tid - 60));
+		a.lanes_out[9 * 64 + tid] = xl_wave_shr1_keep(7000u + tid, v);
 	}
 	if (a.iters > 0) {
 		u32 x0 = gid, x1 = gid * 3u, x2 = gid * 5u, x3 = gid * 7u, x4 = gid * 11u, x5 = gid * 13u, x6 = gid * 17u, x7 = gid * 19u;
@@ -1725,11 +1734,23 @@ extern "C" int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args*
 {
 	ssw_chainx_args args = *a;
 	if (args.njobs <= 0) return 0;
+	if (args.lanes == 64) {   /* the whole wavefront is one chain: one job per workgroup */
+		const int grid = args.njobs;
+		switch (R) {
+#define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * StripGeom<r, 64>::PSTRIDE + StripGeom<r, 64>::EXTRA; \
+		if (capture) SSW_LAUNCH((k_chainx<r, true, 64>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
+		else SSW_LAUNCH((k_chainx<r, false, 64>), ssw_chainx_args, args, grid, 64, ldsb, stream); } break;
+			X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#undef X
+			default: return -2;
+		}
+		return SSW_LAUNCH_OK();
+	}
 	const int grid = (args.njobs + 3) / 4;
 	switch (R) {
-#define X(r) case r: { const size_t ldsb = 4 * ((size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + CHAINX_BYTES); \
-		if (capture) SSW_LAUNCH((k_chainx<r, true>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
-		else SSW_LAUNCH((k_chainx<r, false>), ssw_chainx_args, args, grid, 64, ldsb, stream); } break;
+#define X(r) case r: { const size_t ldsb = 4 * ((size_t)(args.n + 1) * StripGeom<r, 16>::PSTRIDE + StripGeom<r, 16>::EXTRA); \
+		if (capture) SSW_LAUNCH((k_chainx<r, true, 16>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
+		else SSW_LAUNCH((k_chainx<r, false, 16>), ssw_chainx_args, args, grid, 64, ldsb, stream); } break;
 		FOR_EACH_R(X)
 #undef X
 		default: return -2;

@@ -98,6 +98,11 @@ SSW_DEV u32 xl_row_shr1_keep(u32 keep, u32 v)
 	int l = emu::cur->lane;
 	return emu::exchange(v, l - 1, (l & 15) != 0, keep);
 }
+SSW_DEV u32 xl_wave_shr1_keep(u32 keep, u32 v)
+{
+	int l = emu::cur->lane;
+	return emu::exchange(v, l - 1, l != 0, keep);
+}
 template <int N> SSW_DEV u32 xl_row_ror(u32 v)
 {
 	int l = emu::cur->lane;

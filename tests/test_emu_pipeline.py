@@ -91,6 +91,21 @@ def test_long_queries_row_strips(ectx):
     _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
 
 
+@pytest.mark.parametrize("env", [{"SSW_GPU_XR": "1"}, {"SSW_GPU_XR": "3"}, {"SSW_GPU_XLANES": "16"}])
+def test_long_queries_strip_geometries(ectx, env, monkeypatch):
+    """the strip kernel in its other shapes: many thin 64-lane strips (64 / 192 rows) and the 16-lane chains"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(81)
+    ref = random_ref(1200, 19, 4, 0.005)
+    reads = make_reads(rng, ref, 6, [385, 449, 640, 641, 500, 530], 4, sub=0.03, ins=0.01, dele=0.01, frac_random=0.2)
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
+    _run(ectx, reads[:3], [ref], dna_matrix(2, 2), 5, flag=0, maskLen=15)
+    pr = np.random.default_rng(5).integers(0, 20, size=700, dtype=np.int8)
+    preads = make_reads(rng, pr, 3, [390, 420, 400], 20, sub=0.2, ins=0.02, dele=0.02)
+    _run(ectx, preads, [pr], blosum50(), 24, flag=1)
+
+
 def test_database_search_fused_kernel(ectx):
     """flag 0 against several short targets takes the fused k_filldb path (one launch per bucket and target chunk)"""
     rng = np.random.default_rng(9)

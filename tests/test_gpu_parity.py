@@ -185,6 +185,7 @@ def test_cross_lane_primitives_match_isa_semantics(gpu_ctx):
         src = (lane & ~15) | ((lane - nrot) & 15)
         assert (o[row] == 100 + src).all()                                  # row_ror:n reads lane (i-n) mod 16
     assert (o[5] == 100 + ((lane + 16) & 63)).all()
+    assert (o[9] == np.where(lane == 0, 7000, v - 1)).all()                 # wave_shr:1 crosses the DPP rows; lane 0 keeps `old`
     h = o[6:9].view(np.int16).reshape(3, 64, 2).astype(np.int64)
     assert (h[0, :, 0] == np.minimum(32767, 30000 + lane * 100)).all() and (h[0, :, 1] == np.maximum(-32768, -30000 - lane * 100)).all()
     assert (h[1, :, 0] == np.maximum(0, lane - 10)).all() and (h[1, :, 1] == np.maximum(0, 5 - lane)).all()
