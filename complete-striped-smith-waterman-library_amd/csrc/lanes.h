@@ -27,6 +27,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #else
 #include <hip/hip_runtime.h>
 #define SSW_DEV __device__ __forceinline__
+#define SSW_DEVM __device__ __forceinline__          /* member functions */
+#define SSW_HD __host__ __device__ inline             /* also called by the launchers */
 #define SSW_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 
 /* DPP controls (ISA encodings): row_shr:n = 0x110+n, row_ror:n = 0x120+n */
@@ -51,6 +53,8 @@ SSW_DEV u32 lds_ld32(const unsigned char* lds, u32 off) { return *(const u32*)(l
 SSW_DEV u32 lds_ld16(const unsigned char* lds, u32 off) { return *(const uint16_t*)(lds + off); }
 SSW_DEV void lds_st32(unsigned char* lds, u32 off, u32 v) { *(u32*)(lds + off) = v; }
 SSW_DEV void lds_st128(unsigned char* lds, u32 off, u32x4 v) { *(u32x4*)(lds + off) = v; }
+SSW_DEV int lds_ld8s(const unsigned char* lds, u32 off) { return *(const int8_t*)(lds + off); }
+SSW_DEV void lds_st8(unsigned char* lds, u32 off, u32 v) { *(lds + off) = (unsigned char)v; }
 /* orders this wavefront's own global-memory traffic (row arrays re-read by other lanes of the same wave) */
 SSW_DEV void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 SSW_DEV void dev_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); }

@@ -38,7 +38,7 @@ struct ssw_gpu_ctx {
 	void *ev_fill[2], *ev_red[2];
 	char err[512];
 	ssw_gpu_timing tm;
-	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, cigar2, need, goff, gpool, bnd, tlist, cand;
+	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, cigar2, need, goff, gpool, bnd, tlist, cand, tresume;
 	void** ev; int nev, capev;          /* event pairs around fill launches */
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
@@ -105,7 +105,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_set_device(c->device);
 	ssw_shim_stream_sync(c->stream);
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
-	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->cigar2); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand);
+	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->cigar2); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand); dbuf_free(&c->tresume);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
 	free(c->ev);
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
@@ -226,6 +226,13 @@ static void* next_event(ssw_gpu_ctx* c)
    wavefront is one chain, 16: four chains per wavefront) */
 typedef struct { int32_t R, strips, P16, lanes, use_x; int32_t first_pair, npairs; int32_t first_q, nq; } bucket;
 typedef struct { int32_t key, q; } keyed;
+typedef struct { int32_t key, need, q; } tpend;     /* traceback negotiation: key = band (wave kernel) or scratch need */
+static int tpend_cmp(const void* a, const void* b)
+{
+	const tpend* x = (const tpend*)a; const tpend* y = (const tpend*)b;
+	if (x->key != y->key) return x->key < y->key ? -1 : 1;
+	return x->q < y->q ? -1 : x->q > y->q;
+}
 static int keyed_cmp(const void* a, const void* b)
 {
 	const keyed* x = (const keyed*)a; const keyed* y = (const keyed*)b;
@@ -680,25 +687,30 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 			int64_t span = (int64_t)maxlen + (halo_max < refLen ? halo_max : refLen) + 8;
 			cig_stride = (span + 3) / 4 * 4;
 			d_cig = (uint32_t*)ensure(c, &c->cigar, (size_t)(4 * cig_stride * nq));
-			int32_t* d_need = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * (size_t)nq);
-			if (!d_cig || !d_need) goto done;
+			int32_t* d_need = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * 2 * (size_t)nq);
+			int32_t* d_resume = (int32_t*)ensure(c, &c->tresume, sizeof(int32_t) * 8 * (size_t)nq);
+			if (!d_cig || !d_need || !d_resume) goto done;
+			if (ssw_shim_memset(d_resume, 0, sizeof(int32_t) * 8 * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
 			int64_t sstride = ((int64_t)3 * (2 * 16 + 8) * 4 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;
 			/* long reads: one wavefront per alignment (wide bands, 10^4 rows); short reads: one thread per alignment */
 			const char* tw = getenv("SSW_GPU_TRACE_WAVE");
 			const int use_wave = tw ? tw[0] == '1' : maxlen > 1024;
+			const char* tl_ = getenv("SSW_GPU_TRACE_LDS");
+			const int trace_no_lds = tl_ && tl_[0] == '0';     /* experiment / test: band rows in HBM scratch instead of LDS */
 			/* round 0: every alignment with a small scratch (band <= 16).  Alignments whose band had to grow report what
 			   they needed; later rounds run them in classes of similar need (x4 per class) with 4x headroom. */
-			keyed* pend = (keyed*)malloc(sizeof(keyed) * (size_t)nq);     /* key = need in 4-KiB units, q = query */
+			tpend* pend = (tpend*)malloc(sizeof(tpend) * (size_t)nq);     /* key = band that did not fit, need in 4-KiB units, q = query */
 			int32_t* lst = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
+			int32_t* hband = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
 			int32_t npend = nq;
-			for (int32_t k = 0; k < nq; ++k) { pend[k].key = 0; pend[k].q = order[k]; }
+			for (int32_t k = 0; k < nq; ++k) { pend[k].key = 0; pend[k].need = 0; pend[k].q = order[k]; }
 			const int64_t full = (int64_t)maxlen + (halo_max < refLen ? halo_max : refLen);
 			const int64_t worst = (3 * (2 * full + 8) * 4 + (2 * full + 1) * (int64_t)maxlen * 3 + 64 + 15) / 16 * 16;
 			int trace_ok = 1;
 			for (int round = 0; round < 10 && npend > 0 && trace_ok; ++round) {
-				keyed* nextp = (keyed*)malloc(sizeof(keyed) * (size_t)npend);
+				tpend* nextp = (tpend*)malloc(sizeof(tpend) * (size_t)npend);
 				int32_t nnext = 0;
-				if (round > 0) qsort(pend, (size_t)npend, sizeof(keyed), keyed_cmp);
+				if (round > 0) qsort(pend, (size_t)npend, sizeof(tpend), tpend_cmp);
 				if (round == 0) {
 					int64_t per_launch = (int64_t)((size_t)32 << 30) / sstride; if (per_launch < 1) per_launch = 1;
 					for (int32_t q0 = 0; q0 < npend && trace_ok; q0 += (int32_t)per_launch) {
@@ -710,14 +722,16 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
 						ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = sstride; ta.soff = 0;
 						ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;     /* CIGAR slots are indexed by query */
+						ta.resume = d_resume; ta.lds_bytes = trace_no_lds ? 1024 : (int32_t)ssw_shim_trace_lds_need(16);
 						if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
 						    (use_wave ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
 						    ssw_shim_d2h(hneed, d_need, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
+						    (use_wave && ssw_shim_d2h(hband, d_need + cnt_l, sizeof(int32_t) * (size_t)cnt_l, c->stream)) ||
 						    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
 						for (int32_t k = 0; k < cnt_l; ++k)
 							if (hneed[k] != 0) {
 								if (hneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
-								nextp[nnext].key = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
+								nextp[nnext].key = use_wave ? hband[k] : hneed[k]; nextp[nnext].need = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
 							}
 						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round 0: %d alignments, scratch %lld B each, %d pending so far\n",
 						                                     cnt_l, (long long)sstride, nnext);
@@ -730,10 +744,18 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 					for (int32_t g0 = 0; g0 < npend && trace_ok; ) {
 						int32_t g1 = g0; int64_t total = 0;
 						hoff[0] = 0;
+						/* wavefront kernel: one LDS size per launch, enough for twice the band of the launch's widest request */
+						int64_t lds_l = 1024;
 						while (g1 < npend) {
-							int64_t cap_i = ((int64_t)pend[g1].key * 4096 * 2 + 65536 + 15) / 16 * 16;
+							int64_t cap_i = ((int64_t)pend[g1].need * 4096 * 2 + 65536 + 15) / 16 * 16;
 							if (cap_i > worst) cap_i = worst;
 							if (g1 > g0 && total + cap_i > budget) break;
+							if (use_wave) {
+								int64_t l = ssw_shim_trace_lds_need(pend[g1].key > (1 << 20) ? (1 << 20) : 2 * pend[g1].key), cls = 2048;
+								while (cls < l && cls < 65536) cls <<= 1;
+								if (g1 > g0 && cls != lds_l) break;     /* pending alignments are sorted by band: classes are contiguous */
+								lds_l = cls;
+							}
 							total += cap_i; hoff[g1 - g0 + 1] = total; ++g1;
 						}
 						const int32_t cnt_l = g1 - g0;
@@ -745,18 +767,20 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
 						ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = 0; ta.soff = d_soff;
 						ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;
+						ta.resume = d_resume; ta.lds_bytes = trace_no_lds ? 1024 : (int32_t)lds_l;
 						if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
 						    ssw_shim_h2d(d_soff, hoff, sizeof(int64_t) * ((size_t)cnt_l + 1), c->stream) ||
 						    (use_wave ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
 						    ssw_shim_d2h(hneed, d_need, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
+						    (use_wave && ssw_shim_d2h(hband, d_need + cnt_l, sizeof(int32_t) * (size_t)cnt_l, c->stream)) ||
 						    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
 						for (int32_t k = 0; k < cnt_l; ++k)
 							if (hneed[k] != 0) {
 								if (hneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
-								nextp[nnext].key = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
+								nextp[nnext].key = use_wave ? hband[k] : hneed[k]; nextp[nnext].need = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
 							}
-						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, %lld B of scratch in total, %d pending so far\n",
-						                                     round, cnt_l, (long long)total, nnext);
+						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, %lld B of scratch in total, LDS %lld B per wave, %d pending so far\n",
+						                                     round, cnt_l, (long long)total, (long long)lds_l, nnext);
 						g0 = g1;
 					}
 					free(hoff);
@@ -764,7 +788,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 				did_trace = 1;
 				free(pend); pend = nextp; npend = nnext;
 			}
-			free(pend); free(lst);
+			free(pend); free(lst); free(hband);
 			if (!trace_ok) goto done;
 			if (npend > 0) { fail(c, "internal error: traceback scratch negotiation did not converge%s", ""); goto done; }
 			if (did_trace && ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nq, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }

@@ -1336,92 +1336,148 @@ SSW_DEV int cigar_score(const u32* cig, int n_ops, const int8_t* ref, const int8
  * ------------------------------------------------------------------------------------------------ */
 SSW_DEV int wave_bcast(int v, int src) { return (int)xl_shfl((u32)v, src); }
 
-SSW_DEV int trace_wave(const int8_t* ref, const int8_t* read, int refLen, int readLen, int score, int gapO, int gapE,
-                       int band_width, const int8_t* mat, int n, unsigned char* scratch, int64_t cap,
-                       u32* cig, int cigcap, int64_t* need, int lane)
+/* LDS needed to keep the three band rows, a window of the target and the matrix of one alignment on chip */
+SSW_HD u32 trace_ring_size(int band_width) { u32 r = 256; while (r < (u32)(2 * band_width + 130)) r <<= 1; return r; }
+SSW_HD int64_t trace_lds_need(int band_width)
+{
+	const int64_t rowbytes = (((int64_t)(band_width * 2 + 3) + 1) * 4 + 15) & ~(int64_t)15;
+	return 1024 + 3 * rowbytes + (int64_t)trace_ring_size(band_width);
+}
+
+/* row storage of trace_wave: LDS offsets (L) or the scratch arrays in HBM */
+template <bool L> struct TraceRows {
+	unsigned char* lds; u32 ohb, oeb, ohc;
+	int *hb, *eb, *hc;
+	SSW_DEVM int ldhb(int k) const { return L ? (int)lds_ld32(lds, ohb + 4u * (u32)k) : hb[k]; }
+	SSW_DEVM int ldeb(int k) const { return L ? (int)lds_ld32(lds, oeb + 4u * (u32)k) : eb[k]; }
+	SSW_DEVM int ldhc(int k) const { return L ? (int)lds_ld32(lds, ohc + 4u * (u32)k) : hc[k]; }
+	SSW_DEVM void sthb(int k, int v) const { if (L) lds_st32(lds, ohb + 4u * (u32)k, (u32)v); else hb[k] = v; }
+	SSW_DEVM void steb(int k, int v) const { if (L) lds_st32(lds, oeb + 4u * (u32)k, (u32)v); else eb[k] = v; }
+	SSW_DEVM void sthc(int k, int v) const { if (L) lds_st32(lds, ohc + 4u * (u32)k, (u32)v); else hc[k] = v; }
+	SSW_DEVM void fence() const { if (L) wave_lds_fence(); else wg_fence(); }
+};
+
+struct TraceBest { int best, i, j; };
+
+/* one band width: fills the direction bytes, updates the running best cell (row-major, strict >) */
+template <bool L>
+SSW_DEV void trace_wave_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* read, int refLen, int readLen,
+                             int gapO, int gapE, int band_width, const int8_t* mat, int n, int8_t* dir, u32 omat, u32 oring,
+                             u32 ring_mask, TraceBest& tb, int lane)
 {
 	const int NEG = -1073741824;
-	const int len = refLen > readLen ? refLen : readLen;
 	const int m = gapO < gapE ? gapO : gapE;
-	int best = 0, best_i = 0, best_j = 0, width, width_d;
-	int *hb, *eb, *hc; int8_t* dir;
+	const int width = band_width * 2 + 3, width_d = band_width * 2 + 1;
+	unsigned char* lds = R.lds;
+	for (int j = 1 + lane; j < width - 1; j += 64) R.sthb(j, 0);
+	int staged = 0;
+	int lb = tb.best, li = 0, lj = 0;      /* this lane's first cell above everything it saw before */
+	R.fence();
+	int rd = read[0];
+	for (int i = 0; i < readLen; ++i) {
+		const int rdn = i + 1 < readLen ? read[i + 1] : 0;             /* next row's base: in flight during this row */
+		const int xi = i - band_width > 0 ? i - band_width : 0;
+		const int xp = i - 1 - band_width > 0 ? i - 1 - band_width : 0;
+		const int sft = xi - xp;                                   /* 0 or 1: how far the band slid against the previous row */
+		const int beg = xi;
+		const int end = i + band_width < refLen - 1 ? i + band_width : refLen - 1;
+		const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
+		const int ncell = end - beg + 1;
+		int8_t* line = dir + (int64_t)width_d * i * 3;
+		if (L && (i & 63) == 0) {   /* target window: everything the next 64 rows can touch */
+			int64_t hi = (int64_t)i + band_width + 65; if (hi > refLen) hi = refLen;
+			for (int j = staged + lane; j < (int)hi; j += 64) lds_st8(lds, oring + ((u32)j & ring_mask), (u32)(unsigned char)ref[j]);
+			if ((int)hi > staged) staged = (int)hi;
+		}
+		if (lane == 0) { R.sthb(0, 0); R.sthb(edge, 0); R.sthc(0, 0); R.steb(0, NEG); R.steb(edge, NEG); }
+		R.fence();
+		int carryF = NEG, carryA = 0, carryH = 0;                  /* F, A and h of the cell left of the chunk (h_c[0] = 0) */
+		for (int c0 = 1; c0 <= ncell; c0 += 64) {
+			const int u = c0 + lane;
+			const bool ok = u <= ncell;
+			const int j = beg + u - 1;
+			int e = NEG, dia = NEG; int8_t de = 2;
+			if (ok) {
+				const int up = u + sft;
+				const int open = i == 0 ? -gapO : R.ldhb(up) - gapO;
+				const int ext = i == 0 ? NEG : R.ldeb(up) - gapE;
+				e = open > ext ? open : ext; de = open > ext ? 3 : 2;
+				const int sc = L ? lds_ld8s(lds, omat + (u32)((int)lds_ld8s(lds, oring + ((u32)j & ring_mask)) * n + rd))
+				                 : (int)mat[(int)ref[j] * n + rd];
+				dia = R.ldhb(up - 1) + sc;
+			}
+			int A = e > dia ? e : dia; if (A < 0) A = 0;
+			const int Aleft = wave_bcast(A, (lane + 63) & 63);
+			const int cl = (lane == 0 ? carryA : Aleft) - gapO;
+			/* inclusive max-plus scan of c with decay m per cell */
+			int t = cl;
+#pragma unroll
+			for (int d = 1; d < 64; d <<= 1) {
+				const int o = wave_bcast(t, (lane - d) & 63);
+				if (lane >= d) { const int v = o - d * m; t = v > t ? v : t; }
+			}
+			const int fc = carryF - (lane + 1) * m;
+			const int F = fc > t ? fc : t;
+			const int e1 = e > 0 ? e : 0, f1 = F > 0 ? F : 0;
+			const int gap = e1 > f1 ? e1 : f1;
+			const int h = gap > dia ? gap : dia;
+			/* direction of F: needs h and F of the cell to the left */
+			const int hl0 = wave_bcast(h, (lane + 63) & 63), Fl0 = wave_bcast(F, (lane + 63) & 63);
+			const int hleft = lane == 0 ? carryH : hl0, Fleft = lane == 0 ? carryF : Fl0;
+			const int8_t df = (hleft - gapO) > (Fleft - gapE) ? 5 : 4;
+			if (ok) {
+				R.steb(u, e); R.sthc(u, h);
+				line[(u - 1) * 3 + 0] = de;
+				line[(u - 1) * 3 + 1] = df;
+				line[(u - 1) * 3 + 2] = gap <= dia ? (int8_t)1 : (e1 > f1 ? de : df);
+				if (h > lb) { lb = h; li = i; lj = j; }      /* rows and chunks come in row-major order: strict > keeps the first */
+			}
+			const int last = ncell - c0 < 63 ? ncell - c0 : 63;     /* lane holding the chunk's last valid cell */
+			carryF = wave_bcast(F, last); carryA = wave_bcast(A, last); carryH = wave_bcast(h, last);
+		}
+		R.fence();
+		for (int u = 1 + lane; u <= ncell; u += 64) R.sthb(u, R.ldhc(u));
+		R.fence();
+		rd = rdn;
+	}
+	/* the scalar walk's best cell: highest h above the carried best; among equals the first in row-major order */
+	if (lb <= tb.best) { lb = NEG; li = 0x7fffffff; lj = 0x7fffffff; }
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) {
+		const int oh = wave_bcast(lb, lane ^ d), oi = wave_bcast(li, lane ^ d), oj = wave_bcast(lj, lane ^ d);
+		if (oh > lb || (oh == lb && (oi < li || (oi == li && oj < lj)))) { lb = oh; li = oi; lj = oj; }
+	}
+	if (lb > tb.best) { tb.best = lb; tb.i = li; tb.j = lj; }
+}
+
+/* returns the number of CIGAR operations, -1 (traceback failed), or -2: *need holds the scratch bytes wanted and
+   *band_io / tb the state to resume from (the narrower bands need not be walked again: they are deterministic) */
+SSW_DEV int trace_wave(const int8_t* ref, const int8_t* read, int refLen, int readLen, int score, int gapO, int gapE,
+                       int* band_io, TraceBest& tb, const int8_t* mat, int n, unsigned char* scratch, int64_t cap,
+                       unsigned char* lds, int64_t lds_cap, u32* cig, int cigcap, int64_t* need, int lane)
+{
+	const int len = refLen > readLen ? refLen : readLen;
+	int band_width = *band_io, width_d;
+	int8_t* dir;
 	do {
-		width = band_width * 2 + 3; width_d = band_width * 2 + 1;
+		const int width = band_width * 2 + 3; width_d = band_width * 2 + 1;
 		const int64_t rowbytes = (((int64_t)width + 1) * 4 + 15) & ~(int64_t)15;
 		const int64_t want = 3 * rowbytes + (int64_t)width_d * readLen * 3 + 16;
-		if (want > cap) { *need = want; return -2; }
-		hb = (int*)scratch; eb = (int*)(scratch + rowbytes); hc = (int*)(scratch + 2 * rowbytes);
+		if (want > cap) { *need = want; *band_io = band_width; return -2; }
 		dir = (int8_t*)(scratch + 3 * rowbytes);
-		for (int j = 1 + lane; j < width - 1; j += 64) hb[j] = 0;
-		wg_fence();
-		for (int i = 0; i < readLen; ++i) {
-			const int xi = i - band_width > 0 ? i - band_width : 0;
-			const int xp = i - 1 - band_width > 0 ? i - 1 - band_width : 0;
-			const int sft = xi - xp;                                   /* 0 or 1: how far the band slid against the previous row */
-			const int beg = xi;
-			const int end = i + band_width < refLen - 1 ? i + band_width : refLen - 1;
-			const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
-			const int ncell = end - beg + 1;
-			int8_t* line = dir + (int64_t)width_d * i * 3;
-			if (lane == 0) { hb[0] = 0; hb[edge] = 0; hc[0] = 0; eb[0] = NEG; eb[edge] = NEG; }
-			wg_fence();
-			const int rd = read[i];
-			int carryF = NEG, carryA = 0, carryH = 0;                  /* F, A and h of the cell left of the chunk (h_c[0] = 0) */
-			for (int c0 = 1; c0 <= ncell; c0 += 64) {
-				const int u = c0 + lane;
-				const bool ok = u <= ncell;
-				const int j = beg + u - 1;
-				int e = NEG, dia = NEG; int8_t de = 2;
-				if (ok) {
-					const int up = u + sft;
-					const int open = i == 0 ? -gapO : hb[up] - gapO;
-					const int ext = i == 0 ? NEG : eb[up] - gapE;
-					e = open > ext ? open : ext; de = open > ext ? 3 : 2;
-					dia = hb[up - 1] + mat[(int)ref[j] * n + rd];
-				}
-				int A = e > dia ? e : dia; if (A < 0) A = 0;
-				const int Aleft = wave_bcast(A, (lane + 63) & 63);
-				const int cl = (lane == 0 ? carryA : Aleft) - gapO;
-				/* inclusive max-plus scan of c with decay m per cell */
-				int t = cl;
-#pragma unroll
-				for (int d = 1; d < 64; d <<= 1) {
-					const int o = wave_bcast(t, (lane - d) & 63);
-					if (lane >= d) { const int v = o - d * m; t = v > t ? v : t; }
-				}
-				const int fc = carryF - (lane + 1) * m;
-				const int F = fc > t ? fc : t;
-				const int e1 = e > 0 ? e : 0, f1 = F > 0 ? F : 0;
-				const int gap = e1 > f1 ? e1 : f1;
-				const int h = gap > dia ? gap : dia;
-				/* direction of F: needs h and F of the cell to the left */
-				const int hl0 = wave_bcast(h, (lane + 63) & 63), Fl0 = wave_bcast(F, (lane + 63) & 63);
-				const int hleft = lane == 0 ? carryH : hl0, Fleft = lane == 0 ? carryF : Fl0;
-				const int8_t df = (hleft - gapO) > (Fleft - gapE) ? 5 : 4;
-				if (ok) {
-					eb[u] = e; hc[u] = h;
-					line[(u - 1) * 3 + 0] = de;
-					line[(u - 1) * 3 + 1] = df;
-					line[(u - 1) * 3 + 2] = gap <= dia ? (int8_t)1 : (e1 > f1 ? de : df);
-				}
-				/* best cell of the chunk: highest h, then leftmost */
-				int bh = ok ? h : NEG, bl = lane;
-#pragma unroll
-				for (int d = 32; d > 0; d >>= 1) {
-					const int oh = wave_bcast(bh, lane ^ d), ol = wave_bcast(bl, lane ^ d);
-					if (oh > bh || (oh == bh && ol < bl)) { bh = oh; bl = ol; }
-				}
-				if (bh > best) { best = bh; best_i = i; best_j = beg + c0 + bl - 1; }
-				const int last = ncell - c0 < 63 ? ncell - c0 : 63;     /* lane holding the chunk's last valid cell */
-				carryF = wave_bcast(F, last); carryA = wave_bcast(A, last); carryH = wave_bcast(h, last);
-			}
-			wg_fence();
-			for (int u = 1 + lane; u <= ncell; u += 64) hb[u] = hc[u];
-			wg_fence();
+		if (trace_lds_need(band_width) <= lds_cap) {
+			TraceRows<true> R; R.lds = lds; R.ohb = 1024; R.oeb = 1024 + (u32)rowbytes; R.ohc = 1024 + 2 * (u32)rowbytes; R.hb = R.eb = R.hc = 0;
+			const u32 oring = 1024 + 3 * (u32)rowbytes;
+			trace_wave_band<true>(R, ref, read, refLen, readLen, gapO, gapE, band_width, mat, n, dir, 0, oring, trace_ring_size(band_width) - 1, tb, lane);
+		} else {
+			TraceRows<false> R; R.lds = lds; R.ohb = R.oeb = R.ohc = 0;
+			R.hb = (int*)scratch; R.eb = (int*)(scratch + rowbytes); R.hc = (int*)(scratch + 2 * rowbytes);
+			trace_wave_band<false>(R, ref, read, refLen, readLen, gapO, gapE, band_width, mat, n, dir, 0, 0, 0, tb, lane);
 		}
 		band_width *= 2;
-	} while (best < score && band_width <= len);
+	} while (tb.best < score && band_width <= len);
 	band_width /= 2;
+	const int best_i = tb.i, best_j = tb.j;
 
 	wg_fence();
 	int nops = 0;
@@ -1453,9 +1509,11 @@ SSW_DEV int trace_wave(const int8_t* ref, const int8_t* read, int refLen, int re
 	return wave_bcast(nops, 0);
 }
 
-/* one wavefront per alignment; same contract as k_trace */
+/* one wavefront per alignment; same contract as k_trace.  a.resume[q] = {band, best, best_i, best_j, stage} carries an
+   alignment that ran out of scratch to the next negotiation round. */
 __global__ void __launch_bounds__(64) k_trace_wave(ssw_trace_args a)
 {
+	SSW_DYN_LDS(lds);
 	const int job = (int)blockIdx.x, lane = (int)threadIdx.x;
 	const int q = a.qlist[job];
 	ssw_dres r = a.res[q];
@@ -1465,25 +1523,42 @@ __global__ void __launch_bounds__(64) k_trace_wave(ssw_trace_args a)
 	const int8_t* read = a.qcodes + a.qoff[q] + r.read_begin1;
 	const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
 	const int d = refLen - readLen;
-	int band = (d < 0 ? -d : d) + 1;
+	const int band0 = (d < 0 ? -d : d) + 1;
+	int band = band0;
 	const int full = refLen > readLen ? refLen : readLen;
 	u32* cig = a.cigar + (int64_t)q * a.cigar_stride;
 	unsigned char* scratch = a.soff ? a.scratch + a.soff[job] : a.scratch + (int64_t)job * a.scratch_stride;
 	const int64_t scap = a.soff ? a.soff[job + 1] - a.soff[job] : a.scratch_stride;
+	for (int k = lane; k < a.n * a.n && k < 1024; k += 64) lds_st8(lds, (u32)k, (u32)(unsigned char)a.mat[k]);
+	wave_lds_fence();
+	const int64_t lds_cap = a.n * a.n <= 1024 ? (int64_t)a.lds_bytes : 0;
+	TraceBest tb; tb.best = 0; tb.i = 0; tb.j = 0;
+	int stage = 0;                         /* 1: the single full-band retry after a CIGAR that does not re-score (ssw.c:1000-1010) */
+	int32_t* rs = a.resume + (int64_t)q * 8;
+	if (rs[0] > 0) { band = rs[0]; tb.best = rs[1]; tb.i = rs[2]; tb.j = rs[3]; stage = rs[4]; }
 	int nops;
 	for (;;) {
 		int64_t need = 0;
-		nops = trace_wave(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, band, a.mat, a.n, scratch, scap,
-		                  cig, (int)a.cigar_stride, &need, lane);
+		int bio = band;
+		nops = trace_wave(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, &bio, tb, a.mat, a.n, scratch, scap,
+		                  lds, lds_cap, cig, (int)a.cigar_stride, &need, lane);
 		const int64_t need0 = ((int64_t)wave_bcast((int)(need >> 32), 0) << 32) | (u32)wave_bcast((int)(need & 0xffffffff), 0);
-		if (nops == -2) { if (lane == 0) a.need[job] = need0 > 0 ? (int)((need0 + 4095) >> 12) : -1; return; }
+		if (nops == -2) {
+			if (lane == 0) {
+				a.need[job] = need0 > 0 ? (int)((need0 + 4095) >> 12) : -1;
+				a.need[a.nq + job] = bio;
+				rs[0] = bio; rs[1] = tb.best; rs[2] = tb.i; rs[3] = tb.j; rs[4] = stage;
+			}
+			return;
+		}
 		if (nops < 0) break;
 		int sc = 0;
 		if (lane == 0) sc = cigar_score(cig, nops, ref, read, a.mat, a.n, a.gapO, a.gapE);
 		sc = wave_bcast(sc, 0);
 		if (sc == r.score1) break;
-		if (band >= full) { nops = -1; break; }
-		band = full;
+		if (stage || band0 >= full) { nops = -1; break; }
+		band = full; stage = 1;
+		tb.best = 0; tb.i = 0; tb.j = 0;
 	}
 	if (lane == 0) {
 		if (nops < 0) { a.res[q].flag = 1; a.res[q].cigarLen = 0; }
@@ -1774,11 +1849,14 @@ extern "C" int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream)
 	return SSW_LAUNCH_OK();
 }
 
+extern "C" int64_t ssw_shim_trace_lds_need(int band_width) { return trace_lds_need(band_width); }
+
 extern "C" int ssw_shim_launch_trace_wave(const ssw_trace_args* a, void* stream)
 {
 	ssw_trace_args args = *a;
 	if (args.nq <= 0) return 0;
-	SSW_LAUNCH(k_trace_wave, ssw_trace_args, args, args.nq, 64, 0, stream);
+	if (args.lds_bytes < 1024) args.lds_bytes = 1024;
+	SSW_LAUNCH(k_trace_wave, ssw_trace_args, args, args.nq, 64, (size_t)args.lds_bytes, stream);
 	return SSW_LAUNCH_OK();
 }
 

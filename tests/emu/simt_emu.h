@@ -29,6 +29,8 @@
 #define __launch_bounds__(...)
 #define __restrict__
 #define SSW_DEV static inline
+#define SSW_DEVM inline
+#define SSW_HD static inline
 
 namespace emu {
 
@@ -145,6 +147,8 @@ SSW_DEV u32 lds_ld32(const unsigned char* lds, u32 off) { emu_lds_check(off, 4, 
 SSW_DEV u32 lds_ld16(const unsigned char* lds, u32 off) { emu_lds_check(off, 2, 2, "ld16"); uint16_t v; memcpy(&v, lds + off, 2); return v; }
 SSW_DEV void lds_st32(unsigned char* lds, u32 off, u32 v) { emu_lds_check(off, 4, 4, "st32"); memcpy(lds + off, &v, 4); }
 SSW_DEV void lds_st128(unsigned char* lds, u32 off, u32x4 v) { emu_lds_check(off, 16, 16, "st128"); memcpy(lds + off, &v, 16); }
+SSW_DEV int lds_ld8s(const unsigned char* lds, u32 off) { emu_lds_check(off, 1, 1, "ld8"); return (int)(int8_t)lds[off]; }
+SSW_DEV void lds_st8(unsigned char* lds, u32 off, u32 v) { emu_lds_check(off, 1, 1, "st8"); lds[off] = (unsigned char)v; }
 SSW_DEV void dev_fence() { emu::wave_sync(); }
 SSW_DEV void wg_fence() { emu::wave_sync(); }
 SSW_DEV void lds_st16(unsigned char* lds, u32 off, u32 v) { emu_lds_check(off, 2, 2, "st16"); uint16_t h = (uint16_t)v; memcpy(lds + off, &h, 2); }
