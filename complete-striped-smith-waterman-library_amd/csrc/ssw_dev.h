@@ -209,7 +209,8 @@ typedef struct {
 	                            k_trace_wave also stores the band width that did not fit at need[nq + job] */
 	const int64_t* soff;     /* optional: job j owns scratch[soff[j] .. soff[j+1]) instead of a uniform stride */
 	int32_t* resume;         /* k_trace_wave: 8 ints per QUERY {band, best, best_i, best_j, stage}; zeroed before round 0 */
-	int32_t lds_bytes;       /* k_trace_wave: dynamic LDS per wavefront (>= 1024); bands that fit keep their rows on chip */
+	int32_t lds_bytes;       /* k_trace_wave: dynamic LDS per workgroup; bands that fit keep their rows on chip */
+	int32_t waves;           /* k_trace_wave: wavefronts working on one alignment (1, 4 or 16): wide bands need the lanes */
 } ssw_trace_args;
 
 /* device-side mark_mismatch: M -> '=' / 'X' runs, soft clips, edit distance */
@@ -281,7 +282,7 @@ int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args* a, void* s
 int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream);
 int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);
 int ssw_shim_launch_trace_wave(const ssw_trace_args* a, void* stream);
-int64_t ssw_shim_trace_lds_need(int band_width);   /* LDS that keeps a band of this width on chip */   /* one wavefront per alignment (long reads) */
+int64_t ssw_shim_trace_lds_need(int band_width, int waves);   /* LDS that keeps a band of this width on chip */   /* one wavefront per alignment (long reads) */
 int ssw_shim_launch_gather(const ssw_gather_args* a, void* stream);
 int ssw_shim_launch_mark(const ssw_mark_args* a, void* stream);
 int ssw_shim_launch_prep(const ssw_prep_args* a, void* stream);

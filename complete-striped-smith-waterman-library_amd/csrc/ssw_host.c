@@ -697,6 +697,8 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 			const int use_wave = tw ? tw[0] == '1' : maxlen > 1024;
 			const char* tl_ = getenv("SSW_GPU_TRACE_LDS");
 			const int trace_no_lds = tl_ && tl_[0] == '0';     /* experiment / test: band rows in HBM scratch instead of LDS */
+			const char* tv_ = getenv("SSW_GPU_TRACE_WAVES");
+			const int trace_waves_env = tv_ && (atoi(tv_) == 1 || atoi(tv_) == 4 || atoi(tv_) == 16) ? atoi(tv_) : 0;   /* experiment / test */
 			/* round 0: every alignment with a small scratch (band <= 16).  Alignments whose band had to grow report what
 			   they needed; later rounds run them in classes of similar need (x4 per class) with 4x headroom. */
 			tpend* pend = (tpend*)malloc(sizeof(tpend) * (size_t)nq);     /* key = band that did not fit, need in 4-KiB units, q = query */
@@ -722,7 +724,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
 						ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = sstride; ta.soff = 0;
 						ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;     /* CIGAR slots are indexed by query */
-						ta.resume = d_resume; ta.lds_bytes = trace_no_lds ? 1024 : (int32_t)ssw_shim_trace_lds_need(16);
+						ta.resume = d_resume; ta.waves = 1; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)ssw_shim_trace_lds_need(16, 1);
 						if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
 						    (use_wave ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
 						    ssw_shim_d2h(hneed, d_need, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
@@ -745,16 +747,20 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 						int32_t g1 = g0; int64_t total = 0;
 						hoff[0] = 0;
 						/* wavefront kernel: one LDS size per launch, enough for twice the band of the launch's widest request */
-						int64_t lds_l = 1024;
+						int64_t lds_l = 0; int waves_l = 1;
 						while (g1 < npend) {
 							int64_t cap_i = ((int64_t)pend[g1].need * 4096 * 2 + 65536 + 15) / 16 * 16;
 							if (cap_i > worst) cap_i = worst;
 							if (g1 > g0 && total + cap_i > budget) break;
 							if (use_wave) {
-								int64_t l = ssw_shim_trace_lds_need(pend[g1].key > (1 << 20) ? (1 << 20) : 2 * pend[g1].key), cls = 2048;
-								while (cls < l && cls < 65536) cls <<= 1;
-								if (g1 > g0 && cls != lds_l) break;     /* pending alignments are sorted by band: classes are contiguous */
-								lds_l = cls;
+								/* a band row of 2b+1 cells is walked in chunks of 64 cells per wavefront: wide bands get 4 or 16 wavefronts */
+								const int32_t b2 = pend[g1].key > (1 << 20) ? (1 << 21) : 2 * pend[g1].key;
+								int wv = b2 <= 96 ? 1 : b2 <= 768 ? 4 : 16;
+								if (trace_waves_env > 0) wv = trace_waves_env;
+								int64_t l = ssw_shim_trace_lds_need(b2, wv), cls = 2048;
+								while (cls < l && cls < 131072) cls <<= 1;
+								if (g1 > g0 && (cls != lds_l || wv != waves_l)) break;     /* pending alignments are sorted by band: classes are contiguous */
+								lds_l = cls; waves_l = wv;
 							}
 							total += cap_i; hoff[g1 - g0 + 1] = total; ++g1;
 						}
@@ -767,7 +773,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
 						ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = 0; ta.soff = d_soff;
 						ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;
-						ta.resume = d_resume; ta.lds_bytes = trace_no_lds ? 1024 : (int32_t)lds_l;
+						ta.resume = d_resume; ta.waves = waves_l; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)lds_l;
 						if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
 						    ssw_shim_h2d(d_soff, hoff, sizeof(int64_t) * ((size_t)cnt_l + 1), c->stream) ||
 						    (use_wave ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
@@ -779,8 +785,8 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 								if (hneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
 								nextp[nnext].key = use_wave ? hband[k] : hneed[k]; nextp[nnext].need = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
 							}
-						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, %lld B of scratch in total, LDS %lld B per wave, %d pending so far\n",
-						                                     round, cnt_l, (long long)total, (long long)lds_l, nnext);
+						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, %lld B of scratch in total, LDS %lld B x %d waves per alignment, %d pending so far\n",
+						                                     round, cnt_l, (long long)total, (long long)lds_l, waves_l, nnext);
 						g0 = g1;
 					}
 					free(hoff);

@@ -1336,15 +1336,16 @@ SSW_DEV int cigar_score(const u32* cig, int n_ops, const int8_t* ref, const int8
  * ------------------------------------------------------------------------------------------------ */
 SSW_DEV int wave_bcast(int v, int src) { return (int)xl_shfl((u32)v, src); }
 
-/* LDS needed to keep the three band rows, a window of the target and the matrix of one alignment on chip */
-SSW_HD u32 trace_ring_size(int band_width) { u32 r = 256; while (r < (u32)(2 * band_width + 130)) r <<= 1; return r; }
-SSW_HD int64_t trace_lds_need(int band_width)
+/* LDS of the wavefront / workgroup traceback: [matrix 1024][exchange 512][h_b][e_b][h_c][target window ring] */
+#define TRACE_LDS_FIXED 1536u
+SSW_HD u32 trace_ring_size(int band_width, int nthreads) { u32 r = 256; while (r < (u32)(2 * band_width + 2 * nthreads + 2)) r <<= 1; return r; }
+SSW_HD int64_t trace_lds_need(int band_width, int nthreads)
 {
 	const int64_t rowbytes = (((int64_t)(band_width * 2 + 3) + 1) * 4 + 15) & ~(int64_t)15;
-	return 1024 + 3 * rowbytes + (int64_t)trace_ring_size(band_width);
+	return TRACE_LDS_FIXED + 3 * rowbytes + (int64_t)trace_ring_size(band_width, nthreads);
 }
 
-/* row storage of trace_wave: LDS offsets (L) or the scratch arrays in HBM */
+/* row storage: LDS offsets (L) or the scratch arrays in HBM */
 template <bool L> struct TraceRows {
 	unsigned char* lds; u32 ohb, oeb, ohc;
 	int *hb, *eb, *hc;
@@ -1354,25 +1355,43 @@ template <bool L> struct TraceRows {
 	SSW_DEVM void sthb(int k, int v) const { if (L) lds_st32(lds, ohb + 4u * (u32)k, (u32)v); else hb[k] = v; }
 	SSW_DEVM void steb(int k, int v) const { if (L) lds_st32(lds, oeb + 4u * (u32)k, (u32)v); else eb[k] = v; }
 	SSW_DEVM void sthc(int k, int v) const { if (L) lds_st32(lds, ohc + 4u * (u32)k, (u32)v); else hc[k] = v; }
-	SSW_DEVM void fence() const { if (L) wave_lds_fence(); else wg_fence(); }
 };
+/* all threads of the alignment's team (NW wavefronts) see each other's LDS / scratch writes afterwards */
+template <bool L, int NW> SSW_DEV void trace_sync()
+{
+	if (NW > 1) { if (!L) wg_fence(); __syncthreads(); }
+	else if (L) wave_lds_fence();
+	else wg_fence();
+}
 
 struct TraceBest { int best, i, j; };
 
-/* one band width: fills the direction bytes, updates the running best cell (row-major, strict >) */
-template <bool L>
-SSW_DEV void trace_wave_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* read, int refLen, int readLen,
-                             int gapO, int gapE, int band_width, const int8_t* mat, int n, int8_t* dir, u32 omat, u32 oring,
-                             u32 ring_mask, TraceBest& tb, int lane)
+/* exchange area (LDS offset 1024): [0,64) wave totals, [64,128) last h, [128,192) last F, 192.. carries F A H, 208.. broadcast,
+   256.. per-wave best (3 ints each) */
+#define TX_T 1024u
+#define TX_H 1088u
+#define TX_F 1152u
+#define TX_CARRY 1216u
+#define TX_BCAST 1232u
+#define TX_BEST 1280u
+
+/* one band width: fills the direction bytes, updates the running best cell (row-major, strict >).  NW wavefronts
+   (64 * NW cells per chunk) work on one alignment; the horizontal dependency is a two-level max-plus scan. */
+template <bool L, int NW>
+SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* read, int refLen, int readLen,
+                        int gapO, int gapE, int band_width, const int8_t* mat, int n, int8_t* dir, u32 oring,
+                        u32 ring_mask, TraceBest& tb, int tid)
 {
+	constexpr int NT = 64 * NW;
 	const int NEG = -1073741824;
 	const int m = gapO < gapE ? gapO : gapE;
+	const int lane = tid & 63, wv = tid >> 6;
 	const int width = band_width * 2 + 3, width_d = band_width * 2 + 1;
 	unsigned char* lds = R.lds;
-	for (int j = 1 + lane; j < width - 1; j += 64) R.sthb(j, 0);
+	for (int j = 1 + tid; j < width - 1; j += NT) R.sthb(j, 0);
 	int staged = 0;
-	int lb = tb.best, li = 0, lj = 0;      /* this lane's first cell above everything it saw before */
-	R.fence();
+	int lb = tb.best, li = 0, lj = 0;      /* this thread's first cell above everything it saw before */
+	trace_sync<L, NW>();
 	int rd = read[0];
 	for (int i = 0; i < readLen; ++i) {
 		const int rdn = i + 1 < readLen ? read[i + 1] : 0;             /* next row's base: in flight during this row */
@@ -1386,14 +1405,14 @@ SSW_DEV void trace_wave_band(const TraceRows<L>& R, const int8_t* ref, const int
 		int8_t* line = dir + (int64_t)width_d * i * 3;
 		if (L && (i & 63) == 0) {   /* target window: everything the next 64 rows can touch */
 			int64_t hi = (int64_t)i + band_width + 65; if (hi > refLen) hi = refLen;
-			for (int j = staged + lane; j < (int)hi; j += 64) lds_st8(lds, oring + ((u32)j & ring_mask), (u32)(unsigned char)ref[j]);
+			for (int j = staged + tid; j < (int)hi; j += NT) lds_st8(lds, oring + ((u32)j & ring_mask), (u32)(unsigned char)ref[j]);
 			if ((int)hi > staged) staged = (int)hi;
 		}
-		if (lane == 0) { R.sthb(0, 0); R.sthb(edge, 0); R.sthc(0, 0); R.steb(0, NEG); R.steb(edge, NEG); }
-		R.fence();
+		if (tid == 0) { R.sthb(0, 0); R.sthb(edge, 0); R.sthc(0, 0); R.steb(0, NEG); R.steb(edge, NEG); }
+		trace_sync<L, NW>();
 		int carryF = NEG, carryA = 0, carryH = 0;                  /* F, A and h of the cell left of the chunk (h_c[0] = 0) */
-		for (int c0 = 1; c0 <= ncell; c0 += 64) {
-			const int u = c0 + lane;
+		for (int c0 = 1; c0 <= ncell; c0 += NT) {
+			const int u = c0 + tid;
 			const bool ok = u <= ncell;
 			const int j = beg + u - 1;
 			int e = NEG, dia = NEG; int8_t de = 2;
@@ -1402,28 +1421,53 @@ SSW_DEV void trace_wave_band(const TraceRows<L>& R, const int8_t* ref, const int
 				const int open = i == 0 ? -gapO : R.ldhb(up) - gapO;
 				const int ext = i == 0 ? NEG : R.ldeb(up) - gapE;
 				e = open > ext ? open : ext; de = open > ext ? 3 : 2;
-				const int sc = L ? lds_ld8s(lds, omat + (u32)((int)lds_ld8s(lds, oring + ((u32)j & ring_mask)) * n + rd))
+				const int sc = L ? lds_ld8s(lds, (u32)((int)lds_ld8s(lds, oring + ((u32)j & ring_mask)) * n + rd))
 				                 : (int)mat[(int)ref[j] * n + rd];
 				dia = R.ldhb(up - 1) + sc;
 			}
 			int A = e > dia ? e : dia; if (A < 0) A = 0;
-			const int Aleft = wave_bcast(A, (lane + 63) & 63);
-			const int cl = (lane == 0 ? carryA : Aleft) - gapO;
-			/* inclusive max-plus scan of c with decay m per cell */
-			int t = cl;
+			/* s[p] = max_{k <= p} (A[k] - (p - k) m): inclusive max-plus scan, first within the wavefront ... */
+			int s = A;
 #pragma unroll
 			for (int d = 1; d < 64; d <<= 1) {
-				const int o = wave_bcast(t, (lane - d) & 63);
-				if (lane >= d) { const int v = o - d * m; t = v > t ? v : t; }
+				const int o = wave_bcast(s, (lane - d) & 63);
+				if (lane >= d) { const int v = o - d * m; s = v > s ? v : s; }
 			}
-			const int fc = carryF - (lane + 1) * m;
-			const int F = fc > t ? fc : t;
+			int P = NEG;                                            /* ... then across the wavefronts to the left: s of the cell before lane 0 */
+			if (NW > 1) {
+				if (lane == 63) lds_st32(lds, TX_T + 4u * (u32)wv, (u32)s);
+				__syncthreads();
+				for (int v = 0; v < wv; ++v) {
+					const int t = (int)lds_ld32(lds, TX_T + 4u * (u32)v) - 64 * (wv - 1 - v) * m;
+					P = t > P ? t : P;
+				}
+				const int sp = P - (lane + 1) * m;
+				s = sp > s ? sp : s;
+			}
+			const int sl0 = wave_bcast(s, (lane + 63) & 63);
+			const int sleft = lane == 0 ? P : sl0;                  /* s[p-1]; nothing (NEG) left of the chunk's first cell */
+			int F = sleft - gapO;
+			{ const int ca = carryA - gapO - tid * m, cf = carryF - (tid + 1) * m; F = ca > F ? ca : F; F = cf > F ? cf : F; }
 			const int e1 = e > 0 ? e : 0, f1 = F > 0 ? F : 0;
 			const int gap = e1 > f1 ? e1 : f1;
 			const int h = gap > dia ? gap : dia;
-			/* direction of F: needs h and F of the cell to the left */
-			const int hl0 = wave_bcast(h, (lane + 63) & 63), Fl0 = wave_bcast(F, (lane + 63) & 63);
-			const int hleft = lane == 0 ? carryH : hl0, Fleft = lane == 0 ? carryF : Fl0;
+			/* direction of F: needs h and F of the cell to the left; hand-over of the chunk's last cell to the next chunk */
+			const int last = ncell - c0 < NT - 1 ? ncell - c0 : NT - 1;     /* thread holding the chunk's last valid cell */
+			int hleft, Fleft;
+			if (NW > 1) {
+				if (lane == 63) { lds_st32(lds, TX_H + 4u * (u32)wv, (u32)h); lds_st32(lds, TX_F + 4u * (u32)wv, (u32)F); }
+				if (tid == last) { lds_st32(lds, TX_CARRY, (u32)F); lds_st32(lds, TX_CARRY + 4, (u32)A); lds_st32(lds, TX_CARRY + 8, (u32)h); }
+				__syncthreads();
+				const int hl0 = wave_bcast(h, (lane + 63) & 63), Fl0 = wave_bcast(F, (lane + 63) & 63);
+				if (lane != 0) { hleft = hl0; Fleft = Fl0; }
+				else if (wv == 0) { hleft = carryH; Fleft = carryF; }
+				else { hleft = (int)lds_ld32(lds, TX_H + 4u * (u32)(wv - 1)); Fleft = (int)lds_ld32(lds, TX_F + 4u * (u32)(wv - 1)); }
+				carryF = (int)lds_ld32(lds, TX_CARRY); carryA = (int)lds_ld32(lds, TX_CARRY + 4); carryH = (int)lds_ld32(lds, TX_CARRY + 8);
+			} else {
+				const int hl0 = wave_bcast(h, (lane + 63) & 63), Fl0 = wave_bcast(F, (lane + 63) & 63);
+				hleft = lane == 0 ? carryH : hl0; Fleft = lane == 0 ? carryF : Fl0;
+				carryF = wave_bcast(F, last); carryA = wave_bcast(A, last); carryH = wave_bcast(h, last);
+			}
 			const int8_t df = (hleft - gapO) > (Fleft - gapE) ? 5 : 4;
 			if (ok) {
 				R.steb(u, e); R.sthc(u, h);
@@ -1432,12 +1476,10 @@ SSW_DEV void trace_wave_band(const TraceRows<L>& R, const int8_t* ref, const int
 				line[(u - 1) * 3 + 2] = gap <= dia ? (int8_t)1 : (e1 > f1 ? de : df);
 				if (h > lb) { lb = h; li = i; lj = j; }      /* rows and chunks come in row-major order: strict > keeps the first */
 			}
-			const int last = ncell - c0 < 63 ? ncell - c0 : 63;     /* lane holding the chunk's last valid cell */
-			carryF = wave_bcast(F, last); carryA = wave_bcast(A, last); carryH = wave_bcast(h, last);
 		}
-		R.fence();
-		for (int u = 1 + lane; u <= ncell; u += 64) R.sthb(u, R.ldhc(u));
-		R.fence();
+		if (NW == 1) trace_sync<L, NW>();    /* NW > 1: every thread is past the chunk's second barrier, and copies the cells it wrote itself */
+		for (int u = 1 + tid; u <= ncell; u += NT) R.sthb(u, R.ldhc(u));
+		trace_sync<L, NW>();
 		rd = rdn;
 	}
 	/* the scalar walk's best cell: highest h above the carried best; among equals the first in row-major order */
@@ -1447,14 +1489,35 @@ SSW_DEV void trace_wave_band(const TraceRows<L>& R, const int8_t* ref, const int
 		const int oh = wave_bcast(lb, lane ^ d), oi = wave_bcast(li, lane ^ d), oj = wave_bcast(lj, lane ^ d);
 		if (oh > lb || (oh == lb && (oi < li || (oi == li && oj < lj)))) { lb = oh; li = oi; lj = oj; }
 	}
+	if (NW > 1) {
+		if (lane == 0) { lds_st32(lds, TX_BEST + 12u * (u32)wv, (u32)lb); lds_st32(lds, TX_BEST + 12u * (u32)wv + 4, (u32)li); lds_st32(lds, TX_BEST + 12u * (u32)wv + 8, (u32)lj); }
+		__syncthreads();
+		for (int v = 0; v < NW; ++v) {
+			const int oh = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v), oi = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v + 4), oj = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v + 8);
+			if (oh > lb || (oh == lb && (oi < li || (oi == li && oj < lj)))) { lb = oh; li = oi; lj = oj; }
+		}
+		__syncthreads();
+	}
 	if (lb > tb.best) { tb.best = lb; tb.i = li; tb.j = lj; }
+}
+
+/* value of thread 0 in every thread of the team */
+template <int NW> SSW_DEV int team_bcast0(unsigned char* lds, int v, int tid)
+{
+	if (NW == 1) return wave_bcast(v, 0);
+	if (tid == 0) lds_st32(lds, TX_BCAST, (u32)v);
+	__syncthreads();
+	const int r = (int)lds_ld32(lds, TX_BCAST);
+	__syncthreads();
+	return r;
 }
 
 /* returns the number of CIGAR operations, -1 (traceback failed), or -2: *need holds the scratch bytes wanted and
    *band_io / tb the state to resume from (the narrower bands need not be walked again: they are deterministic) */
-SSW_DEV int trace_wave(const int8_t* ref, const int8_t* read, int refLen, int readLen, int score, int gapO, int gapE,
+template <int NW>
+SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int readLen, int score, int gapO, int gapE,
                        int* band_io, TraceBest& tb, const int8_t* mat, int n, unsigned char* scratch, int64_t cap,
-                       unsigned char* lds, int64_t lds_cap, u32* cig, int cigcap, int64_t* need, int lane)
+                       unsigned char* lds, int64_t lds_cap, u32* cig, int cigcap, int64_t* need, int tid)
 {
 	const int len = refLen > readLen ? refLen : readLen;
 	int band_width = *band_io, width_d;
@@ -1465,23 +1528,24 @@ SSW_DEV int trace_wave(const int8_t* ref, const int8_t* read, int refLen, int re
 		const int64_t want = 3 * rowbytes + (int64_t)width_d * readLen * 3 + 16;
 		if (want > cap) { *need = want; *band_io = band_width; return -2; }
 		dir = (int8_t*)(scratch + 3 * rowbytes);
-		if (trace_lds_need(band_width) <= lds_cap) {
-			TraceRows<true> R; R.lds = lds; R.ohb = 1024; R.oeb = 1024 + (u32)rowbytes; R.ohc = 1024 + 2 * (u32)rowbytes; R.hb = R.eb = R.hc = 0;
-			const u32 oring = 1024 + 3 * (u32)rowbytes;
-			trace_wave_band<true>(R, ref, read, refLen, readLen, gapO, gapE, band_width, mat, n, dir, 0, oring, trace_ring_size(band_width) - 1, tb, lane);
+		if (trace_lds_need(band_width, 64 * NW) <= lds_cap) {
+			TraceRows<true> R; R.lds = lds; R.ohb = TRACE_LDS_FIXED; R.oeb = TRACE_LDS_FIXED + (u32)rowbytes; R.ohc = TRACE_LDS_FIXED + 2 * (u32)rowbytes;
+			R.hb = R.eb = R.hc = 0;
+			const u32 oring = TRACE_LDS_FIXED + 3 * (u32)rowbytes;
+			trace_band<true, NW>(R, ref, read, refLen, readLen, gapO, gapE, band_width, mat, n, dir, oring, trace_ring_size(band_width, 64 * NW) - 1, tb, tid);
 		} else {
 			TraceRows<false> R; R.lds = lds; R.ohb = R.oeb = R.ohc = 0;
 			R.hb = (int*)scratch; R.eb = (int*)(scratch + rowbytes); R.hc = (int*)(scratch + 2 * rowbytes);
-			trace_wave_band<false>(R, ref, read, refLen, readLen, gapO, gapE, band_width, mat, n, dir, 0, 0, 0, tb, lane);
+			trace_band<false, NW>(R, ref, read, refLen, readLen, gapO, gapE, band_width, mat, n, dir, 0, 0, tb, tid);
 		}
 		band_width *= 2;
 	} while (tb.best < score && band_width <= len);
 	band_width /= 2;
 	const int best_i = tb.i, best_j = tb.j;
 
-	wg_fence();
+	if (NW > 1) { wg_fence(); __syncthreads(); } else wg_fence();
 	int nops = 0;
-	if (lane == 0) {
+	if (tid == 0) {
 		int run = 0, state = 2, cur = 0, prev = 0, i = best_i, j = best_j, failed = 0;
 		while (i >= 0 && j > 0) {
 			const int8_t d = dir[(int64_t)width_d * i * 3 + band_d(band_width, i, j, state)];
@@ -1506,18 +1570,19 @@ SSW_DEV int trace_wave(const int8_t* ref, const int8_t* read, int refLen, int re
 		}
 	}
 	wg_fence();
-	return wave_bcast(nops, 0);
+	return team_bcast0<NW>(lds, nops, tid);
 }
 
-/* one wavefront per alignment; same contract as k_trace.  a.resume[q] = {band, best, best_i, best_j, stage} carries an
-   alignment that ran out of scratch to the next negotiation round. */
-__global__ void __launch_bounds__(64) k_trace_wave(ssw_trace_args a)
+/* one team of NW wavefronts (one workgroup) per alignment; same contract as k_trace.  a.resume[q] = {band, best, best_i,
+   best_j, stage} carries an alignment that ran out of scratch to the next negotiation round. */
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_trace_wave(ssw_trace_args a)
 {
 	SSW_DYN_LDS(lds);
-	const int job = (int)blockIdx.x, lane = (int)threadIdx.x;
+	const int job = (int)blockIdx.x, tid = (int)threadIdx.x;
 	const int q = a.qlist[job];
 	ssw_dres r = a.res[q];
-	if (lane == 0) a.need[job] = 0;
+	if (tid == 0) a.need[job] = 0;
 	if (!r.want_cigar || r.status != 0) return;
 	const int8_t* ref = a.tgt + r.ref_begin1;
 	const int8_t* read = a.qcodes + a.qoff[q] + r.read_begin1;
@@ -1529,8 +1594,8 @@ __global__ void __launch_bounds__(64) k_trace_wave(ssw_trace_args a)
 	u32* cig = a.cigar + (int64_t)q * a.cigar_stride;
 	unsigned char* scratch = a.soff ? a.scratch + a.soff[job] : a.scratch + (int64_t)job * a.scratch_stride;
 	const int64_t scap = a.soff ? a.soff[job + 1] - a.soff[job] : a.scratch_stride;
-	for (int k = lane; k < a.n * a.n && k < 1024; k += 64) lds_st8(lds, (u32)k, (u32)(unsigned char)a.mat[k]);
-	wave_lds_fence();
+	for (int k = tid; k < a.n * a.n && k < 1024; k += 64 * NW) lds_st8(lds, (u32)k, (u32)(unsigned char)a.mat[k]);
+	trace_sync<true, NW>();
 	const int64_t lds_cap = a.n * a.n <= 1024 ? (int64_t)a.lds_bytes : 0;
 	TraceBest tb; tb.best = 0; tb.i = 0; tb.j = 0;
 	int stage = 0;                         /* 1: the single full-band retry after a CIGAR that does not re-score (ssw.c:1000-1010) */
@@ -1540,11 +1605,11 @@ __global__ void __launch_bounds__(64) k_trace_wave(ssw_trace_args a)
 	for (;;) {
 		int64_t need = 0;
 		int bio = band;
-		nops = trace_wave(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, &bio, tb, a.mat, a.n, scratch, scap,
-		                  lds, lds_cap, cig, (int)a.cigar_stride, &need, lane);
-		const int64_t need0 = ((int64_t)wave_bcast((int)(need >> 32), 0) << 32) | (u32)wave_bcast((int)(need & 0xffffffff), 0);
+		nops = trace_team<NW>(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, &bio, tb, a.mat, a.n, scratch, scap,
+		                      lds, lds_cap, cig, (int)a.cigar_stride, &need, tid);
 		if (nops == -2) {
-			if (lane == 0) {
+			const int64_t need0 = ((int64_t)team_bcast0<NW>(lds, (int)(need >> 32), tid) << 32) | (u32)team_bcast0<NW>(lds, (int)(need & 0xffffffff), tid);
+			if (tid == 0) {
 				a.need[job] = need0 > 0 ? (int)((need0 + 4095) >> 12) : -1;
 				a.need[a.nq + job] = bio;
 				rs[0] = bio; rs[1] = tb.best; rs[2] = tb.i; rs[3] = tb.j; rs[4] = stage;
@@ -1553,14 +1618,14 @@ __global__ void __launch_bounds__(64) k_trace_wave(ssw_trace_args a)
 		}
 		if (nops < 0) break;
 		int sc = 0;
-		if (lane == 0) sc = cigar_score(cig, nops, ref, read, a.mat, a.n, a.gapO, a.gapE);
-		sc = wave_bcast(sc, 0);
+		if (tid == 0) sc = cigar_score(cig, nops, ref, read, a.mat, a.n, a.gapO, a.gapE);
+		sc = team_bcast0<NW>(lds, sc, tid);
 		if (sc == r.score1) break;
 		if (stage || band0 >= full) { nops = -1; break; }
 		band = full; stage = 1;
 		tb.best = 0; tb.i = 0; tb.j = 0;
 	}
-	if (lane == 0) {
+	if (tid == 0) {
 		if (nops < 0) { a.res[q].flag = 1; a.res[q].cigarLen = 0; }
 		else { a.res[q].cigarLen = nops; a.res[q].cigar_off = (int64_t)q * a.cigar_stride; }
 	}
@@ -1849,14 +1914,18 @@ extern "C" int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream)
 	return SSW_LAUNCH_OK();
 }
 
-extern "C" int64_t ssw_shim_trace_lds_need(int band_width) { return trace_lds_need(band_width); }
+extern "C" int64_t ssw_shim_trace_lds_need(int band_width, int waves) { return trace_lds_need(band_width, 64 * waves); }
 
 extern "C" int ssw_shim_launch_trace_wave(const ssw_trace_args* a, void* stream)
 {
 	ssw_trace_args args = *a;
 	if (args.nq <= 0) return 0;
-	if (args.lds_bytes < 1024) args.lds_bytes = 1024;
-	SSW_LAUNCH(k_trace_wave, ssw_trace_args, args, args.nq, 64, (size_t)args.lds_bytes, stream);
+	if (args.lds_bytes < (int32_t)TRACE_LDS_FIXED) args.lds_bytes = (int32_t)TRACE_LDS_FIXED;
+	switch (args.waves) {
+		case 16: SSW_LAUNCH((k_trace_wave<16>), ssw_trace_args, args, args.nq, 1024, (size_t)args.lds_bytes, stream); break;
+		case 4: SSW_LAUNCH((k_trace_wave<4>), ssw_trace_args, args, args.nq, 256, (size_t)args.lds_bytes, stream); break;
+		default: SSW_LAUNCH((k_trace_wave<1>), ssw_trace_args, args, args.nq, 64, (size_t)args.lds_bytes, stream); break;
+	}
 	return SSW_LAUNCH_OK();
 }
 

@@ -128,13 +128,15 @@ def test_database_search_fused_kernel(ectx):
     _run(ectx, preads, refs[:5], blosum50(), 24, flag=0)
 
 
-@pytest.mark.parametrize("wave", ["0", "1", "1-hbm-rows"])
+@pytest.mark.parametrize("wave", ["0", "1", "1-hbm-rows", "1-teams4", "1-teams16", "1-teams4-hbm-rows"])
 def test_traceback_band_growth_and_both_kernels(ectx, wave, monkeypatch):
     """alignments with long gaps force the band to double past the first scratch class (negotiation rounds); checked with
     the per-thread (k_trace) and the per-wavefront (k_trace_wave) traceback"""
     monkeypatch.setenv("SSW_GPU_TRACE_WAVE", wave[0])
     if wave.endswith("hbm-rows"):
         monkeypatch.setenv("SSW_GPU_TRACE_LDS", "0")
+    if "teams" in wave:
+        monkeypatch.setenv("SSW_GPU_TRACE_WAVES", wave.split("teams")[1].split("-")[0])
     rng = np.random.default_rng(12)
     ref = random_ref(900, 17, 4)
     reads = [np.concatenate([ref[100:200], ref[260:360]]),            # 60-base deletion
@@ -146,12 +148,16 @@ def test_traceback_band_growth_and_both_kernels(ectx, wave, monkeypatch):
         _run(ectx, [np.ascontiguousarray(r, dtype=np.int8) for r in reads], [ref], dna_matrix(2, 2), 5, flag=flag)
 
 
-def test_long_read_wave_traceback_resumes_across_rounds(ectx):
+@pytest.mark.parametrize("teams", [None, "4", "16"])
+def test_long_read_wave_traceback_resumes_across_rounds(ectx, teams, monkeypatch):
     """reads above 1024 bases take the wavefront traceback by default; a 90-base deletion and a 70-base insertion push the
     band through several doublings, i.e. through scratch-negotiation rounds that resume at the band that did not fit"""
+    if teams:
+        monkeypatch.setenv("SSW_GPU_TRACE_WAVES", teams)
     rng = np.random.default_rng(44)
     ref = random_ref(2600, 23, 4)
     reads = [np.concatenate([ref[100:700], ref[790:1300]]),
+             np.concatenate([ref[50:650], ref[860:1400]]),            # 210-base deletion: band rows of > 256 cells
              np.concatenate([ref[1300:1800], rng.integers(0, 4, size=70, dtype=np.int8), ref[1800:2400]])]
     reads += make_reads(rng, ref, 2, [1100, 1250], 4, sub=0.02, ins=0.005, dele=0.005)
     _run(ectx, [np.ascontiguousarray(r, dtype=np.int8) for r in reads], [ref], dna_matrix(2, 2), 5, flag=2)
