@@ -31,10 +31,13 @@ struct _profile {
 
 typedef struct { void* p; size_t cap; } dbuf;
 
+#define SSW_TSTREAMS 6
+
 struct ssw_gpu_ctx {
 	int device;
 	void* stream;
 	void* stream2;                      /* reductions of chunk i overlap the fill of chunk i+1 */
+	void* tstream[SSW_TSTREAMS]; void* tev[SSW_TSTREAMS];   /* traceback classes of one negotiation round run side by side */
 	void *ev_fill[2], *ev_red[2];
 	char err[512];
 	ssw_gpu_timing tm;
@@ -89,6 +92,7 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
 	c->device = device;
 	c->stream = ssw_shim_stream_create();
 	c->stream2 = ssw_shim_stream_create();
+	for (int i = 0; i < SSW_TSTREAMS; ++i) { c->tstream[i] = ssw_shim_stream_create(); c->tev[i] = ssw_shim_event_create(); }
 	for (int i = 0; i < 2; ++i) { c->ev_fill[i] = ssw_shim_event_create(); c->ev_red[i] = ssw_shim_event_create(); }
 	c->ev_t0 = ssw_shim_event_create(); c->ev_a = ssw_shim_event_create(); c->ev_b = ssw_shim_event_create();
 	c->ev_c = ssw_shim_event_create(); c->ev_d = ssw_shim_event_create();
@@ -112,6 +116,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_event_destroy(c->ev_c); ssw_shim_event_destroy(c->ev_d);
 	for (int i = 0; i < 2; ++i) { ssw_shim_event_destroy(c->ev_fill[i]); ssw_shim_event_destroy(c->ev_red[i]); }
 	ssw_shim_stream_destroy(c->stream2);
+	for (int i = 0; i < SSW_TSTREAMS; ++i) { ssw_shim_stream_destroy(c->tstream[i]); ssw_shim_event_destroy(c->tev[i]); }
 	ssw_shim_stream_destroy(c->stream);
 	free(c);
 }
@@ -739,57 +744,84 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 						                                     cnt_l, (long long)sstride, nnext);
 					}
 				} else {
-					/* every pending alignment gets twice what it last needed (one more band doubling), all in as few launches
-					   as the HBM budget allows: the wide bands are few, so they must run side by side to fill the device */
-					int64_t* hoff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)npend + 1));
+					/* every pending alignment gets a multiple of what it last needed (one or two more band doublings).  The
+					   launches of a round -- one per (LDS size, team size) class, split further by the HBM budget -- work on
+					   different alignments and different scratch: they are issued on separate streams and run side by side
+					   (each is bound by the latency of its longest alignment, not by throughput). */
+					int64_t* hoff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)npend * 2 + 2));
+					int32_t* hall = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)npend);
 					const int64_t budget = (int64_t)c->cm_budget * 2;
-					for (int32_t g0 = 0; g0 < npend && trace_ok; ) {
-						int32_t g1 = g0; int64_t total = 0;
-						hoff[0] = 0;
-						/* wavefront kernel: one LDS size per launch, enough for twice the band of the launch's widest request */
-						int64_t lds_l = 0; int waves_l = 1;
-						while (g1 < npend) {
-							int64_t cap_i = ((int64_t)pend[g1].need * 4096 * 2 + 65536 + 15) / 16 * 16;
-							if (cap_i > worst) cap_i = worst;
-							if (g1 > g0 && total + cap_i > budget) break;
-							if (use_wave) {
-								/* a band row of 2b+1 cells is walked in chunks of 64 cells per wavefront: wide bands get 4 or 16 wavefronts */
-								const int32_t b2 = pend[g1].key > (1 << 20) ? (1 << 21) : 2 * pend[g1].key;
-								int wv = b2 <= 96 ? 1 : b2 <= 768 ? 4 : 16;
-								if (trace_waves_env > 0) wv = trace_waves_env;
-								int64_t l = ssw_shim_trace_lds_need(b2, wv), cls = 2048;
-								while (cls < l && cls < 131072) cls <<= 1;
-								if (g1 > g0 && (cls != lds_l || wv != waves_l)) break;     /* pending alignments are sorted by band: classes are contiguous */
-								lds_l = cls; waves_l = wv;
+					for (int32_t k = 0; k < npend; ++k) lst[k] = pend[k].q;
+					int64_t* d_soff = (int64_t*)ensure(c, &c->goff, sizeof(int64_t) * ((size_t)npend * 2 + 2));
+					if (!d_soff || ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)npend, c->stream)) { trace_ok = 0; free(hoff); free(hall); free(nextp); break; }
+					for (int32_t b0 = 0; b0 < npend && trace_ok; ) {       /* one batch = what fits the HBM budget at once */
+						struct { int32_t g0, g1, waves; int64_t lds, base, soff0; } grp[64];
+						int ngrp = 0; int64_t batch_total = 0; int32_t g0 = b0; int64_t soff_at = 0;
+						while (g0 < npend && ngrp < 64) {
+							int32_t g1 = g0; int64_t total = 0, lds_l = 0; int waves_l = 1;
+							hoff[soff_at] = 0;
+							while (g1 < npend) {
+								const int64_t nb_ = (int64_t)pend[g1].need * 4096;
+								int64_t cap_i = (nb_ * (nb_ < ((int64_t)32 << 20) ? 4 : 2) + 65536 + 15) / 16 * 16;
+								if (cap_i > worst) cap_i = worst;
+								if ((g1 > g0 || ngrp > 0) && batch_total + total + cap_i > budget) break;
+								if (use_wave) {
+									/* a band row of 2b+1 cells is walked in chunks of 64 cells per wavefront: wide bands get 4 or 16 wavefronts */
+									const int32_t b2 = pend[g1].key > (1 << 20) ? (1 << 21) : 2 * pend[g1].key;
+									int wv = b2 <= 96 ? 1 : b2 <= 768 ? 4 : 16;
+									if (trace_waves_env > 0) wv = trace_waves_env;
+									int64_t l = ssw_shim_trace_lds_need(b2, wv), cls = 2048;
+									while (cls < l && cls < 131072) cls <<= 1;
+									if (g1 > g0 && (cls != lds_l || wv != waves_l)) break;     /* pending alignments are sorted by band: classes are contiguous */
+									lds_l = cls; waves_l = wv;
+								}
+								total += cap_i; hoff[soff_at + (g1 - g0) + 1] = total; ++g1;
 							}
-							total += cap_i; hoff[g1 - g0 + 1] = total; ++g1;
+							if (g1 == g0) break;                               /* budget exhausted: next batch */
+							grp[ngrp].g0 = g0; grp[ngrp].g1 = g1; grp[ngrp].waves = waves_l; grp[ngrp].lds = lds_l;
+							grp[ngrp].base = batch_total; grp[ngrp].soff0 = soff_at; ++ngrp;
+							batch_total += total; soff_at += (g1 - g0) + 1; g0 = g1;
 						}
-						const int32_t cnt_l = g1 - g0;
-						for (int32_t k = 0; k < cnt_l; ++k) lst[k] = pend[g0 + k].q;
-						uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)total);
-						int64_t* d_soff = (int64_t*)ensure(c, &c->goff, sizeof(int64_t) * ((size_t)cnt_l + 1));
-						if (!d_scr || !d_soff) { trace_ok = 0; break; }
-						ssw_trace_args ta;
-						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
-						ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = 0; ta.soff = d_soff;
-						ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;
-						ta.resume = d_resume; ta.waves = waves_l; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)lds_l;
-						if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
-						    ssw_shim_h2d(d_soff, hoff, sizeof(int64_t) * ((size_t)cnt_l + 1), c->stream) ||
-						    (use_wave ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
-						    ssw_shim_d2h(hneed, d_need, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
-						    (use_wave && ssw_shim_d2h(hband, d_need + cnt_l, sizeof(int32_t) * (size_t)cnt_l, c->stream)) ||
+						uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)batch_total);
+						if (!d_scr) { trace_ok = 0; break; }
+						if (ssw_shim_h2d(d_soff, hoff, sizeof(int64_t) * (size_t)soff_at, c->stream) || ssw_shim_event_record(c->ev_fill[0], c->stream)) {
+							fail(c, "upload failed: %s", ssw_shim_last_error()); trace_ok = 0; break;
+						}
+						/* widest bands first: they take longest, and only a few hardware queues run side by side */
+						for (int gx = 0; gx < ngrp && trace_ok; ++gx) {
+							const int gi = ngrp - 1 - gx;
+							void* st = gx == 0 ? c->stream : c->tstream[(gx - 1) % SSW_TSTREAMS];
+							const int32_t cnt_l = grp[gi].g1 - grp[gi].g0;
+							ssw_trace_args ta;
+							ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist + grp[gi].g0; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
+							ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr + grp[gi].base; ta.scratch_stride = 0;
+							ta.soff = d_soff + grp[gi].soff0;
+							ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need + 2 * (int64_t)grp[gi].g0;
+							ta.resume = d_resume; ta.waves = grp[gi].waves; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)grp[gi].lds;
+							if (st != c->stream) ssw_shim_stream_wait_event(st, c->ev_fill[0]);
+							if (use_wave ? ssw_shim_launch_trace_wave(&ta, st) : ssw_shim_launch_trace(&ta, st)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
+							if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, LDS %lld B x %d waves per alignment, scratch at %lld\n",
+							                                     round, cnt_l, (long long)grp[gi].lds, grp[gi].waves, (long long)grp[gi].base);
+						}
+						for (int gi = 1; gi < ngrp && gi <= SSW_TSTREAMS; ++gi)     /* the main stream continues after all of them */
+							if (ssw_shim_event_record(c->tev[gi - 1], c->tstream[gi - 1]) || ssw_shim_stream_wait_event(c->stream, c->tev[gi - 1])) trace_ok = 0;
+						if (!trace_ok) break;
+						if (ssw_shim_d2h(hall + 2 * (int64_t)b0, d_need + 2 * (int64_t)b0, sizeof(int32_t) * 2 * (size_t)(g0 - b0), c->stream) ||
 						    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
-						for (int32_t k = 0; k < cnt_l; ++k)
-							if (hneed[k] != 0) {
-								if (hneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
-								nextp[nnext].key = use_wave ? hband[k] : hneed[k]; nextp[nnext].need = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
-							}
-						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, %lld B of scratch in total, LDS %lld B x %d waves per alignment, %d pending so far\n",
-						                                     round, cnt_l, (long long)total, (long long)lds_l, waves_l, nnext);
-						g0 = g1;
+						for (int gi = 0; gi < ngrp && trace_ok; ++gi) {
+							const int32_t cnt_l = grp[gi].g1 - grp[gi].g0;
+							const int32_t* gneed = hall + 2 * (int64_t)grp[gi].g0; const int32_t* gband = gneed + cnt_l;
+							for (int32_t k = 0; k < cnt_l; ++k)
+								if (gneed[k] != 0) {
+									if (gneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
+									nextp[nnext].key = use_wave ? gband[k] : gneed[k]; nextp[nnext].need = gneed[k]; nextp[nnext].q = lst[grp[gi].g0 + k]; ++nnext;
+								}
+						}
+						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d launches side by side, %lld B of scratch, %d pending so far\n",
+						                                     round, ngrp, (long long)batch_total, nnext);
+						b0 = g0;
 					}
-					free(hoff);
+					free(hoff); free(hall);
 				}
 				did_trace = 1;
 				free(pend); pend = nextp; npend = nnext;

@@ -1402,7 +1402,7 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 		const int end = i + band_width < refLen - 1 ? i + band_width : refLen - 1;
 		const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
 		const int ncell = end - beg + 1;
-		int8_t* line = dir + (int64_t)width_d * i * 3;
+		int8_t* line = dir + (int64_t)width_d * i;     /* one packed byte per cell: bit 0 = E opened, bit 1 = F opened, bits 2.. = H's source */
 		if (L && (i & 63) == 0) {   /* target window: everything the next 64 rows can touch */
 			int64_t hi = (int64_t)i + band_width + 65; if (hi > refLen) hi = refLen;
 			for (int j = staged + tid; j < (int)hi; j += NT) lds_st8(lds, oring + ((u32)j & ring_mask), (u32)(unsigned char)ref[j]);
@@ -1471,9 +1471,8 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 			const int8_t df = (hleft - gapO) > (Fleft - gapE) ? 5 : 4;
 			if (ok) {
 				R.steb(u, e); R.sthc(u, h);
-				line[(u - 1) * 3 + 0] = de;
-				line[(u - 1) * 3 + 1] = df;
-				line[(u - 1) * 3 + 2] = gap <= dia ? (int8_t)1 : (e1 > f1 ? de : df);
+				const int dh = gap <= dia ? 1 : (e1 > f1 ? de : df);
+				line[u - 1] = (int8_t)((de == 3 ? 1 : 0) | (df == 5 ? 2 : 0) | (dh << 2));     /* 64 contiguous bytes per wavefront store */
 				if (h > lb) { lb = h; li = i; lj = j; }      /* rows and chunks come in row-major order: strict > keeps the first */
 			}
 		}
@@ -1525,7 +1524,7 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 	do {
 		const int width = band_width * 2 + 3; width_d = band_width * 2 + 1;
 		const int64_t rowbytes = (((int64_t)width + 1) * 4 + 15) & ~(int64_t)15;
-		const int64_t want = 3 * rowbytes + (int64_t)width_d * readLen * 3 + 16;
+		const int64_t want = 3 * rowbytes + (int64_t)width_d * readLen + 16;
 		if (want > cap) { *need = want; *band_io = band_width; return -2; }
 		dir = (int8_t*)(scratch + 3 * rowbytes);
 		if (trace_lds_need(band_width, 64 * NW) <= lds_cap) {
@@ -1548,7 +1547,9 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 	if (tid == 0) {
 		int run = 0, state = 2, cur = 0, prev = 0, i = best_i, j = best_j, failed = 0;
 		while (i >= 0 && j > 0) {
-			const int8_t d = dir[(int64_t)width_d * i * 3 + band_d(band_width, i, j, state)];
+			const int x0 = i - band_width > 0 ? i - band_width : 0;
+			const int pk = (unsigned char)dir[(int64_t)width_d * i + (j - x0)];
+			const int d = state == 0 ? 2 + (pk & 1) : state == 1 ? 4 + ((pk >> 1) & 1) : pk >> 2;
 			if (d == 1) { --i; --j; state = 2; cur = 0; }
 			else if (d == 2) { --i; state = 0; cur = 1; }
 			else if (d == 3) { --i; state = 2; cur = 1; }
