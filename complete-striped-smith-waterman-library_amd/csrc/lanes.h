@@ -37,6 +37,14 @@ SSW_DEV u32 xl_row_shr1_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_upd
 template <int N> SSW_DEV u32 xl_row_ror(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x120 + N, 0xf, 0xf, true); }
 /* wave_shr:1 (0x138, GFX9 family only): lane i reads lane i-1 across the whole wavefront; lane 0 keeps `keep` */
 SSW_DEV u32 xl_wave_shr1_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x138, 0xf, 0xf, false); }
+/* row_shr:N keeping `keep` where the row has no lane N to the left; row_bcast:15 / row_bcast:31 (GFX9 family): lane 15 of
+   every row to the lanes of the next row (rows 1 and 3 take it), lane 31 to rows 2 and 3 -- the two cross-row steps of a
+   wavefront-wide prefix scan; lanes outside the row mask keep `keep` */
+template <int N> SSW_DEV u32 xl_row_shr_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x110 + N, 0xf, 0xf, false); }
+SSW_DEV u32 xl_row_bcast15_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x142, 0xa, 0xf, false); }
+SSW_DEV u32 xl_row_bcast31_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x143, 0xc, 0xf, false); }
+/* value of one lane (wavefront-uniform index) in every lane */
+SSW_DEV u32 xl_readlane(u32 v, int lane_uniform) { return (u32)__builtin_amdgcn_readlane((int)v, lane_uniform); }
 SSW_DEV u32 xl_shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 64); }
 SSW_DEV bool wave_any(bool p) { return __any(p) != 0; }
 SSW_DEV bool wave_all(bool p) { return __all(p) != 0; }

@@ -905,14 +905,14 @@ done:
 	return rc;
 }
 
-int ssw_gpu_selftest_lanes(ssw_gpu_ctx* c, uint32_t* out640)
+int ssw_gpu_selftest_lanes(ssw_gpu_ctx* c, uint32_t* out1024)
 {
-	if (!c || !out640) return -1;
+	if (!c || !out1024) return -1;
 	ssw_shim_set_device(c->device);
-	uint32_t* d = (uint32_t*)ssw_shim_malloc(640 * 4);
+	uint32_t* d = (uint32_t*)ssw_shim_malloc(1024 * 4);
 	if (!d) return fail(c, "device allocation failed: %s", ssw_shim_last_error());
 	ssw_selftest_args a; a.lanes_out = d; a.sink = 0; a.iters = 0; a.seed = 0;
-	int rc = ssw_shim_launch_selftest(&a, 1, c->stream) || ssw_shim_d2h(out640, d, 640 * 4, c->stream) || ssw_shim_stream_sync(c->stream);
+	int rc = ssw_shim_launch_selftest(&a, 1, c->stream) || ssw_shim_d2h(out1024, d, 1024 * 4, c->stream) || ssw_shim_stream_sync(c->stream);
 	ssw_shim_free(d);
 	return rc ? fail(c, "selftest failed: %s", ssw_shim_last_error()) : 0;
 }

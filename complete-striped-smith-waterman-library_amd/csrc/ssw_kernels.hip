@@ -1428,24 +1428,33 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 			int A = e > dia ? e : dia; if (A < 0) A = 0;
 			/* s[p] = max_{k <= p} (A[k] - (p - k) m): inclusive max-plus scan, first within the wavefront ... */
 			int s = A;
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				const int o = wave_bcast(s, (lane - d) & 63);
-				if (lane >= d) { const int v = o - d * m; s = v > s ? v : s; }
+			{   /* DPP scan: four steps inside the 16-lane rows, then lane 15 -> next row, lane 31 -> upper half */
+				int o;
+				o = (int)xl_row_shr_keep<1>((u32)NEG, (u32)s) - m; s = o > s ? o : s;
+				o = (int)xl_row_shr_keep<2>((u32)NEG, (u32)s) - 2 * m; s = o > s ? o : s;
+				o = (int)xl_row_shr_keep<4>((u32)NEG, (u32)s) - 4 * m; s = o > s ? o : s;
+				o = (int)xl_row_shr_keep<8>((u32)NEG, (u32)s) - 8 * m; s = o > s ? o : s;
+				o = (int)xl_row_bcast15_keep((u32)NEG, (u32)s) - ((lane & 15) + 1) * m; s = o > s ? o : s;
+				o = (int)xl_row_bcast31_keep((u32)NEG, (u32)s) - ((lane & 31) + 1) * m; s = o > s ? o : s;
 			}
 			int P = NEG;                                            /* ... then across the wavefronts to the left: s of the cell before lane 0 */
 			if (NW > 1) {
 				if (lane == 63) lds_st32(lds, TX_T + 4u * (u32)wv, (u32)s);
 				__syncthreads();
-				for (int v = 0; v < wv; ++v) {
-					const int t = (int)lds_ld32(lds, TX_T + 4u * (u32)v) - 64 * (wv - 1 - v) * m;
-					P = t > P ? t : P;
+				{   /* every wavefront scans the (at most 16) wave totals itself: lane v holds T_v, decay 64 m per wavefront */
+					int t = lane < NW ? (int)lds_ld32(lds, TX_T + 4u * (u32)lane) : NEG, o;
+					o = (int)xl_row_shr_keep<1>((u32)NEG, (u32)t) - 64 * m; t = o > t ? o : t;
+					o = (int)xl_row_shr_keep<2>((u32)NEG, (u32)t) - 128 * m; t = o > t ? o : t;
+					if (NW > 4) {
+						o = (int)xl_row_shr_keep<4>((u32)NEG, (u32)t) - 256 * m; t = o > t ? o : t;
+						o = (int)xl_row_shr_keep<8>((u32)NEG, (u32)t) - 512 * m; t = o > t ? o : t;
+					}
+					if (wv > 0) P = (int)xl_readlane((u32)t, wv - 1);
 				}
 				const int sp = P - (lane + 1) * m;
 				s = sp > s ? sp : s;
 			}
-			const int sl0 = wave_bcast(s, (lane + 63) & 63);
-			const int sleft = lane == 0 ? P : sl0;                  /* s[p-1]; nothing (NEG) left of the chunk's first cell */
+			const int sleft = (int)xl_wave_shr1_keep((u32)P, (u32)s);   /* s[p-1]; nothing (NEG) left of the chunk's first cell */
 			int F = sleft - gapO;
 			{ const int ca = carryA - gapO - tid * m, cf = carryF - (tid + 1) * m; F = ca > F ? ca : F; F = cf > F ? cf : F; }
 			const int e1 = e > 0 ? e : 0, f1 = F > 0 ? F : 0;
@@ -1458,15 +1467,13 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 				if (lane == 63) { lds_st32(lds, TX_H + 4u * (u32)wv, (u32)h); lds_st32(lds, TX_F + 4u * (u32)wv, (u32)F); }
 				if (tid == last) { lds_st32(lds, TX_CARRY, (u32)F); lds_st32(lds, TX_CARRY + 4, (u32)A); lds_st32(lds, TX_CARRY + 8, (u32)h); }
 				__syncthreads();
-				const int hl0 = wave_bcast(h, (lane + 63) & 63), Fl0 = wave_bcast(F, (lane + 63) & 63);
-				if (lane != 0) { hleft = hl0; Fleft = Fl0; }
-				else if (wv == 0) { hleft = carryH; Fleft = carryF; }
-				else { hleft = (int)lds_ld32(lds, TX_H + 4u * (u32)(wv - 1)); Fleft = (int)lds_ld32(lds, TX_F + 4u * (u32)(wv - 1)); }
+				int kh = carryH, kf = carryF;
+				if (wv > 0) { kh = (int)lds_ld32(lds, TX_H + 4u * (u32)(wv - 1)); kf = (int)lds_ld32(lds, TX_F + 4u * (u32)(wv - 1)); }
+				hleft = (int)xl_wave_shr1_keep((u32)kh, (u32)h); Fleft = (int)xl_wave_shr1_keep((u32)kf, (u32)F);
 				carryF = (int)lds_ld32(lds, TX_CARRY); carryA = (int)lds_ld32(lds, TX_CARRY + 4); carryH = (int)lds_ld32(lds, TX_CARRY + 8);
 			} else {
-				const int hl0 = wave_bcast(h, (lane + 63) & 63), Fl0 = wave_bcast(F, (lane + 63) & 63);
-				hleft = lane == 0 ? carryH : hl0; Fleft = lane == 0 ? carryF : Fl0;
-				carryF = wave_bcast(F, last); carryA = wave_bcast(A, last); carryH = wave_bcast(h, last);
+				hleft = (int)xl_wave_shr1_keep((u32)carryH, (u32)h); Fleft = (int)xl_wave_shr1_keep((u32)carryF, (u32)F);
+				carryF = (int)xl_readlane((u32)F, last); carryA = (int)xl_readlane((u32)A, last); carryH = (int)xl_readlane((u32)h, last);
 			}
 			const int8_t df = (hleft - gapO) > (Fleft - gapE) ? 5 : 4;
 			if (ok) {
@@ -1745,6 +1752,12 @@ __global__ void __launch_bounds__(256) k_selftest(ssw_selftest_args a)
 		a.lanes_out[7 * 64 + tid] = pk_subu(pk_make((int)tid, 5), pk_make(10, (int)tid));
 		a.lanes_out[8 * 64 + tid] = pk_max(pk_make((int)tid - 32, 3), pk_make(0, (int)tid - 60));
 		a.lanes_out[9 * 64 + tid] = xl_wave_shr1_keep(7000u + tid, v);
+		a.lanes_out[10 * 64 + tid] = xl_row_shr_keep<2>(7000u + tid, v);
+		a.lanes_out[11 * 64 + tid] = xl_row_shr_keep<4>(7000u + tid, v);
+		a.lanes_out[12 * 64 + tid] = xl_row_shr_keep<8>(7000u + tid, v);
+		a.lanes_out[13 * 64 + tid] = xl_row_bcast15_keep(7000u + tid, v);
+		a.lanes_out[14 * 64 + tid] = xl_row_bcast31_keep(7000u + tid, v);
+		a.lanes_out[15 * 64 + tid] = xl_readlane(v, 37);
 	}
 	if (a.iters > 0) {
 		u32 x0 = gid, x1 = gid * 3u, x2 = gid * 5u, x3 = gid * 7u, x4 = gid * 11u, x5 = gid * 13u, x6 = gid * 17u, x7 = gid * 19u;

@@ -180,7 +180,7 @@ class Context(object):
         return {k: getattr(t, k) for k, _ in Timing._fields_}
 
     def selftest_lanes(self):
-        out = np.zeros((10, 64), dtype=np.uint32)
+        out = np.zeros((16, 64), dtype=np.uint32)
         if self.lib.ssw_gpu_selftest_lanes(self.h, out.ctypes.data_as(_u32p)) != 0:
             raise RuntimeError("ssw_gpu_selftest_lanes: " + self.error())
         return out

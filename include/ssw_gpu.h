@@ -103,10 +103,10 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* queries, const ssw
 
 int ssw_gpu_last_timing(const ssw_gpu_ctx* ctx, ssw_gpu_timing* out);
 
-/* Diagnostics.  ssw_gpu_selftest_lanes: 10 x 64 words produced by the cross-lane / packed-arithmetic primitives the
+/* Diagnostics.  ssw_gpu_selftest_lanes: 16 x 64 words produced by the cross-lane / packed-arithmetic primitives the
    kernels are written in (checked by tests against the ISA semantics).  ssw_gpu_valu_probe: measured issue rate of
    packed 16-bit VALU instructions in lane-operations per second (the compute roofline of this integer path). */
-int ssw_gpu_selftest_lanes(ssw_gpu_ctx* ctx, uint32_t* out640);
+int ssw_gpu_selftest_lanes(ssw_gpu_ctx* ctx, uint32_t* out1024);
 double ssw_gpu_valu_probe(ssw_gpu_ctx* ctx, int32_t blocks, int32_t iters);
 
 /* Convert one batch record into a heap s_align (align_destroy()-compatible), copying its CIGAR. */

@@ -110,6 +110,22 @@ template <int N> SSW_DEV u32 xl_row_ror(u32 v)
 	int l = emu::cur->lane;
 	return emu::exchange(v, (l & ~15) | ((l - N) & 15), true, 0u);
 }
+template <int N> SSW_DEV u32 xl_row_shr_keep(u32 keep, u32 v)
+{
+	int l = emu::cur->lane;
+	return emu::exchange(v, l - N, (l & 15) >= N, keep);
+}
+SSW_DEV u32 xl_row_bcast15_keep(u32 keep, u32 v)
+{
+	int l = emu::cur->lane, row = l >> 4;
+	return emu::exchange(v, (row << 4) - 1, row == 1 || row == 3, keep);
+}
+SSW_DEV u32 xl_row_bcast31_keep(u32 keep, u32 v)
+{
+	int l = emu::cur->lane;
+	return emu::exchange(v, 31, l >= 32, keep);
+}
+SSW_DEV u32 xl_readlane(u32 v, int lane_uniform) { return emu::exchange(v, lane_uniform & 63, true, 0u); }
 SSW_DEV u32 xl_shfl(u32 v, int src_lane) { return emu::exchange(v, src_lane & 63, true, 0u); }
 SSW_DEV bool wave_any(bool p)
 {

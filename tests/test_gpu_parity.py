@@ -186,6 +186,12 @@ def test_cross_lane_primitives_match_isa_semantics(gpu_ctx):
         assert (o[row] == 100 + src).all()                                  # row_ror:n reads lane (i-n) mod 16
     assert (o[5] == 100 + ((lane + 16) & 63)).all()
     assert (o[9] == np.where(lane == 0, 7000, v - 1)).all()                 # wave_shr:1 crosses the DPP rows; lane 0 keeps `old`
+    for row, nsh in ((10, 2), (11, 4), (12, 8)):
+        assert (o[row] == np.where((lane % 16) >= nsh, v - nsh, 7000 + lane)).all()   # row_shr:n, `old` kept at the row's left edge
+    r16 = lane // 16
+    assert (o[13] == np.where((r16 == 1) | (r16 == 3), 100 + r16 * 16 - 1, 7000 + lane)).all()   # row_bcast:15, row_mask 0xA
+    assert (o[14] == np.where(lane >= 32, 100 + 31, 7000 + lane)).all()                        # row_bcast:31, row_mask 0xC
+    assert (o[15] == 137).all()                                                                 # v_readlane
     h = o[6:9].view(np.int16).reshape(3, 64, 2).astype(np.int64)
     assert (h[0, :, 0] == np.minimum(32767, 30000 + lane * 100)).all() and (h[0, :, 1] == np.maximum(-32768, -30000 - lane * 100)).all()
     assert (h[1, :, 0] == np.maximum(0, lane - 10)).all() and (h[1, :, 1] == np.maximum(0, 5 - lane)).all()
@@ -205,6 +211,26 @@ def test_long_queries_row_strips(gpu_ctx):
     bg = rng.integers(0, 20, size=3000, dtype=np.int8)
     preads = make_reads(rng, bg, 16, [450, 390, 600, 999, 385, 1000, 50, 300], 20, sub=0.15)
     _run(gpu_ctx, preads, [bg[:1200].copy(), bg[500:2500].copy()], blosum50(), 24, flag=2)
+
+
+@pytest.mark.parametrize("env", [{}, {"SSW_GPU_TRACE_WAVES": "4"}, {"SSW_GPU_TRACE_WAVES": "16"}, {"SSW_GPU_TRACE_LDS": "0"},
+                                 {"SSW_GPU_XLANES": "16"}, {"SSW_GPU_XR": "5"}])
+def test_long_read_traceback_teams(gpu_ctx, env, monkeypatch):
+    """long reads whose band must grow through several doublings: long indels, and unrelated reads (with 2/-2/3/1 a random
+    3-kb read still aligns over most of its length with hundreds of gaps: band rows of > 1000 cells).  Wavefront traceback
+    with 1 / 4 / 16 wavefronts per alignment, rows in LDS or HBM, resuming across scratch-negotiation rounds; the strip
+    kernel in its other geometries."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(45)
+    ref = random_ref(9000, 79, 4)
+    reads = [np.concatenate([ref[100:1300], ref[1390:2600]]),                 # 90-base deletion
+             np.concatenate([ref[3000:4100], ref[4400:5600]]),                 # 300-base deletion
+             np.concatenate([ref[6000:7000], rng.integers(0, 4, size=150, dtype=np.int8), ref[7000:8200]]),
+             rng.integers(0, 4, size=3000, dtype=np.int8), rng.integers(0, 4, size=2200, dtype=np.int8)]
+    reads += make_reads(rng, ref, 6, [2500, 1100, 3000, 1500, 2048, 1025], 4, sub=0.02, ins=0.004, dele=0.004, frac_random=0.0)
+    reads = [np.ascontiguousarray(r, dtype=np.int8) for r in reads]
+    _run(gpu_ctx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
 
 
 def test_long_queries_tiled_target(gpu_ctx):
