@@ -154,6 +154,7 @@ typedef struct {
 	/* capture mode */
 	const int32_t* qlist;
 	int32_t reverse;
+	int32_t nlist;           /* capture: entries of qlist (set by the launcher; njobs = pairs of entries) */
 	int32_t lanes;           /* lanes per chain: 16 (one DPP row, 4 jobs per wavefront) or 64 (the wavefront is one chain) */
 	int32_t window_extra;    /* reverse pass: >= 0 caps the window at rows + rows/4 + window_extra columns (retry uncapped if missed) */
 	int32_t* retry_count;    /* incremented for every alignment whose capped window missed */

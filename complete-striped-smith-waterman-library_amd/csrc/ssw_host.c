@@ -768,10 +768,11 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 								if (use_wave) {
 									/* a band row of 2b+1 cells is walked in chunks of 64 cells per wavefront: wide bands get 4 or 16 wavefronts */
 									const int32_t b2 = pend[g1].key > (1 << 20) ? (1 << 21) : 2 * pend[g1].key;
-									int wv = b2 <= 96 ? 1 : b2 <= 768 ? 4 : 16;
+									int wv = b2 <= 96 ? 1 : b2 <= 256 ? 4 : 16;
 									if (trace_waves_env > 0) wv = trace_waves_env;
-									int64_t l = ssw_shim_trace_lds_need(b2, wv), cls = 2048;
-									while (cls < l && cls < 131072) cls <<= 1;
+									/* few LDS classes (16 KiB, 64 KiB, 128 KiB): only a handful of hardware queues run side by side */
+									int64_t l = ssw_shim_trace_lds_need(b2, wv), cls = 16384;
+									while (cls < l && cls < 131072) cls <<= (cls == 16384 ? 2 : 1);
 									if (g1 > g0 && (cls != lds_l || wv != waves_l)) break;     /* pending alignments are sorted by band: classes are contiguous */
 									lds_l = cls; waves_l = wv;
 								}

@@ -703,12 +703,14 @@ template <int R, int GL> struct StripGeom {
 	static constexpr u32 PSTRIDE = (u32)C * CSTRIDE;           /* one residue */
 	static constexpr int RB = GL == 64 ? 128 : 64;             /* target ring entries (> GL + 30), + 16 mirrored */
 	static constexpr u32 RINGB = (u32)(RB + 16) * 2u;
-	static constexpr u32 EXTRA = RINGB + 2 * BND_RING_BYTES + (u32)GL * 12u;
+	static constexpr u32 EXTRA = 2 * RINGB + 2 * BND_RING_BYTES + (u32)GL * 12u;   /* capture: one target ring per query half */
 };
 
+/* profile of one strip: word = (score of query a's row, score of query b's row) against residue b; rows at or below a
+   query's padded length are dead for that half */
 template <int R, int GL>
 SSW_DEV void build_profile_strip(unsigned char* lds, u32 base, int first, int nthreads, const int8_t* mat, int n,
-                                 const int8_t* qa, int lena, int reva, const int8_t* qb, int lenb, int row0, int rows_total)
+                                 const int8_t* qa, int lena, int reva, int rowsa, const int8_t* qb, int lenb, int revb, int rowsb, int row0)
 {
 	constexpr int C = StripGeom<R, GL>::C;
 	const int total = (n + 1) * C * GL * 4;
@@ -718,11 +720,11 @@ SSW_DEV void build_profile_strip(unsigned char* lds, u32 base, int first, int nt
 		const int r = c * 4 + k, row = row0 + l * R + r;
 		u32 v;
 		if (r >= R) v = 0;
-		else if (b == n || row >= rows_total) v = DEAD2;      /* null residue / rows below the padded query */
+		else if (b == n) v = DEAD2;                            /* null residue */
 		else {
-			int lo = 0, hi = 0;
-			if (row < lena) lo = mat[b * n + (reva ? qa[lena - 1 - row] : qa[row])];
-			if (qb && row < lenb) hi = mat[b * n + qb[row]];
+			int lo = -32768, hi = -32768;                      /* rows below the padded query */
+			if (row < rowsa) lo = row < lena ? mat[b * n + (reva ? qa[lena - 1 - row] : qa[row])] : 0;
+			if (row < rowsb) hi = qb && row < lenb ? mat[b * n + (revb ? qb[lenb - 1 - row] : qb[row])] : 0;
 			v = pk_make(lo, hi);
 		}
 		lds_st32(lds, base + (u32)w * 4u, v);
@@ -732,14 +734,16 @@ SSW_DEV void build_profile_strip(unsigned char* lds, u32 base, int first, int nt
 template <int R> struct ChainState {
 	u32 H[R], E[R];
 	u32 Hlast, Fout, cmout, cm8out, hsave;
-	int best, btc, brow;
+	/* capture mode: best cell of the window per query half (value, first column, smallest row) */
+	int best[2], btc[2], brow[2];
 	/* fill mode: best cell seen by this lane, per query half (value, first column, smallest row) */
 	int tv[2], ttc[2], trow[2];
 };
 
 struct StripCtx {
-	u32 prof, ring, bin, bout, nulloff;
+	u32 prof, ring, ringb, bin, bout, nulloff;
 	int l16, ncols, nsteps, c_edge, dirstep, store_from, row0;
+	int ncols2[2], c_edge2[2];   /* capture: the two query halves have their own windows of the target */
 	bool mine, first, last;
 	const int8_t* tg;
 	u32* bnd;          /* this job's boundary records */
@@ -747,6 +751,14 @@ struct StripCtx {
 	u32 gapO2, gapE2;
 	int n;
 };
+
+template <int PS> SSW_DEV u32 strip_code_off(const StripCtx& x, int h, int tc, bool capture)
+{
+	const int nc = capture ? x.ncols2[h] : x.ncols, ce = capture ? x.c_edge2[h] : x.c_edge;
+	int code = tc < nc ? x.tg[ce + x.dirstep * tc] : x.n;
+	if (code < 0 || code > x.n) code = x.n;
+	return (u32)code * (u32)PS;
+}
 
 template <int R, bool CAPTURE, bool MASK8, int GL>
 SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st, const u32 (&m8)[R])
@@ -757,17 +769,19 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	const bool stg = l16 < 16;         /* the 16 lanes that stage the rings and flush the boundary records */
 	/* rings: target columns -GL..-1 null, 0..15 now, 16..31 in flight; boundary-in likewise */
 	lds_st16(lds, x.ring + 2u * (RB - GL + l16), x.nulloff);
-	u32 nxt = 0;
+	if (CAPTURE) lds_st16(lds, x.ringb + 2u * (RB - GL + l16), x.nulloff);
+	u32 nxt = 0, nxtb = 0;
 	if (stg) {
-		int code = l16 < x.ncols ? x.tg[x.c_edge + x.dirstep * l16] : x.n;
-		if (code < 0 || code > x.n) code = x.n;
-		const u32 off = (u32)code * G::PSTRIDE;
+		const u32 off = strip_code_off<G::PSTRIDE>(x, 0, l16, CAPTURE);
 		lds_st16(lds, x.ring + 2u * l16, off);
 		lds_st16(lds, x.ring + 2u * (RB + l16), off);
-		const int tc = 16 + l16;
-		code = tc < x.ncols ? x.tg[x.c_edge + x.dirstep * tc] : x.n;
-		if (code < 0 || code > x.n) code = x.n;
-		nxt = (u32)code * G::PSTRIDE;
+		nxt = strip_code_off<G::PSTRIDE>(x, 0, 16 + l16, CAPTURE);
+		if (CAPTURE) {
+			const u32 offb = strip_code_off<G::PSTRIDE>(x, 1, l16, true);
+			lds_st16(lds, x.ringb + 2u * l16, offb);
+			lds_st16(lds, x.ringb + 2u * (RB + l16), offb);
+			nxtb = strip_code_off<G::PSTRIDE>(x, 1, 16 + l16, true);
+		}
 	}
 	const u32x4 zero4 = { 0u, 0u, 0u, 0u };
 	const bool take = !x.first && x.mine && stg;
@@ -784,6 +798,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	st.Hlast = 0; st.Fout = 0; st.cmout = 0; st.cm8out = 0; st.hsave = 0;
 	const u32 lane_prof = x.prof + (u32)l16 * 16u;
 	u32 sbest = 0; int stc[2] = { 0x7fffffff, 0x7fffffff }, srow[2] = { 0x7fffffff, 0x7fffffff };   /* this strip's tracking */
+	if (CAPTURE) sbest = pk_subu(pk_make(st.best[0], st.best[1]), 0x00010001u);
 	wave_lds_fence();
 
 	for (int s0 = 0; s0 < x.nsteps; s0 += 16) {
@@ -791,11 +806,14 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			const int p = (s0 + 16 + l16) & (RB - 1);
 			lds_st16(lds, x.ring + 2u * p, nxt);
 			if (p < 16) lds_st16(lds, x.ring + 2u * (RB + p), nxt);
+			if (CAPTURE) {
+				lds_st16(lds, x.ringb + 2u * p, nxtb);
+				if (p < 16) lds_st16(lds, x.ringb + 2u * (RB + p), nxtb);
+			}
 			lds_st128(lds, x.bin + 16u * (p & 63), nb);
 			const int tc = s0 + 32 + l16;
-			int code = tc < x.ncols ? x.tg[x.c_edge + x.dirstep * tc] : x.n;
-			if (code < 0 || code > x.n) code = x.n;
-			nxt = (u32)code * G::PSTRIDE;
+			nxt = strip_code_off<G::PSTRIDE>(x, 0, tc, CAPTURE);
+			if (CAPTURE) nxtb = strip_code_off<G::PSTRIDE>(x, 1, tc, true);
 			nb = zero4;
 			if (take && tc < x.ncols) nb = *(const u32x4*)(x.bnd + 4 * (int64_t)tc);
 		}
@@ -809,14 +827,23 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			}
 		}
 		wave_lds_fence();
-		const u32 rp = x.ring + 2u * (u32)((s0 - l16) & (RB - 1));
+		const u32 rpo = 2u * (u32)((s0 - l16) & (RB - 1));
 #pragma unroll 2
 		for (int j = 0; j < 16; ++j) {
 			const int s = s0 + j, tc = s - l16;
-			const u32 paddr = lds_ld16(lds, rp + 2u * j) + lane_prof;
+			const u32 paddr = lds_ld16(lds, x.ring + rpo + 2u * j) + lane_prof;
 			u32x4 sc[C];
 #pragma unroll
 			for (int c = 0; c < C; ++c) sc[c] = lds_ld128(lds, paddr + G::CSTRIDE * c);
+			if (CAPTURE) {   /* the upper query half looks at its own target column */
+				const u32 paddrb = lds_ld16(lds, x.ringb + rpo + 2u * j) + lane_prof;
+#pragma unroll
+				for (int c = 0; c < C; ++c) {
+					const u32x4 sb = lds_ld128(lds, paddrb + G::CSTRIDE * c);
+#pragma unroll
+					for (int k = 0; k < 4; ++k) sc[c][k] = (sc[c][k] & 0xffffu) | (sb[k] & 0xffff0000u);
+				}
+			}
 			const u32x4 rec = lds_ld128(lds, x.bin + 16u * (s & 63));       /* what lane 0 receives from the strip above */
 			const u32 hin = xl_chain_shr1_keep<GL>(rec[0], st.Hlast);
 			u32 f = xl_chain_shr1_keep<GL>(rec[1], st.Fout);
@@ -858,12 +885,18 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 				const u32x4 o = { st.Hlast, st.Fout, st.cmout, st.cm8out };
 				lds_st128(lds, x.bout + 16u * ((s - (GL - 1)) & 63), o);
 			}
-			if (CAPTURE) {
-				const int m = (int)(lm & 0xffffu);
-				if (x.mine && tc >= 0 && tc < x.ncols && (m > st.best || (m == st.best && m > 0 && tc < st.btc))) {
-					st.best = m; st.btc = tc;
+			if (CAPTURE) {   /* rarely taken: some half reaches (at least) its best so far -- sbest holds best - 1 per half */
+				if (pk_max(sbest, lm) != sbest && x.mine && tc >= 0) {
 #pragma unroll
-					for (int k = R - 1; k >= 0; --k) if ((int)(st.H[k] & 0xffffu) == m) st.brow = x.row0 + l16 * R + k;
+					for (int h = 0; h < 2; ++h) {
+						const int m = (int)((lm >> (16 * h)) & 0xffffu);
+						if (tc < x.ncols2[h] && (m > st.best[h] || (m == st.best[h] && m > 0 && tc < st.btc[h]))) {
+							st.best[h] = m; st.btc[h] = tc;
+#pragma unroll
+							for (int k = R - 1; k >= 0; --k) if ((int)((st.H[k] >> (16 * h)) & 0xffffu) == m) st.brow[h] = x.row0 + l16 * R + k;
+						}
+					}
+					sbest = pk_subu(pk_make(st.best[0], st.best[1]), 0x00010001u);
 				}
 			}
 		}
@@ -889,6 +922,59 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	dev_fence();   /* the next strip of this chain re-reads the boundary records through HBM */
 }
 
+/* capture mode: one query half of a job (see k_chainx) */
+struct CapHalf {
+	int q, qlen, lena, rows, ncols, c_edge;
+	bool active, capped;
+	ssw_dres r;
+	const int8_t* qc;
+};
+
+SSW_DEV void cap_half_setup(CapHalf& h, const ssw_chainx_args& a, int q)
+{
+	h.q = q; h.active = false; h.capped = false; h.qlen = 0; h.lena = 0; h.rows = 0; h.ncols = 0; h.c_edge = 0; h.qc = a.qcodes;
+	if (q < 0) return;
+	h.r = a.res[q];
+	h.active = h.r.status == 0 && h.r.score1 > 0 && (a.reverse ? h.r.want_begin == 1 : !h.r.loc_done);
+	if (!h.active) return;
+	h.qc = a.qcodes + a.qoff[q];
+	h.qlen = (int)(a.qoff[q + 1] - a.qoff[q]);
+	h.lena = a.reverse ? h.r.read_end1 + 1 : h.qlen;
+	h.rows = (h.lena + 15) & ~15;
+	long long w = (long long)h.rows + ((long long)h.rows * (a.maxmat > 0 ? a.maxmat : 0) + a.gapE - 1) / (a.gapE > 0 ? a.gapE : 1) + 1;
+	if (a.gapE <= 0 || w > h.r.ref_end1) w = h.r.ref_end1;
+	if (a.reverse && a.window_extra >= 0) {   /* first try: the alignment rarely spans more than its rows + 25 % */
+		const long long cap = (long long)h.rows + h.rows / 4 + a.window_extra;
+		if (cap < w) { w = cap; h.capped = true; }
+	}
+	h.ncols = (int)w + 1;
+	h.c_edge = a.reverse ? h.r.ref_end1 : h.r.ref_end1 - (int)w;
+}
+
+/* the window's best cell of one half -> the result record (same contract as k_capture) */
+SSW_DEV void cap_half_finish(const CapHalf& h, const ssw_chainx_args& a, int bv, int bc, int br)
+{
+	const int q = h.q;
+	if (!a.reverse) {
+		a.res[q].read_end1 = (bv == h.r.score1) ? (br < h.qlen - 1 ? br : h.qlen - 1) : -1;
+		if (bv != h.r.score1) a.res[q].status = 3;
+	} else {
+		if (bv != h.r.score1 && h.capped) { if (a.retry_count) atomicAdd(a.retry_count, 1); }   /* stays want_begin == 1: rerun uncapped */
+		else if (bv != h.r.score1 && h.ncols <= h.r.ref_end1) a.res[q].status = 3;
+		else {
+			const int rb = h.r.ref_end1 - bc, qbeg = h.r.read_end1 - (br < h.lena - 1 ? br : h.lena - 1);
+			a.res[q].want_begin = 2;   /* done */
+			a.res[q].ref_begin1 = rb; a.res[q].read_begin1 = qbeg; a.res[q].rev_score = bv;
+			if (h.r.score1 > bv) a.res[q].flag = 2;
+			const int skip = (7 & a.flag) == 0 || ((2 & a.flag) != 0 && h.r.score1 < a.filters) ||
+			                 ((4 & a.flag) != 0 && (h.r.ref_end1 - rb > a.filterd || h.r.read_end1 - qbeg > a.filterd));
+			a.res[q].want_cigar = !skip;
+		}
+	}
+}
+
+/* CAPTURE = false: job = (pair, tile) of the forward fill.  CAPTURE = true: job = two queries of the list (2 job, 2 job + 1),
+   one per 16-bit half, each with its own window of the target -- locate (forward) or begin position (reverse). */
 template <int R, bool CAPTURE, int GL>
 __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 {
@@ -897,7 +983,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 	const int tid = (int)threadIdx.x, l16 = tid & (GL - 1), grp = tid / GL;
 	const u32 prof_bytes = (u32)(a.n + 1) * G::PSTRIDE;
 	StripCtx x;
-	x.prof = (u32)grp * (prof_bytes + G::EXTRA); x.ring = x.prof + prof_bytes; x.bin = x.ring + G::RINGB;
+	x.prof = (u32)grp * (prof_bytes + G::EXTRA); x.ring = x.prof + prof_bytes; x.ringb = x.ring + G::RINGB; x.bin = x.ringb + G::RINGB;
 	x.bout = x.bin + BND_RING_BYTES; x.nulloff = (u32)a.n * G::PSTRIDE;
 	const u32 red = x.bout + BND_RING_BYTES;
 	x.l16 = l16; x.gapO2 = a.gapO2; x.gapE2 = a.gapE2; x.n = a.n; x.tg = a.tgt;
@@ -905,10 +991,11 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 	const bool valid = job < a.njobs;
 
 	const int8_t *qa = a.qcodes, *qb = 0;
-	int lena = 0, lenb = 0, rev = 0, rows_total = 0, p8a = 0, p8b = 0, q = -1, qlen = 0;
-	bool active = false, capped = false;
-	ssw_dres r;
+	int lena = 0, lenb = 0, rev = 0, rowsa = 0, rowsb = 0, rows_total = 0, p8a = 0, p8b = 0;
+	bool active = false;
+	CapHalf ch[2];
 	x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0;
+	x.ncols2[0] = x.ncols2[1] = 0; x.c_edge2[0] = x.c_edge2[1] = 0;
 	if (!CAPTURE) {
 		if (valid) {
 			const int pair = job / a.ntiles, t = job - pair * a.ntiles;
@@ -916,6 +1003,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 			qa = a.qcodes + a.qoff[pr.qa]; lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
 			if (pr.qb >= 0) { qb = a.qcodes + a.qoff[pr.qb]; lenb = (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]); }
 			rows_total = ((lena > lenb ? lena : lenb) + 15) & ~15;
+			rowsa = rowsb = rows_total;
 			p8a = (lena + 7) & ~7; p8b = qb ? (lenb + 7) & ~7 : rows_total;
 			const int tile_lo = t * a.tile, tile_hi = tile_lo + a.tile < a.refLen ? tile_lo + a.tile : a.refLen;
 			const int c_first = tile_lo - a.halo > 0 ? tile_lo - a.halo : 0;
@@ -924,24 +1012,16 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 			active = true;
 		}
 	} else {
-		q = valid ? a.qlist[job] : -1;
-		if (q >= 0) { r = a.res[q]; active = r.status == 0 && r.score1 > 0 && (a.reverse ? r.want_begin == 1 : !r.loc_done); }
-		if (active) {
-			qa = a.qcodes + a.qoff[q];
-			qlen = (int)(a.qoff[q + 1] - a.qoff[q]);
-			lena = a.reverse ? r.read_end1 + 1 : qlen;
-			rev = a.reverse;
-			rows_total = (lena + 15) & ~15;
-			long long w = (long long)rows_total + ((long long)rows_total * (a.maxmat > 0 ? a.maxmat : 0) + a.gapE - 1) / (a.gapE > 0 ? a.gapE : 1) + 1;
-			if (a.gapE <= 0 || w > r.ref_end1) w = r.ref_end1;
-			if (a.reverse && a.window_extra >= 0) {   /* first try: the alignment rarely spans more than its rows + 25 % */
-				const long long cap = (long long)rows_total + rows_total / 4 + a.window_extra;
-				if (cap < w) { w = cap; capped = true; }
-			}
-			x.ncols = (int)w + 1;
-			x.c_edge = a.reverse ? r.ref_end1 : r.ref_end1 - (int)w;
-			x.dirstep = a.reverse ? -1 : 1;
-		}
+		cap_half_setup(ch[0], a, valid ? a.qlist[2 * job] : -1);
+		cap_half_setup(ch[1], a, valid && 2 * job + 1 < a.nlist ? a.qlist[2 * job + 1] : -1);
+		active = ch[0].active || ch[1].active;
+		rev = a.reverse;
+		x.dirstep = a.reverse ? -1 : 1;
+		if (ch[0].active) { qa = ch[0].qc; lena = ch[0].lena; rowsa = ch[0].rows; }
+		if (ch[1].active) { qb = ch[1].qc; lenb = ch[1].lena; rowsb = ch[1].rows; }
+		rows_total = rowsa > rowsb ? rowsa : rowsb;
+		for (int h = 0; h < 2; ++h) { x.ncols2[h] = ch[h].active ? ch[h].ncols : 0; x.c_edge2[h] = ch[h].c_edge; }
+		x.ncols = x.ncols2[0] > x.ncols2[1] ? x.ncols2[0] : x.ncols2[1];
 	}
 	const int S = active ? (rows_total + GL * R - 1) / (GL * R) : 0;
 	int maxS = S, mc = x.ncols;
@@ -954,12 +1034,12 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 	x.bnd = a.bnd + (int64_t)(valid ? job : 0) * a.bnd_stride * 4;
 
 	ChainState<R> st;
-	st.best = 0; st.btc = 0x7fffffff; st.brow = 0;
+	st.best[0] = st.best[1] = 0; st.btc[0] = st.btc[1] = 0x7fffffff; st.brow[0] = st.brow[1] = 0;
 	st.tv[0] = st.tv[1] = 0; st.ttc[0] = st.ttc[1] = 0x7fffffff; st.trow[0] = st.trow[1] = 0x7fffffff;
 	u32 m8[R];
 	for (int sidx = 0; sidx < maxS; ++sidx) {
 		x.mine = sidx < S; x.first = sidx == 0; x.last = sidx == S - 1; x.row0 = sidx * GL * R;
-		build_profile_strip<R, GL>(lds, x.prof, l16, GL, a.mat, a.n, qa, lena, rev, qb, lenb, x.row0, x.mine ? rows_total : 0);
+		build_profile_strip<R, GL>(lds, x.prof, l16, GL, a.mat, a.n, qa, lena, rev, x.mine ? rowsa : 0, qb, lenb, rev, x.mine ? rowsb : 0, x.row0);
 		bool need_mask = false;
 		if (!CAPTURE) {
 			need_mask = x.mine && x.last && (p8a < rows_total || p8b < rows_total);
@@ -995,32 +1075,20 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 		}
 	}
 	if (CAPTURE) {
-		lds_st32(lds, red + 12u * l16, (u32)st.best);
-		lds_st32(lds, red + 12u * l16 + 4, (u32)st.btc);
-		lds_st32(lds, red + 12u * l16 + 8, (u32)st.brow);
-		wave_lds_fence();
-		if (l16 == 0 && active) {
-			int bv = 0, bc = 0x7fffffff, br = 0;
-			for (int k = 0; k < GL; ++k) {
-				const int v = (int)lds_ld32(lds, red + 12u * k), c = (int)lds_ld32(lds, red + 12u * k + 4), w = (int)lds_ld32(lds, red + 12u * k + 8);
-				if (v > bv || (v == bv && v > 0 && (c < bc || (c == bc && w < br)))) { bv = v; bc = c; br = w; }
-			}
-			if (!a.reverse) {
-				a.res[q].read_end1 = (bv == r.score1) ? (br < qlen - 1 ? br : qlen - 1) : -1;
-				if (bv != r.score1) a.res[q].status = 3;
-			} else {
-				if (bv != r.score1 && capped) { if (a.retry_count) atomicAdd(a.retry_count, 1); }   /* stays want_begin == 1: rerun uncapped */
-				else if (bv != r.score1 && x.ncols <= r.ref_end1) a.res[q].status = 3;
-				else {
-					const int rb = r.ref_end1 - bc, qbeg = r.read_end1 - (br < lena - 1 ? br : lena - 1);
-					a.res[q].want_begin = 2;   /* done */
-					a.res[q].ref_begin1 = rb; a.res[q].read_begin1 = qbeg; a.res[q].rev_score = bv;
-					if (r.score1 > bv) a.res[q].flag = 2;
-					const int skip = (7 & a.flag) == 0 || ((2 & a.flag) != 0 && r.score1 < a.filters) ||
-					                 ((4 & a.flag) != 0 && (r.ref_end1 - rb > a.filterd || r.read_end1 - qbeg > a.filterd));
-					a.res[q].want_cigar = !skip;
+		for (int h = 0; h < 2; ++h) {
+			lds_st32(lds, red + 12u * l16, (u32)st.best[h]);
+			lds_st32(lds, red + 12u * l16 + 4, (u32)st.btc[h]);
+			lds_st32(lds, red + 12u * l16 + 8, (u32)st.brow[h]);
+			wave_lds_fence();
+			if (l16 == 0 && ch[h].active) {
+				int bv = 0, bc = 0x7fffffff, br = 0;
+				for (int k = 0; k < GL; ++k) {
+					const int v = (int)lds_ld32(lds, red + 12u * k), c = (int)lds_ld32(lds, red + 12u * k + 4), w = (int)lds_ld32(lds, red + 12u * k + 8);
+					if (v > bv || (v == bv && v > 0 && (c < bc || (c == bc && w < br)))) { bv = v; bc = c; br = w; }
 				}
+				cap_half_finish(ch[h], a, bv, bc, br);
 			}
+			wave_lds_fence();
 		}
 	}
 }
@@ -1887,6 +1955,7 @@ extern "C" int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* s
 extern "C" int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args* a, void* stream)
 {
 	ssw_chainx_args args = *a;
+	if (capture) { args.nlist = args.njobs; args.njobs = (args.njobs + 1) / 2; }   /* two queries of the list per job */
 	if (args.njobs <= 0) return 0;
 	if (args.lanes == 64) {   /* the whole wavefront is one chain: one job per workgroup */
 		const int grid = args.njobs;

@@ -91,6 +91,23 @@ def test_long_queries_row_strips(ectx):
     _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
 
 
+@pytest.mark.parametrize("env", [{}, {"SSW_GPU_XR": "2"}, {"SSW_GPU_XLANES": "16"}, {"SSW_GPU_NO_TRACK": "1"}])
+def test_long_queries_paired_window_passes(ectx, env, monkeypatch):
+    """locate / reverse passes of long queries run two queries per chain (one per 16-bit half), each with its own window of
+    the target: same bucket (padded length), different positions, lengths, window sizes; odd count; an unrelated read"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(83)
+    ref = random_ref(2500, 29, 4, 0.005)
+    lens = [400, 386, 399, 393, 388, 397, 391]
+    reads = make_reads(rng, ref, 7, lens, 4, sub=0.04, ins=0.01, dele=0.01, frac_random=0.0)
+    reads[3] = np.ascontiguousarray(np.concatenate([ref[40:240], ref[700:893]]))      # long deletion: wide reverse window (capped window misses)
+    reads[5] = rng.integers(0, 4, size=397, dtype=np.int8)                             # unrelated read
+    reads[6] = np.ascontiguousarray(ref[2500 - 391:])                                  # ends at the last target base
+    for flag in (0, 1, 2):
+        _run(ectx, reads, [ref, ref[:900].copy()], dna_matrix(2, 2), 5, flag=flag)
+
+
 @pytest.mark.parametrize("env", [{"SSW_GPU_XR": "1"}, {"SSW_GPU_XR": "3"}, {"SSW_GPU_XLANES": "16"}])
 def test_long_queries_strip_geometries(ectx, env, monkeypatch):
     """the strip kernel in its other shapes: many thin 64-lane strips (64 / 192 rows) and the 16-lane chains"""
