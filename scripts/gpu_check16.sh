@@ -1,0 +1,9 @@
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+tail -n 5 gpurun_out/pytest_gpu.log
+C4="--reads 10000 --read-len 10000 --ref-len 100000 --flag 2 --sub 0.01 --indel 0.0025 --mask-len 5000 --steps 1 --warmup 0 --cpu-sample 64"
+mkdir -p gpurun_out/prof_c4
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c4/trace -o bench -- python bench.py $C4 > gpurun_out/prof_c4/trace.log 2>&1
