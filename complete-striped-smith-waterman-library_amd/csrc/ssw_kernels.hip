@@ -701,8 +701,8 @@ template <int R, int GL> struct StripGeom {
 	static constexpr int C = (R + 3) / 4;
 	static constexpr u32 CSTRIDE = (u32)GL * 16u;              /* one 16-byte chunk of every lane */
 	static constexpr u32 PSTRIDE = (u32)C * CSTRIDE;           /* one residue */
-	static constexpr int RB = GL == 64 ? 128 : 64;             /* target ring entries (> GL + 30), + 16 mirrored */
-	static constexpr u32 RINGB = (u32)(RB + 16) * 2u;
+	static constexpr int RB = GL == 64 ? 128 : 64;             /* target ring entries (> GL + 30), + 32 mirrored */
+	static constexpr u32 RINGB = (u32)(RB + 32) * 2u;
 	static constexpr u32 EXTRA = 2 * RINGB + 2 * BND_RING_BYTES + (u32)GL * 12u;   /* capture: one target ring per query half */
 };
 
@@ -800,15 +800,34 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	u32 sbest = 0; int stc[2] = { 0x7fffffff, 0x7fffffff }, srow[2] = { 0x7fffffff, 0x7fffffff };   /* this strip's tracking */
 	if (CAPTURE) sbest = pk_subu(pk_make(st.best[0], st.best[1]), 0x00010001u);
 	wave_lds_fence();
+	/* software pipeline of the LDS reads (two waves per SIMD do not hide their latency): the scores and the boundary record
+	   of step s+1 and the ring entry of step s+2 are requested before step s computes.  Ring entries are staged a chunk ahead
+	   and the mirror is 32 entries deep, so reading up to 17 entries past a chunk's first one is safe. */
+	u32x4 sc_n[C], sb_n[C], rec_n;
+	u32 pa_n, pb_n = 0;
+	{
+		const u32 r0 = 2u * (u32)((0 - l16) & (RB - 1));
+		const u32 pa0 = lds_ld16(lds, x.ring + r0) + lane_prof;
+#pragma unroll
+		for (int c = 0; c < C; ++c) sc_n[c] = lds_ld128(lds, pa0 + G::CSTRIDE * c);
+		if (CAPTURE) {
+			const u32 pb0 = lds_ld16(lds, x.ringb + r0) + lane_prof;
+#pragma unroll
+			for (int c = 0; c < C; ++c) sb_n[c] = lds_ld128(lds, pb0 + G::CSTRIDE * c);
+			pb_n = lds_ld16(lds, x.ringb + r0 + 2u) + lane_prof;
+		}
+		rec_n = lds_ld128(lds, x.bin);
+		pa_n = lds_ld16(lds, x.ring + r0 + 2u) + lane_prof;
+	}
 
 	for (int s0 = 0; s0 < x.nsteps; s0 += 16) {
 		if (stg) {   /* stage [s0+16, s0+32), prefetch [s0+32, s0+48) */
 			const int p = (s0 + 16 + l16) & (RB - 1);
 			lds_st16(lds, x.ring + 2u * p, nxt);
-			if (p < 16) lds_st16(lds, x.ring + 2u * (RB + p), nxt);
+			if (p < 32) lds_st16(lds, x.ring + 2u * (RB + p), nxt);
 			if (CAPTURE) {
 				lds_st16(lds, x.ringb + 2u * p, nxtb);
-				if (p < 16) lds_st16(lds, x.ringb + 2u * (RB + p), nxtb);
+				if (p < 32) lds_st16(lds, x.ringb + 2u * (RB + p), nxtb);
 			}
 			lds_st128(lds, x.bin + 16u * (p & 63), nb);
 			const int tc = s0 + 32 + l16;
@@ -831,20 +850,26 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 #pragma unroll 2
 		for (int j = 0; j < 16; ++j) {
 			const int s = s0 + j, tc = s - l16;
-			const u32 paddr = lds_ld16(lds, x.ring + rpo + 2u * j) + lane_prof;
 			u32x4 sc[C];
 #pragma unroll
-			for (int c = 0; c < C; ++c) sc[c] = lds_ld128(lds, paddr + G::CSTRIDE * c);
+			for (int c = 0; c < C; ++c) sc[c] = sc_n[c];
 			if (CAPTURE) {   /* the upper query half looks at its own target column */
-				const u32 paddrb = lds_ld16(lds, x.ringb + rpo + 2u * j) + lane_prof;
 #pragma unroll
-				for (int c = 0; c < C; ++c) {
-					const u32x4 sb = lds_ld128(lds, paddrb + G::CSTRIDE * c);
+				for (int c = 0; c < C; ++c)
 #pragma unroll
-					for (int k = 0; k < 4; ++k) sc[c][k] = (sc[c][k] & 0xffffu) | (sb[k] & 0xffff0000u);
-				}
+					for (int k = 0; k < 4; ++k) sc[c][k] = (sc[c][k] & 0xffffu) | (sb_n[c][k] & 0xffff0000u);
 			}
-			const u32x4 rec = lds_ld128(lds, x.bin + 16u * (s & 63));       /* what lane 0 receives from the strip above */
+			const u32x4 rec = rec_n;       /* what lane 0 receives from the strip above */
+			/* requests for the next steps */
+#pragma unroll
+			for (int c = 0; c < C; ++c) sc_n[c] = lds_ld128(lds, pa_n + G::CSTRIDE * c);
+			if (CAPTURE) {
+#pragma unroll
+				for (int c = 0; c < C; ++c) sb_n[c] = lds_ld128(lds, pb_n + G::CSTRIDE * c);
+				pb_n = lds_ld16(lds, x.ringb + rpo + 2u * (j + 2)) + lane_prof;
+			}
+			rec_n = lds_ld128(lds, x.bin + 16u * ((s + 1) & 63));
+			pa_n = lds_ld16(lds, x.ring + rpo + 2u * (j + 2)) + lane_prof;
 			const u32 hin = xl_chain_shr1_keep<GL>(rec[0], st.Hlast);
 			u32 f = xl_chain_shr1_keep<GL>(rec[1], st.Fout);
 			u32 cm = xl_chain_shr1_keep<GL>(rec[2], st.cmout);
