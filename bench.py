@@ -239,6 +239,13 @@ def main(argv=None):
         # readLen + n^2 query/matrix bytes, 4*refLen column-maximum bytes written (2 rule sets x u16), 40 B result
         aln_per_launch = args.reads * args.steps / max(1, fill_launches)
         bytes_per_aln = args.ref_len + args.read_len + 25 + 40 + 4 * args.ref_len
+        if args.read_len <= 384:
+            fill_kernel = "k_fill<%d>" % ((args.read_len + 15) // 16)
+        else:   # long queries: row strips of 64 x R rows (csrc/ssw_host.c); boundary records of 16 B per column and pair between strips
+            p16 = (args.read_len + 15) // 16 * 16
+            strips = (p16 + 64 * 12 - 1) // (64 * 12)
+            fill_kernel = "k_chainx<%d, false, 64> x %d strips" % ((p16 + 64 * strips - 1) // (64 * strips), strips)
+            bytes_per_aln += 16 * args.ref_len * (strips - 1)      # written once, read once, shared by the two queries of a pair
         achieved_gbs = aln_per_launch * bytes_per_aln / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         # VALU view: 9 packed instructions per (row, column) for two queries -> 4.5 lane-ops per evaluated cell
         valu_ops = fill_cells * 4.5
@@ -265,7 +272,7 @@ def main(argv=None):
             "phases_ms_per_step": {"fill": round(fill_ms / args.steps, 3), "locate": round(phase["locate_ms"] / args.steps, 3),
                                    "trace": round(phase["trace_ms"] / args.steps, 3),
                                    "reduce_and_copies": round(phase["reduce_ms"] / args.steps, 3)},
-            "roofline": {"bound": "hbm", "kernel": "k_fill<%d>" % ((args.read_len + 15) // 16), "achieved": round(achieved_gbs, 2),
+            "roofline": {"bound": "hbm", "kernel": fill_kernel, "achieved": round(achieved_gbs, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_note": "GB/s from rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE of this kernel (profiles/round1_traffic.json), per launch",
                          "launch_ms": round(launch_ms, 3), "launches": int(fill_launches),

@@ -113,6 +113,31 @@ def test_random_parameter_sweep(gpu_ctx):
              maskLen=int(rng.choice([-1, -1, 15, 10, 40])), ss=int(rng.choice([2, 2, 2, 0, 1])))
 
 
+def test_random_parameter_sweep_long_queries(gpu_ctx):
+    """the same sweep for queries above 384 residues (strip kernel, paired window passes, wavefront traceback): random
+    matrices, gap penalties, flags, filters, mask lengths, score sizes; DNA and protein; several reads share a bucket"""
+    rng = np.random.default_rng(77)
+    for it in range(14):
+        kind = "dna" if rng.random() < 0.65 else "aa"
+        nq = int(rng.integers(2, 14))
+        refLen = int(rng.integers(1500, 7000))
+        if kind == "dna":
+            n, nc, mat = 5, 4, dna_matrix(int(rng.integers(1, 4)), int(rng.integers(1, 6)))
+            ref = random_ref(refLen, int(rng.integers(1 << 30)), 4, 0.01)
+        else:
+            n, nc, mat = 24, 20, blosum50()
+            ref = rng.integers(0, 20, size=refLen, dtype=np.int8)
+        gapE = int(rng.integers(1, 4)); gapO = gapE + int(rng.integers(1, 6))
+        base = int(rng.integers(385, 1400))
+        lens = [base + int(rng.integers(0, 14)) for _ in range(nq)]            # mostly one or two buckets: pairs in the window passes
+        if it % 3 == 0:
+            lens[0] = int(rng.integers(1025, 2600))                             # wavefront traceback for the whole batch
+        reads = make_reads(rng, ref, nq, lens, nc, sub=0.05 if kind == "dna" else 0.2, ins=0.01, dele=0.01, frac_random=0.15)
+        _run(gpu_ctx, reads, [ref], mat, n, gapO, gapE, flag=int(rng.choice([0, 1, 2, 2, 9, 15, 6])),
+             filters=int(rng.choice([0, 0, 100, 600])), filterd=int(rng.choice([0, 500, 100000])),
+             maskLen=int(rng.choice([-1, -1, 15, 200])), ss=int(rng.choice([2, 2, 0, 1])))
+
+
 def test_protein_db_multiple_targets(gpu_ctx):
     """BASELINE config 5 shape at test size: BLOSUM50, 24-letter profile, several targets per call"""
     rng = np.random.default_rng(9)
