@@ -797,7 +797,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	for (int r = 0; r < R; ++r) { st.H[r] = 0; st.E[r] = 0; }
 	st.Hlast = 0; st.Fout = 0; st.cmout = 0; st.cm8out = 0; st.hsave = 0;
 	const u32 lane_prof = x.prof + (u32)l16 * 16u;
-	u32 sbest = 0; int stc[2] = { 0x7fffffff, 0x7fffffff }, srow[2] = { 0x7fffffff, 0x7fffffff };   /* this strip's tracking */
+	u32 sbest = 0; int sv[2] = { 0, 0 }, stc[2] = { 0x7fffffff, 0x7fffffff }, srow[2] = { 0x7fffffff, 0x7fffffff };   /* this strip's tracking */
 	if (CAPTURE) sbest = pk_subu(pk_make(st.best[0], st.best[1]), 0x00010001u);
 	wave_lds_fence();
 	/* software pipeline of the LDS reads (two waves per SIMD do not hide their latency): the scores and the boundary record
@@ -885,27 +885,31 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 				const u32 t0 = pk_subu(h0, x.gapO2);
 				st.E[r] = pk_max(pk_subu(st.E[r], x.gapE2), t0);
 				f = pk_max(pk_subu(f, x.gapE2), t0);
-				if (CAPTURE) lm = pk_max(lm, h); else cm = pk_max(cm, h);
+				lm = pk_max(lm, h);
 				if (MASK8) cm8 = pk_max(cm8, h & m8[r]);
 				st.H[r] = h;
 				d = hold;
 			}
-			st.hsave = hin; st.Hlast = st.H[R - 1]; st.Fout = f; st.cmout = cm; st.cm8out = MASK8 ? cm8 : cm;
-			if (!CAPTURE) {   /* the first lane (top-down) whose running maximum reaches a new high holds its smallest row */
-				const u32 nb = pk_max(sbest, cm);
-				if (nb != sbest && x.mine && tc >= 0 && tc < x.ncols) {
+			if (!CAPTURE) {
+				/* best-cell tracking: `pre` = everything this lane knows of rows above and of earlier columns (its running
+				   record and this column's maximum of the rows above).  Only the lane whose OWN rows beat that -- the lane
+				   holding the new record cell, not every lane below it -- takes the branch. */
+				const u32 pre = pk_max(sbest, cm);
+				cm = pk_max(cm, lm);
+				sbest = pk_max(pre, lm);
+				if (sbest != pre && x.mine && tc >= 0 && tc < x.ncols) {
 #pragma unroll
 					for (int h = 0; h < 2; ++h) {
-						const int nv = (int)((nb >> (16 * h)) & 0xffffu), ov = (int)((sbest >> (16 * h)) & 0xffffu);
+						const int nv = (int)((sbest >> (16 * h)) & 0xffffu), ov = (int)((pre >> (16 * h)) & 0xffffu);
 						if (nv > ov) {
-							stc[h] = tc; srow[h] = 0x7fffffff;
+							sv[h] = nv; stc[h] = tc; srow[h] = 0x7fffffff;
 #pragma unroll
 							for (int k = R - 1; k >= 0; --k) if ((int)((st.H[k] >> (16 * h)) & 0xffffu) == nv) srow[h] = x.row0 + l16 * R + k;
 						}
 					}
-					sbest = nb;
 				}
 			}
+			st.hsave = hin; st.Hlast = st.H[R - 1]; st.Fout = f; st.cmout = cm; st.cm8out = MASK8 ? cm8 : cm;
 			if (l16 == GL - 1) {
 				const u32x4 o = { st.Hlast, st.Fout, st.cmout, st.cm8out };
 				lds_st128(lds, x.bout + 16u * ((s - (GL - 1)) & 63), o);
@@ -938,7 +942,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	if (!CAPTURE) {   /* merge the strip's best cell into the lane's: higher value, then earlier column, then smaller row */
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
-			const int v = (int)((sbest >> (16 * h)) & 0xffffu);
+			const int v = sv[h];      /* the last record this lane set itself in this strip */
 			if (v > st.tv[h] || (v == st.tv[h] && v > 0 && (stc[h] < st.ttc[h] || (stc[h] == st.ttc[h] && srow[h] < st.trow[h])))) {
 				st.tv[h] = v; st.ttc[h] = stc[h]; st.trow[h] = srow[h];
 			}

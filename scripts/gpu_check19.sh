@@ -1,0 +1,10 @@
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+tail -n 5 gpurun_out/pytest_gpu.log
+C4="--reads 10000 --read-len 10000 --ref-len 100000 --flag 2 --sub 0.01 --indel 0.0025 --mask-len 5000 --steps 1 --warmup 0 --cpu-sample 16"
+timeout 300 python bench.py $C4 > gpurun_out/c4_a.log 2>&1; echo "rc=$?" >> gpurun_out/c4_a.log
+timeout 300 python bench.py --reads 10000 --read-len 10000 --ref-len 20000 --flag 2 --sub 0.01 --indel 0.0025 --mask-len 5000 --steps 1 --warmup 0 --cpu-sample 16 > gpurun_out/c4_ref20k.log 2>&1; echo "rc=$?" >> gpurun_out/c4_ref20k.log
+SSW_GPU_NO_TRACK=1 timeout 300 python bench.py $C4 > gpurun_out/c4_notrack.log 2>&1; echo "rc=$?" >> gpurun_out/c4_notrack.log
