@@ -264,6 +264,8 @@ void  ssw_shim_stream_destroy(void* stream);
 int   ssw_shim_stream_sync(void* stream);
 void* ssw_shim_malloc(size_t bytes);
 void  ssw_shim_free(void* p);
+void* ssw_shim_host_alloc(size_t bytes);   /* page-locked host memory */
+void  ssw_shim_host_free(void* p);
 int   ssw_shim_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int   ssw_shim_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int   ssw_shim_memset(void* dst, int value, size_t bytes, void* stream);

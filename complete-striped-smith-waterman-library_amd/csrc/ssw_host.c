@@ -906,6 +906,22 @@ done:
 	return rc;
 }
 
+void* ssw_gpu_host_alloc(ssw_gpu_ctx* c, size_t bytes)
+{
+	if (!c) return 0;
+	ssw_shim_set_device(c->device);
+	void* p = ssw_shim_host_alloc(bytes);
+	if (!p) fail(c, "page-locked host allocation failed: %s", ssw_shim_last_error());
+	return p;
+}
+
+void ssw_gpu_host_free(ssw_gpu_ctx* c, void* p)
+{
+	if (!c || !p) return;
+	ssw_shim_set_device(c->device);
+	ssw_shim_host_free(p);
+}
+
 int ssw_gpu_selftest_lanes(ssw_gpu_ctx* c, uint32_t* out1024)
 {
 	if (!c || !out1024) return -1;

@@ -2097,6 +2097,13 @@ extern "C" void* ssw_shim_malloc(size_t bytes)
 	return p;
 }
 extern "C" void ssw_shim_free(void* p) { if (p) (void)hipFree(p); }
+extern "C" void* ssw_shim_host_alloc(size_t bytes)
+{
+	void* p = 0;
+	if (shim_check(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault), "hipHostMalloc")) return 0;
+	return p;
+}
+extern "C" void ssw_shim_host_free(void* p) { if (p) (void)hipHostFree(p); }
 extern "C" int ssw_shim_h2d(void* d, const void* s, size_t n, void* st) { return n ? shim_check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st), "hipMemcpy H2D") : 0; }
 extern "C" int ssw_shim_d2h(void* d, const void* s, size_t n, void* st) { return n ? shim_check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st), "hipMemcpy D2H") : 0; }
 extern "C" int ssw_shim_memset(void* d, int v, size_t n, void* st) { return n ? shim_check(hipMemsetAsync(d, v, n, (hipStream_t)st), "hipMemset") : 0; }

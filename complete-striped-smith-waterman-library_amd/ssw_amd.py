@@ -96,6 +96,10 @@ def load(path=None):
     L.ssw_gpu_align_batch.restype = C.c_int
     L.ssw_gpu_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.ssw_gpu_last_timing.restype = C.c_int
+    L.ssw_gpu_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    L.ssw_gpu_host_alloc.restype = C.c_void_p
+    L.ssw_gpu_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.ssw_gpu_host_free.restype = None
     L.ssw_gpu_selftest_lanes.argtypes = [C.c_void_p, _u32p]
     L.ssw_gpu_selftest_lanes.restype = C.c_int
     L.ssw_gpu_valu_probe.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
@@ -141,6 +145,7 @@ class Context(object):
 
     def __init__(self, device=0, lib=None):
         self.lib = lib if lib is not None and not isinstance(lib, str) else load(lib)
+        self._pinned = []
         self.h = self.lib.ssw_gpu_open(device)
         if not self.h:
             raise RuntimeError("ssw_gpu_open: " + self.lib.ssw_gpu_last_error(None).decode())
@@ -152,13 +157,19 @@ class Context(object):
         return Seqs(self, seqs)
 
     def align_batch(self, queries, targets, mat, n, gapO=3, gapE=1, flag=0, filters=0, filterd=0, maskLen=-1,
-                    score_size=2, target_first=0, target_count=None, want_cigar=True, mark_mismatch=False):
-        """-> (numpy record array [nq, nt] of RESULT_DTYPE, numpy uint32 CIGAR pool)."""
+                    score_size=2, target_first=0, target_count=None, want_cigar=True, mark_mismatch=False, out=None):
+        """-> (numpy record array [nq, nt] of RESULT_DTYPE, numpy uint32 CIGAR pool).  `out`: a result array to fill
+        (e.g. page-locked, from result_array(): large database searches download at PCIe rate only into pinned pages)."""
         if target_count is None:
             target_count = targets.count - target_first
         mat = np.ascontiguousarray(mat, dtype=np.int8)
         p = Params(mat.ctypes.data_as(_i8p), n, gapO, gapE, flag, filters, filterd, maskLen, score_size, 1 if mark_mismatch else 0)
-        res = np.zeros((queries.count, target_count), dtype=RESULT_DTYPE)
+        if out is None:
+            res = np.zeros((queries.count, target_count), dtype=RESULT_DTYPE)
+        else:
+            res = out
+            if res.dtype != RESULT_DTYPE or res.shape != (queries.count, target_count) or not res.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be a C-contiguous [nq, nt] array of RESULT_DTYPE")
         pool = _u32p()
         words = C.c_int64(0)
         rc = self.lib.ssw_gpu_align_batch(self.h, queries.h, targets.h, target_first, target_count, C.byref(p),
@@ -173,6 +184,16 @@ class Context(object):
         if want_cigar and pool:
             C.CDLL(None).free(pool)
         return res, cig
+
+    def result_array(self, nq, nt):
+        """[nq, nt] result records in page-locked host memory (freed with the context)"""
+        nbytes = int(nq) * int(nt) * RESULT_DTYPE.itemsize
+        p = self.lib.ssw_gpu_host_alloc(self.h, nbytes)
+        if not p:
+            raise RuntimeError("ssw_gpu_host_alloc: " + self.error())
+        self._pinned.append(p)
+        buf = (C.c_char * nbytes).from_address(p)
+        return np.frombuffer(buf, dtype=RESULT_DTYPE).reshape(int(nq), int(nt))
 
     def timing(self):
         t = Timing()
@@ -190,5 +211,8 @@ class Context(object):
 
     def close(self):
         if self.h:
+            for p in self._pinned:
+                self.lib.ssw_gpu_host_free(self.h, p)
+            self._pinned = []
             self.lib.ssw_gpu_close(self.h)
             self.h = None

@@ -17,6 +17,7 @@
 #ifndef SSW_GPU_H
 #define SSW_GPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 #include "ssw.h"
 
@@ -102,6 +103,11 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* queries, const ssw
                         ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words);
 
 int ssw_gpu_last_timing(const ssw_gpu_ctx* ctx, ssw_gpu_timing* out);
+
+/* Page-locked host memory for result arrays (optional): a database search returns nq x nt records, and their download
+   runs at PCIe rate only into pinned pages.  Any host pointer is accepted by ssw_gpu_align_batch; this one is faster. */
+void* ssw_gpu_host_alloc(ssw_gpu_ctx* ctx, size_t bytes);
+void ssw_gpu_host_free(ssw_gpu_ctx* ctx, void* p);
 
 /* Diagnostics.  ssw_gpu_selftest_lanes: 16 x 64 words produced by the cross-lane / packed-arithmetic primitives the
    kernels are written in (checked by tests against the ISA semantics).  ssw_gpu_valu_probe: measured issue rate of

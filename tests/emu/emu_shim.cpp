@@ -19,6 +19,8 @@ void ssw_shim_stream_destroy(void*) {}
 int ssw_shim_stream_sync(void*) { return 0; }
 void* ssw_shim_malloc(size_t bytes) { void* p = malloc(bytes ? bytes : 16); if (p) memset(p, 0xEE, bytes); return p; }
 void ssw_shim_free(void* p) { free(p); }
+void* ssw_shim_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 16); }
+void ssw_shim_host_free(void* p) { free(p); }
 int ssw_shim_h2d(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); return 0; }
 int ssw_shim_d2h(void* d, const void* s, size_t n, void*) { memcpy(d, s, n); return 0; }
 int ssw_shim_memset(void* d, int v, size_t n, void*) { memset(d, v, n); return 0; }
