@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 	for (int r = 0; r < R; ++r) { H[r] = 0; E[r] = 0; }
 	u32 Hlast = 0, Fout = 0, cmout = 0, ck = 0, hsave = 0;
 	u32 best = 0;                                   /* packed: highest running column maximum this lane has seen */
-	int btc[2] = { 0x7fffffff, 0x7fffffff }, brow[2] = { 0x7fffffff, 0x7fffffff };
+	int bval[2] = { 0, 0 }, btc[2] = { 0x7fffffff, 0x7fffffff }, brow[2] = { 0x7fffffff, 0x7fffffff };   /* the last record this lane set itself */
 	const u32 lane_prof = (u32)l16 * 16u;
 
 	for (int s0 = 0; s0 < nsteps; s0 += 16) {
@@ -336,28 +336,32 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			u32 f = xl_row_shr1_zero(Fout);
 			const u32 x = xl_row_ror<1>(cmout);
 			const u32 x8 = MASKED ? xl_row_ror<1>(ck) : xl_row_ror<16 - G::TAP>(ck);   /* MASKED: ck carries the masked chain */
-			u32 cm = x, cm8 = x8;
+			u32 cin = x, cin8 = x8;      /* this column's maxima of the rows above (lane 0 starts a new column) */
 			if (l16 == 0) {
 				lds_st32(lds, ob16 + 4u * j, x);
 				lds_st32(lds, ob8 + 4u * j, x8);
-				cm = 0; cm8 = 0;
+				cin = 0; cin8 = 0;
 			}
-			if (MASKED) { chain_rows_masked<R>(sc, H, E, hsave, f, cm, cm8, (const u32(&)[R])m8, a.gapO2, a.gapE2); ck = cm8; }
-			else chain_rows<R, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);
+			u32 lm = 0, lm8 = 0;         /* maxima of this lane's own rows */
+			if (MASKED) chain_rows_masked<R>(sc, H, E, hsave, f, lm, lm8, (const u32(&)[R])m8, a.gapO2, a.gapE2);
+			else chain_rows<R, true>(sc, H, E, hsave, f, lm, lm8, a.gapO2, a.gapE2);
+			const u32 cm = pk_max(cin, lm);
+			ck = pk_max(MASKED ? cin8 : cin, lm8);     /* unmasked: the 8-bit-rule maximum is the same chain, tapped after K8 rows of lane TAP */
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
-			/* best cell: the first lane (top-down) whose running maximum reaches a new high holds its smallest row */
-			const u32 nb = pk_max(best, cm);
-			if (nb != best && tc >= 0 && tc < ncols) {
+			/* best cell: `pre` = the lane's running record and the rows above in this column; only the lane whose OWN rows
+			   beat it -- the lane holding the new record cell, not every lane below -- takes the branch */
+			const u32 pre = pk_max(best, cin);
+			best = pk_max(pre, lm);
+			if (best != pre && tc >= 0 && tc < ncols) {
 #pragma unroll
 				for (int h = 0; h < 2; ++h) {
-					const int nv = (int)((nb >> (16 * h)) & 0xffffu), ov = (int)((best >> (16 * h)) & 0xffffu);
+					const int nv = (int)((best >> (16 * h)) & 0xffffu), ov = (int)((pre >> (16 * h)) & 0xffffu);
 					if (nv > ov) {
-						btc[h] = tc; brow[h] = 0x7fffffff;
+						bval[h] = nv; btc[h] = tc; brow[h] = 0x7fffffff;
 #pragma unroll
 						for (int k = R - 1; k >= 0; --k) if ((int)((H[k] >> (16 * h)) & 0xffffu) == nv) brow[h] = l16 * R + k;
 					}
 				}
-				best = nb;
 			}
 		}
 	}
@@ -377,7 +381,7 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 		const int q = h ? pr.qb : pr.qa;
 		if (q < 0) continue;                         /* uniform in the workgroup */
 		const int len = h ? lenb : lena;
-		const int myv = (int)((best >> (16 * h)) & 0xffffu);
+		const int myv = bval[h];
 		lds_st32(lds, red + 16u * l16, (u32)myv);
 		lds_st32(lds, red + 16u * l16 + 4, (u32)btc[h]);
 		lds_st32(lds, red + 16u * l16 + 8, (u32)brow[h]);
