@@ -336,22 +336,19 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			u32 f = xl_row_shr1_zero(Fout);
 			const u32 x = xl_row_ror<1>(cmout);
 			const u32 x8 = MASKED ? xl_row_ror<1>(ck) : xl_row_ror<16 - G::TAP>(ck);   /* MASKED: ck carries the masked chain */
-			u32 cin = x, cin8 = x8;      /* this column's maxima of the rows above (lane 0 starts a new column) */
+			u32 cm = x, cm8 = x8;        /* this column's maxima of the rows above (lane 0 starts a new column) */
 			if (l16 == 0) {
 				lds_st32(lds, ob16 + 4u * j, x);
 				lds_st32(lds, ob8 + 4u * j, x8);
-				cin = 0; cin8 = 0;
+				cm = 0; cm8 = 0;
 			}
-			u32 lm = 0, lm8 = 0;         /* maxima of this lane's own rows */
-			if (MASKED) chain_rows_masked<R>(sc, H, E, hsave, f, lm, lm8, (const u32(&)[R])m8, a.gapO2, a.gapE2);
-			else chain_rows<R, true>(sc, H, E, hsave, f, lm, lm8, a.gapO2, a.gapE2);
-			const u32 cm = pk_max(cin, lm);
-			ck = pk_max(MASKED ? cin8 : cin, lm8);     /* unmasked: the 8-bit-rule maximum is the same chain, tapped after K8 rows of lane TAP */
-			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
 			/* best cell: `pre` = the lane's running record and the rows above in this column; only the lane whose OWN rows
-			   beat it -- the lane holding the new record cell, not every lane below -- takes the branch */
-			const u32 pre = pk_max(best, cin);
-			best = pk_max(pre, lm);
+			   beat it -- the lane holding the new record cell, not every lane below -- takes the branch further down */
+			const u32 pre = pk_max(best, cm);
+			if (MASKED) { chain_rows_masked<R>(sc, H, E, hsave, f, cm, cm8, (const u32(&)[R])m8, a.gapO2, a.gapE2); ck = cm8; }
+			else chain_rows<R, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);
+			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
+			best = pk_max(best, cm);     /* = max(pre, own rows) */
 			if (best != pre && tc >= 0 && tc < ncols) {
 #pragma unroll
 				for (int h = 0; h < 2; ++h) {
@@ -880,6 +877,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			u32 cm8 = MASK8 ? xl_chain_shr1_keep<GL>(rec[3], st.cm8out) : 0u;
 			u32 d = st.hsave;
 			u32 lm = 0;   /* capture: this lane's own maximum in this column */
+			const u32 pre = pk_max(sbest, cm);   /* fill: the lane's running record and this column's rows above */
 #pragma unroll
 			for (int r = 0; r < R; ++r) {
 				const u32 hold = st.H[r];
@@ -889,7 +887,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 				const u32 t0 = pk_subu(h0, x.gapO2);
 				st.E[r] = pk_max(pk_subu(st.E[r], x.gapE2), t0);
 				f = pk_max(pk_subu(f, x.gapE2), t0);
-				lm = pk_max(lm, h);
+				if (CAPTURE) lm = pk_max(lm, h); else cm = pk_max(cm, h);
 				if (MASK8) cm8 = pk_max(cm8, h & m8[r]);
 				st.H[r] = h;
 				d = hold;
@@ -898,9 +896,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 				/* best-cell tracking: `pre` = everything this lane knows of rows above and of earlier columns (its running
 				   record and this column's maximum of the rows above).  Only the lane whose OWN rows beat that -- the lane
 				   holding the new record cell, not every lane below it -- takes the branch. */
-				const u32 pre = pk_max(sbest, cm);
-				cm = pk_max(cm, lm);
-				sbest = pk_max(pre, lm);
+				sbest = pk_max(sbest, cm);      /* = max(pre, own rows); pre was taken before the rows */
 				if (sbest != pre && x.mine && tc >= 0 && tc < x.ncols) {
 #pragma unroll
 					for (int h = 0; h < 2; ++h) {
