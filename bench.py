@@ -142,6 +142,10 @@ def parse_args(argv=None):
     ap.add_argument("--reads", type=int, default=100_000, help="reads per GPU and step (config 2: 100k)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--ref-len", type=int, default=1_000_000)
+    ap.add_argument("--match", type=int, default=2, help="match score (ssw_test -m)")
+    ap.add_argument("--mismatch", type=int, default=2, help="mismatch penalty (ssw_test -x)")
+    ap.add_argument("--gap-open", type=int, default=3, help="gap opening penalty (ssw_test -o)")
+    ap.add_argument("--gap-extend", type=int, default=1, help="gap extension penalty (ssw_test -e)")
     ap.add_argument("--flag", type=int, default=0, help="ssw_align flag (0 = scores + end positions; 2 = + begin + CIGAR)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads in the CPU-baseline sample (-1: ~20 s of work; 0: skip)")
     ap.add_argument("--sub", type=float, default=0.03, help="substitution rate of the synthetic reads")
@@ -187,7 +191,7 @@ def main(argv=None):
     ndev = lib.ssw_gpu_device_count()
     ctx = ssw_amd.Context(local_rank % ndev, lib)
 
-    mat = dna_matrix(2, 2)
+    mat = dna_matrix(args.match, args.mismatch)
     ref = random_ref(args.ref_len, 1, 4)                                   # seed 1: BASELINE config 2
     reads = make_reads_fast(ref, args.reads, args.read_len, seed=1000 + rank, sub=args.sub, ins=args.indel, dele=args.indel)
     # upload through the packed form directly (a Python list of 100k arrays is slow to concatenate)
@@ -200,7 +204,7 @@ def main(argv=None):
     T = ctx.upload([ref])
 
     def step():
-        return ctx.align_batch(Q, T, mat, 5, 3, 1, args.flag, 0, 0, args.mask_len, 2, want_cigar=(args.flag & 7) != 0)
+        return ctx.align_batch(Q, T, mat, 5, args.gap_open, args.gap_extend, args.flag, 0, 0, args.mask_len, 2, want_cigar=(args.flag & 7) != 0)
 
     def sync_all():
         # align_batch() returns only after its stream is synchronised and the results are on the host, so every rank is
@@ -264,9 +268,9 @@ def main(argv=None):
             "metric": "GCUPS", "value": round(value, 2), "unit": "GCUPS", "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16x2 (packed; reference u8/int16 semantics)", "data": "synthetic",
-            "config": {"workload": "%s: %d x %d bp DNA reads vs %.1f Mb target per GPU, 2/-2/3/1, score_size 2, flag %d"
+            "config": {"workload": "%s: %d x %d bp DNA reads vs %.1f Mb target per GPU, %d/-%d/%d/%d, score_size 2, flag %d"
                                    % ("BASELINE config 2" if (args.reads, args.read_len, args.ref_len) == (100000, 150, 1000000) else "custom",
-                                      args.reads, args.read_len, args.ref_len / 1e6, args.flag),
+                                      args.reads, args.read_len, args.ref_len / 1e6, args.match, args.mismatch, args.gap_open, args.gap_extend, args.flag),
                        "reads_per_gpu": args.reads, "read_len": args.read_len, "ref_len": args.ref_len,
                        "sharding": "reads sharded across ranks, target replicated, no collective"},
             "mix": {"word_rules": int(tm["n_word"]), "byte_rules": int(tm["n_byte"])},
@@ -294,7 +298,7 @@ def main(argv=None):
                     sample = np.ascontiguousarray(reads[:k])
                     soff = np.arange(k + 1, dtype=np.int64) * args.read_len
                     cres = np.zeros((k, 10), dtype=np.int32)
-                    secs = R.refwrap_bench(_ptr(sample, i8p), _ptr(soff, i64p), k, _ptr(ref, i8p), len(ref), _ptr(mat, i8p), 5, 3, 1,
+                    secs = R.refwrap_bench(_ptr(sample, i8p), _ptr(soff, i64p), k, _ptr(ref, i8p), len(ref), _ptr(mat, i8p), 5, args.gap_open, args.gap_extend,
                                            args.flag, 0, 0, args.mask_len, cores, _ptr(cres, i32p))
                     return secs, cres
                 if args.cpu_sample > 0:
@@ -319,7 +323,7 @@ def main(argv=None):
                 t1 = time.perf_counter()
                 mism = 0
                 for i in range(ns):
-                    d, _ = oracle_align(reads[i], mat, 5, ref, 3, 1, args.flag, 0, 0, args.read_len // 2, 2, 0)
+                    d, _ = oracle_align(reads[i], mat, 5, ref, args.gap_open, args.gap_extend, args.flag, 0, 0, args.read_len // 2, 2, 0)
                     g = res[i, 0]
                     mism += any(int(g[k]) != d[k] for k in ("score1", "score2", "ref_end1", "read_end1", "ref_end2"))
                 secs = time.perf_counter() - t1

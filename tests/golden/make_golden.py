@@ -173,6 +173,17 @@ def cli_goldens():
         with open(os.path.join(out, name + ".args"), "w") as f:
             f.write(" ".join(args))
     print("cli goldens:", len(runs))
+    # the reference's example programs (C API and C++ wrapper), all-reference builds
+    ex_c = os.path.join(tmp, "example_c_ref"); ex_cpp = os.path.join(tmp, "example_cpp_ref")
+    subprocess.run(["gcc", "-O2", "-I/root/reference/src", "/root/reference/src/example.c", "/root/reference/src/ssw.c", "-o", ex_c, "-lm"],
+                   check=True, stderr=subprocess.DEVNULL)
+    subprocess.run(["g++", "-O2", "-I/root/reference/src", "/root/reference/src/example.cpp", "/root/reference/src/ssw_cpp.cpp",
+                    "-x", "c", "/root/reference/src/ssw.c", "-o", ex_cpp, "-lm"], check=True, stderr=subprocess.DEVNULL)
+    for exe, name in ((ex_c, "example_c"), (ex_cpp, "example_cpp")):
+        r = subprocess.run([exe], capture_output=True, text=True)
+        with open(os.path.join(out, name + ".example_stdout"), "w") as f:
+            f.write(r.stdout)
+    print("example goldens: 2")
 
 
 if __name__ == "__main__":
