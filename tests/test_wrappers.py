@@ -53,3 +53,25 @@ def test_reference_examples_on_our_library(name):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout == open(os.path.join(CLI_DIR, name + ".example_stdout")).read()
+
+
+def test_reference_python_wrapper_binds_our_library(product_lib_path):
+    """ssw_lib.py (the reference's ctypes wrapper, used by pyssw.py) is imported from where it lies -- build container
+    only -- and pointed at the directory of OUR libssw.so: every function it declares resolves, and its result struct has
+    the layout of include/ssw.h's s_align.  (No alignment is run here: that needs a GPU and the file cannot travel.)"""
+    import ctypes as C
+    import importlib.util
+    src = "/root/reference/src/ssw_lib.py"
+    if not os.path.exists(src):
+        pytest.skip("reference sources not present")
+    spec = importlib.util.spec_from_file_location("ref_ssw_lib", src)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    w = mod.CSsw(os.path.dirname(product_lib_path))
+    for fn in ("ssw_init", "init_destroy", "ssw_align", "align_destroy"):
+        assert getattr(w, fn) is not None
+    import ssw_amd
+    ours = [(n, getattr(ssw_amd.CAlignRes, n).offset) for n, _ in ssw_amd.CAlignRes._fields_]
+    theirs = [(n, getattr(mod.CAlignRes, n).offset) for n, _ in mod.CAlignRes._fields_]
+    assert [o for _, o in ours[:len(theirs)]] == [o for _, o in theirs]
+    assert C.sizeof(mod.CAlignRes) <= C.sizeof(ssw_amd.CAlignRes)
