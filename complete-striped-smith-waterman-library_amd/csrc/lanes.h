@@ -85,6 +85,21 @@ SSW_DEV u32 pk_max(u32 a, u32 b)    /* v_pk_max_i16 */
 {
 	return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
+/* v_perm_b32: byte k of the result is byte sel[k] of the 8 bytes { lo (0..3), hi (4..7) }.  PK_LO2 / PK_HI2 gather the low / the
+   high 16-bit halves of two registers into one (lo's half first). */
+#ifdef SSW_SIMT_EMU
+SSW_DEV u32 pk_perm(u32 hi, u32 lo, u32 sel)
+{
+	const unsigned long long src = ((unsigned long long)hi << 32) | lo;
+	u32 r = 0;
+	for (int k = 0; k < 4; ++k) r |= (u32)((src >> (8 * ((sel >> (8 * k)) & 7u))) & 0xffu) << (8 * k);
+	return r;
+}
+#else
+SSW_DEV u32 pk_perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+#endif
+#define PK_LO2 0x05040100u
+#define PK_HI2 0x07060302u
 SSW_DEV u32 pk_dup(int v) { return ((u32)v & 0xffffu) * 0x10001u; }
 SSW_DEV u32 pk_make(int lo, int hi) { return ((u32)lo & 0xffffu) | ((u32)hi << 16); }
 

@@ -302,6 +302,12 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 	u32 Hlast = 0, Fout = 0, cmout = 0, ck = 0, hsave = 0;
 	u32 best = 0;                                   /* packed: highest running column maximum this lane has seen */
 	int bval[2] = { 0, 0 }, btc[2] = { 0x7fffffff, 0x7fffffff }, brow[2] = { 0x7fffffff, 0x7fffffff };   /* the last record this lane set itself */
+	/* The wavefront pays for every record any of its 4 chains x 2 queries sets (unrelated proteins: ~100 per target), so a
+	   record only copies the query's half of the lane's column (R/2 byte permutes instead of 2R compare/select); measured on the config-5 shape the row
+	   search at every record cost 24 % of the kernel. */
+	u32 snap[2][MASKED ? 1 : (R + 1) / 2];
+#pragma unroll
+	for (int k = 0; k < (MASKED ? 1 : (R + 1) / 2); ++k) { snap[0][k] = 0; snap[1][k] = 0; }
 	const u32 lane_prof = (u32)l16 * 16u;
 
 	for (int s0 = 0; s0 < nsteps; s0 += 16) {
@@ -349,14 +355,26 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			else chain_rows<R, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
 			best = pk_max(best, cm);     /* = max(pre, own rows) */
-			if (best != pre && tc >= 0 && tc < ncols) {
+			const bool hit = best != pre && tc >= 0 && tc < ncols;
+			if (wave_any(hit)) {         /* a scalar branch: hipcc otherwise if-converts half of the row search into every step */
+				if (hit) {
 #pragma unroll
-				for (int h = 0; h < 2; ++h) {
-					const int nv = (int)((best >> (16 * h)) & 0xffffu), ov = (int)((pre >> (16 * h)) & 0xffffu);
-					if (nv > ov) {
-						bval[h] = nv; btc[h] = tc; brow[h] = 0x7fffffff;
+					for (int h = 0; h < 2; ++h) {
+						const int nv = (int)((best >> (16 * h)) & 0xffffu), ov = (int)((pre >> (16 * h)) & 0xffffu);
+						if (nv > ov) {
+							bval[h] = nv; btc[h] = tc;
+							if (MASKED) {     /* size classes of 28..40 rows per lane: no registers to spare, search now */
+								brow[h] = 0x7fffffff;
 #pragma unroll
-						for (int k = R - 1; k >= 0; --k) if ((int)((H[k] >> (16 * h)) & 0xffffu) == nv) brow[h] = l16 * R + k;
+								for (int k = R - 1; k >= 0; --k) if ((int)((H[k] >> (16 * h)) & 0xffffu) == nv) brow[h] = l16 * R + k;
+							} else {          /* keep this query's half of the column (two rows per register); the row is looked up once, after the last column */
+#pragma unroll
+								for (int k = 0; k < R; k += 2) {
+									const u32 lo = H[k], hi = k + 1 < R ? H[k + 1] : 0u;
+									snap[h][k >> 1] = pk_perm(hi, lo, h ? PK_HI2 : PK_LO2);
+								}
+							}
+						}
 					}
 				}
 			}
@@ -371,6 +389,16 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 		}
 	}
 	dev_fence();   /* the chain re-reads its own column maxima below */
+	if (!MASKED) {
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			brow[h] = 0x7fffffff;
+			if (bval[h] > 0) {
+#pragma unroll
+				for (int k = R - 1; k >= 0; --k) if ((int)((snap[h][MASKED ? 0 : k >> 1] >> (16 * (k & 1))) & 0xffffu) == bval[h]) brow[h] = l16 * R + k;
+			}
+		}
+	}
 
 	/* ---- per chain, per query: reduce (the role of k_reduce + the locate pass) ---- */
 	const u32 red = ring;   /* the rings are free now: 16 lanes x 16 bytes */
