@@ -31,6 +31,28 @@ VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9    # packed 16-bit (VOP3P) instructions
                                             # = 39.3e12 packed lane-instr/s = 78.6e12 16-bit values/s, the same datapath rate as v_fma_f32 (profiles/round1_valu_rate_probe.txt)
 
 
+def usable_cores():
+    """host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU box reports 256
+    logical CPUs but runs the container under cpu.max = 16 CPUs; 256 threads on a 16-CPU quota only thrash)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:            # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def make_reads_fast(ref, nreads, length, seed, sub=0.03, ins=0.005, dele=0.005, frac_random=0.05):
     """vectorised version of tests/sswutil.sample_reads (same model, different stream): [nreads, length] int8"""
     rng = np.random.default_rng(seed)
@@ -108,7 +130,7 @@ def bench_db(args, rank, world, local_rank, dist):
                "fill_gcups_padded": round(tm["fill_cells"] / (tm["fill_ms"] * 1e-3) / 1e9, 1) if tm["fill_ms"] > 0 else 0.0}
         R = ref_lib()
         if world == 1 and args.cpu_sample != 0 and R is not None:
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             ns = min(args.reads, max(cores, 512)); ntc = min(args.db_targets, 8)
             codes = np.concatenate(qs[:ns]).astype(np.int8); off = np.zeros(ns + 1, dtype=np.int64)
             off[1:] = np.cumsum([len(x) for x in qs[:ns]])
@@ -291,7 +313,7 @@ def main(argv=None):
         # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) ----
         if ngpus == 1 and args.cpu_sample != 0:
             from sswutil import ref_lib, oracle_align, _ptr, i8p, i32p, i64p
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             R = ref_lib()
             if R is not None:
                 def cpu_run(k):
@@ -314,7 +336,8 @@ def main(argv=None):
                                 g["cigarLen"], g["flag"]], axis=1).astype(np.int32)
                 mism = int((got != cres[:, :9]).any(axis=1).sum())
                 out["cpu_baseline"] = {"value": round(cpu_gcups, 2), "unit": "GCUPS", "cores": cores, "kind": "reference",
-                                       "per_core": round(cpu_gcups / cores, 2),
+                                       "per_core": round(cpu_gcups / cores, 2), "host_logical_cpus": os.cpu_count(),
+                                       "cores_note": "threads = CPUs this container may use (affinity capped by the cgroup cpu.max quota)",
                                        "sample": "first %d reads of the batch vs the same target, ssw_init(...,2)+ssw_align through the C API, "
                                                  "reference ssw.c built -O2 (oracle/_ref), one thread per core, %.1f s" % (ns, secs)}
                 out["parity"] = {"sample": ns, "mismatching_alignments": mism, "fields": "score1 score2 ref/read begin/end ref_end2 cigarLen flag"}
