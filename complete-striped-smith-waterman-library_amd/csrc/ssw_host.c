@@ -482,6 +482,8 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 
 	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
 	double fill_ms = 0, reduce_ms = 0, locate_ms = 0, trace_ms = 0;
+	int fill_f16 = 1;
+	{ const char* e = getenv("SSW_GPU_FILL_F16"); if (e && e[0] == '0') fill_f16 = 0; }     /* experiment / test: int16 form everywhere */
 
 	{   /* database search: scores only, several short targets -> fused kernel for the short-query buckets */
 		int any_short = 0, any_long = 0; int64_t maxt = 0;
@@ -596,6 +598,8 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 					fa.pairs = d_pairs + B->first_pair + p0; fa.npairs = np; fa.mat = d_mat; fa.n = n;
 					fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.tile = tile; fa.halo = halo; fa.ntiles = ntiles;
 					fa.bpp = (ntiles + 15) / 16; fa.cm16 = d_cm16; fa.cm8 = d_cm8; fa.cm_stride = stride;
+					/* no cell of this bucket can score 2048 or more -> f16 form of the recurrence (8 instead of 9 instructions per cell) */
+					fa.f16 = fill_f16 && (int64_t)16 * B->R * (maxmat > 0 ? maxmat : 0) <= 2047;
 					void* e0 = next_event(c); void* e1 = next_event(c);
 					ssw_shim_event_record(e0, c->stream);
 					if (use_x) {

@@ -47,7 +47,7 @@ template <int R> struct ChainGeom {
 };
 
 /* build one packed profile: rows of query A in the low halves, query B in the high halves */
-template <int R>
+template <int R, bool F16 = false>
 SSW_DEV void build_profile(unsigned char* lds, u32 base, int first, int nthreads,
                            const int8_t* mat, int n,
                            const int8_t* qa, int lena, int reva,
@@ -60,20 +60,20 @@ SSW_DEV void build_profile(unsigned char* lds, u32 base, int first, int nthreads
 		const int c = rem >> 6, l = (rem & 63) >> 2, k = rem & 3;
 		const int r = c * 4 + k, row = l * R + r;
 		u32 v;
-		if (b == n) v = DEAD2;
+		if (b == n) v = F16 ? PKF_DEAD2 : DEAD2;
 		else if (r >= R) v = 0;
 		else {
 			int lo = row < p16a ? 0 : -32768, hi = row < p16b ? 0 : -32768;   /* rows below a padded query are dead */
 			if (row < lena) lo = mat[b * n + (reva ? qa[lena - 1 - row] : qa[row])];
 			if (qb && row < lenb) hi = mat[b * n + qb[row]];
-			v = pk_make(lo, hi);
+			v = F16 ? pkf_make(lo < -2048 ? -2048 : lo, hi < -2048 ? -2048 : hi) : pk_make(lo, hi);
 		}
 		lds_st32(lds, base + (u32)w * 4u, v);
 	}
 }
 
 /* one DP step of a chain lane: R rows of one target column for two packed queries */
-template <int R, bool TRACK8>
+template <int R, bool TRACK8, bool F16 = false>
 SSW_DEV void chain_rows(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f, u32& cm, u32& ck,
                         u32 gapO2, u32 gapE2)
 {
@@ -83,6 +83,13 @@ SSW_DEV void chain_rows(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f
 		if (TRACK8 && r == K8) ck = cm;
 		const u32 hold = H[r];
 		const u32 s = sc[r >> 2][r & 3];
+		if (F16) {   /* 8 instructions: scores / 2048 in f16, gapO2 / gapE2 hold the NEGATIVE penalties; H = max(0, d + s, E, F) */
+			u32 h;                                        /* gaps open from H: same H matrix as opening from the F-free value */
+			pkf_cell(d, s, E[r], f, cm, h, gapO2, gapE2);
+			H[r] = h;
+			d = hold;
+			continue;
+		}
 		const u32 h0 = pk_max(pk_adds(d, s), E[r]);   /* E >= 0 supplies the max(0, .) of local alignment */
 		const u32 h = pk_max(h0, f);
 		const u32 t0 = pk_subu(h0, gapO2);            /* gap opened from the F-free value */
@@ -118,7 +125,7 @@ SSW_DEV void chain_rows_masked(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d,
 /* ================================================================================================
  * k_fill: forward fill, column maxima only.  grid = npairs * bpp workgroups of 256 threads.
  * ================================================================================================ */
-template <int R>
+template <int R, bool F16>
 __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 {
 	typedef ChainGeom<R> G;
@@ -136,7 +143,7 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 		const int lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
 		const int8_t* qb = pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0;
 		const int lenb = pr.qb >= 0 ? (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]) : 0;
-		build_profile<R>(lds, 0, tid, 256, a.mat, a.n, qa, lena, 0, qb, lenb);
+		build_profile<R, F16>(lds, 0, tid, 256, a.mat, a.n, qa, lena, 0, qb, lenb);
 	}
 
 	/* this chain's tile */
@@ -176,6 +183,9 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 	for (int r = 0; r < R; ++r) { H[r] = 0; E[r] = 0; }
 	u32 Hlast = 0, Fout = 0, cmout = 0, ck = 0, hsave = 0;
 	const u32 lane_prof = (u32)l16 * 16u;
+	/* f16 form: the penalties enter as negative scaled constants */
+	const u32 gO = F16 ? pkf_make(-(int)(a.gapO2 & 0xffffu), -(int)(a.gapO2 & 0xffffu)) : a.gapO2;
+	const u32 gE = F16 ? pkf_make(-(int)(a.gapE2 & 0xffffu), -(int)(a.gapE2 & 0xffffu)) : a.gapE2;
 
 	for (int s0 = 0; s0 < nsteps; s0 += 16) {
 		{   /* stage target columns [s0+16, s0+32), prefetch [s0+32, s0+48) */
@@ -191,8 +201,9 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 		if (s0 >= 32) {   /* columns [s0-32, s0-16) are complete in the out rings */
 			const int tc = s0 - 32 + l16;
 			if (tc >= store_from && tc < ncols) {
-				o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
-				o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
+				const u32 v16 = lds_ld32(lds, out16 + 4u * (tc & 63)), v8 = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
+				o16[tc] = F16 ? pkf_to_int2(v16) : v16;
+				o8[tc] = F16 ? pkf_to_int2(v8) : v8;
 			}
 		}
 		wave_lds_fence();
@@ -215,7 +226,7 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 				lds_st32(lds, ob8 + 4u * j, x8);
 				cm = 0;
 			}
-			chain_rows<R, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);
+			chain_rows<R, true, F16>(sc, H, E, hsave, f, cm, ck, gO, gE);
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
 		}
 	}
@@ -223,8 +234,9 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 	for (int base = nsteps - 32; base < nsteps; base += 16) {
 		const int tc = base + l16;
 		if (tc >= store_from && tc < ncols && tc >= 0) {
-			o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
-			o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
+			const u32 v16 = lds_ld32(lds, out16 + 4u * (tc & 63)), v8 = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
+			o16[tc] = F16 ? pkf_to_int2(v16) : v16;
+			o8[tc] = F16 ? pkf_to_int2(v8) : v8;
 		}
 	}
 }
@@ -1937,7 +1949,8 @@ extern "C" int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream)
 	if (grid <= 0) return 0;
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
-		SSW_LAUNCH(k_fill<r>, ssw_fill_args, args, grid, 256, ldsb, stream); } break;
+		if (args.f16) SSW_LAUNCH((k_fill<r, true>), ssw_fill_args, args, grid, 256, ldsb, stream); \
+		else SSW_LAUNCH((k_fill<r, false>), ssw_fill_args, args, grid, 256, ldsb, stream); } break;
 		FOR_EACH_R(X)
 #undef X
 		default: return -2;
@@ -1955,8 +1968,8 @@ extern "C" int ssw_shim_fill_resident_blocks(int R, int n)
 	int per_cu = 0, dev = 0, cus = 0;
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = (size_t)(n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
-		shim_allow_lds(k_fill<r>, ldsb); \
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fill<r>, 256, ldsb) != hipSuccess) per_cu = 0; } break;
+		shim_allow_lds(k_fill<r, false>, ldsb); \
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fill<r, false>, 256, ldsb) != hipSuccess) per_cu = 0; } break;
 		FOR_EACH_R(X)
 #undef X
 		default: return 0;

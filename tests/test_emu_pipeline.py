@@ -180,6 +180,23 @@ def test_long_read_wave_traceback_resumes_across_rounds(ectx, teams, monkeypatch
     _run(ectx, [np.ascontiguousarray(r, dtype=np.int8) for r in reads], [ref], dna_matrix(2, 2), 5, flag=2)
 
 
+@pytest.mark.parametrize("fill", ["f16", "int16"])
+def test_f16_and_int16_fill_forms(ectx, fill, monkeypatch):
+    """short queries whose scores stay below 2048 use the f16 form of the recurrence; both forms against the reference,
+    including exact copies at the f16 limit (128 rows x 15 = 1920) and the first class beyond it"""
+    if fill == "int16":
+        monkeypatch.setenv("SSW_GPU_FILL_F16", "0")
+    rng = np.random.default_rng(32)
+    ref = random_ref(1500, 92, 4)
+    mat = dna_matrix(15, 9)
+    reads = [ref[100:228].copy(), ref[300:436].copy(), ref[700:844].copy()]
+    reads += make_reads(rng, ref, 9, [128, 100, 127, 60, 136, 33], 4, sub=0.03, ins=0.01, dele=0.01, frac_random=0.1)
+    _run(ectx, reads, [ref], mat, 5, gapO=11, gapE=2, flag=2)
+    reads = make_reads(rng, ref, 12, [150, 151, 75, 36, 250, 16], 4)
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=1, maskLen=15)
+    _run(ectx, reads, [ref], dna_matrix(1, 3), 5, gapO=5, gapE=2, flag=0)
+
+
 def test_randomised_parameters(ectx):
     rng = np.random.default_rng(6)
     for _ in range(25):

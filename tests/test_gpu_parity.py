@@ -92,7 +92,12 @@ def test_random_dna_all_flags(gpu_ctx, flag):
     _run(gpu_ctx, reads, [ref], dna_matrix(2, 2), 5, flag=flag, filters=int(rng.choice([0, 60])), filterd=int(rng.choice([0, 100, 1000])))
 
 
-def test_random_parameter_sweep(gpu_ctx):
+@pytest.mark.parametrize("fill", ["f16", "int16"])
+def test_random_parameter_sweep(gpu_ctx, fill, monkeypatch):
+    """short queries take the f16 form of the recurrence when no score can reach 2048 (k_fill<R, true>); the int16 form
+    (SSW_GPU_FILL_F16=0) must give the same records"""
+    if fill == "int16":
+        monkeypatch.setenv("SSW_GPU_FILL_F16", "0")
     rng = np.random.default_rng(7)
     for _ in range(30):
         kind = "dna" if rng.random() < 0.6 else "aa"
@@ -174,6 +179,18 @@ def test_config2_shape_sample_and_properties(gpu_ctx):
     # a second, 1/-3/5/2 pass (README alt scoring): every read stays under 8-bit rules
     res3, _ = _run(gpu_ctx, reads[:512], [ref], dna_matrix(1, 3), 5, 5, 2, flag=0, check=list(range(0, 512, 64)))
     assert gpu_ctx.timing()["n_word"] == 0
+
+
+def test_f16_fill_at_its_score_limit(gpu_ctx):
+    """the f16 form is chosen while 16 R x max(mat) <= 2047: exact copies at that limit (scores up to 2040), and the
+    first size class beyond it (int16 form), with a matrix whose match score is large"""
+    rng = np.random.default_rng(31)
+    ref = random_ref(5000, 91, 4)
+    mat = dna_matrix(15, 9)
+    reads = [ref[100:236].copy(), ref[900:1028].copy(), ref[2000:2137].copy(), ref[3000:3144].copy()]    # 136 = 8.5 x 16 -> R 9: 144 x 15 = 2160 (int16); 128 -> R 8: 1920 (f16)
+    reads += make_reads(rng, ref, 24, [128, 120, 127, 113, 136, 144], 4, sub=0.03, ins=0.01, dele=0.01, frac_random=0.1)
+    for flag in (0, 2):
+        _run(gpu_ctx, reads, [ref], mat, 5, gapO=11, gapE=2, flag=flag)
 
 
 def test_tile_seams_exact(gpu_ctx):
