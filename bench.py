@@ -267,15 +267,20 @@ def main(argv=None):
         aln_per_launch = args.reads * args.steps / max(1, fill_launches)
         bytes_per_aln = args.ref_len + args.read_len + 25 + 40 + 4 * args.ref_len
         if args.read_len <= 384:
-            fill_kernel = "k_fill<%d>" % ((args.read_len + 15) // 16)
+            fill_kernel = "k_fill<%d, %s>" % ((args.read_len + 15) // 16, "f16" if (16 * ((args.read_len + 15) // 16) * max(args.match, 0) <= 2047
+                                                                                      and os.environ.get("SSW_GPU_FILL_F16", "1") != "0") else "int16")
         else:   # long queries: row strips of 64 x R rows (csrc/ssw_host.c); boundary records of 16 B per column and pair between strips
             p16 = (args.read_len + 15) // 16 * 16
             strips = (p16 + 64 * 12 - 1) // (64 * 12)
             fill_kernel = "k_chainx<%d, false, 64> x %d strips" % ((p16 + 64 * strips - 1) // (64 * strips), strips)
             bytes_per_aln += 16 * args.ref_len * (strips - 1)      # written once, read once, shared by the two queries of a pair
         achieved_gbs = aln_per_launch * bytes_per_aln / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        # VALU view: 9 packed instructions per (row, column) for two queries -> 4.5 lane-ops per evaluated cell
-        valu_ops = fill_cells * 4.5
+        # VALU view: 9 packed int16 instructions per (row, column) for two queries -> 4.5 lane-ops per evaluated cell; 8 in the
+        # f16 form that csrc/ssw_host.c selects when no score of the bucket can reach 2048 (short reads, small match scores)
+        f16_form = (args.read_len <= 384 and 16 * ((args.read_len + 15) // 16) * max(args.match, 0) <= 2047
+                    and os.environ.get("SSW_GPU_FILL_F16", "1") != "0")
+        ops_per_pair_cell = 8 if f16_form else 9
+        valu_ops = fill_cells * ops_per_pair_cell / 2.0
         achieved_valu = valu_ops / (fill_ms * 1e-3) if fill_ms > 0 else 0.0
         probe = ctx.valu_probe(8192, 4000) if args.lib is None else 0.0   # (skipped on the test emulator)
         traffic = None
@@ -289,7 +294,8 @@ def main(argv=None):
         out = {
             "metric": "GCUPS", "value": round(value, 2), "unit": "GCUPS", "n_gpus": ngpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int16x2 (packed; reference u8/int16 semantics)", "data": "synthetic",
+            "dtype": ("f16x2 holding exact integers (scores/2048); reference u8/int16 semantics" if f16_form else
+                      "int16x2 (packed; reference u8/int16 semantics)"), "data": "synthetic",
             "config": {"workload": "%s: %d x %d bp DNA reads vs %.1f Mb target per GPU, %d/-%d/%d/%d, score_size 2, flag %d"
                                    % ("BASELINE config 2" if (args.reads, args.read_len, args.ref_len) == (100000, 150, 1000000) else "custom",
                                       args.reads, args.read_len, args.ref_len / 1e6, args.match, args.mismatch, args.gap_open, args.gap_extend, args.flag),
@@ -304,10 +310,11 @@ def main(argv=None):
                          "traffic_note": "GB/s from rocprofv3 FETCH_SIZE(x2)+WRITE_SIZE of this kernel (profiles/round1_traffic.json), per launch",
                          "launch_ms": round(launch_ms, 3), "launches": int(fill_launches),
                          "note": "integer max-plus recurrence: HBM is not the binding resource, see roofline_valu"},
-            "roofline_valu": {"bound": "valu-int16x2", "achieved": round(achieved_valu / 1e12, 3), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
+            "roofline_valu": {"bound": "valu-packed16", "achieved": round(achieved_valu / 1e12, 3), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
                               "unit": "T lane-op/s", "frac": round(achieved_valu / VALU_PEAK_LANEOPS, 4),
                               "measured_peak_probe": round(probe / 1e12, 2),
-                              "note": "packed-int16 instruction rate; VOP3P issues at 16 lanes/clk/SIMD (peak = 256 CU x 4 SIMD x 16 x 2.4 GHz), the probe is the same mix measured on this device",
+                              "ops_per_pair_cell": ops_per_pair_cell,
+                              "note": "packed 16-bit (VOP3P) instruction rate: 16 lanes/clk/SIMD (peak = 256 CU x 4 SIMD x 16 x 2.4 GHz); the probe is the int16 mix measured on this device",
                               "fill_gcups_padded": round(fill_cells / (fill_ms * 1e-3) / 1e9, 1) if fill_ms > 0 else 0.0},
         }
         # ---- CPU baseline + parity on a bounded sample (rank 0, N = 1 only) ----
