@@ -166,6 +166,39 @@ SSW_DEV void pkf_cell(u32 d, u32 s, u32& E, u32& f, u32& cm, u32& h, u32 nO, u32
 	    : [d] "v"(d), [s] "v"(s), [nO] "v"(nO), [nE] "v"(nE));
 }
 #endif
+/* two consecutive rows of a lane: 15 instructions -- the column maximum takes both rows in one v_pk_maximum3_f16.
+   d0 / d1 = diagonal inputs (d1 is row 0's previous H), h0 / h1 = the new H values. */
+#ifdef SSW_SIMT_EMU
+SSW_DEV void pkf_cell2(u32 d0, u32 s0, u32 d1, u32 s1, u32& E0, u32& E1, u32& f, u32& cm, u32& h0, u32& h1, u32 nO, u32 nE)
+{
+	u32 c0 = 0, c1 = 0;
+	pkf_cell(d0, s0, E0, f, c0, h0, nO, nE);
+	pkf_cell(d1, s1, E1, f, c1, h1, nO, nE);
+	cm = pkf_max3(cm, h0, h1);
+}
+#else
+SSW_DEV void pkf_cell2(u32 d0, u32 s0, u32 d1, u32 s1, u32& E0, u32& E1, u32& f, u32& cm, u32& h0, u32& h1, u32 nO, u32 nE)
+{
+	u32 t;
+	asm("v_pk_add_f16 %[h0], %[d0], %[s0] clamp\n\t"
+	    "v_pk_maximum3_f16 %[h0], %[h0], %[E0], %[f]\n\t"
+	    "v_pk_add_f16 %[t], %[h0], %[nO] clamp\n\t"
+	    "v_pk_add_f16 %[E0], %[E0], %[nE] clamp\n\t"
+	    "v_pk_add_f16 %[f], %[f], %[nE] clamp\n\t"
+	    "v_pk_max_f16 %[E0], %[E0], %[t]\n\t"
+	    "v_pk_max_f16 %[f], %[f], %[t]\n\t"
+	    "v_pk_add_f16 %[h1], %[d1], %[s1] clamp\n\t"
+	    "v_pk_maximum3_f16 %[h1], %[h1], %[E1], %[f]\n\t"
+	    "v_pk_add_f16 %[t], %[h1], %[nO] clamp\n\t"
+	    "v_pk_add_f16 %[E1], %[E1], %[nE] clamp\n\t"
+	    "v_pk_add_f16 %[f], %[f], %[nE] clamp\n\t"
+	    "v_pk_max_f16 %[E1], %[E1], %[t]\n\t"
+	    "v_pk_max_f16 %[f], %[f], %[t]\n\t"
+	    "v_pk_maximum3_f16 %[cm], %[cm], %[h0], %[h1]"
+	    : [h0] "=&v"(h0), [h1] "=&v"(h1), [t] "=&v"(t), [E0] "+v"(E0), [E1] "+v"(E1), [f] "+v"(f), [cm] "+v"(cm)
+	    : [d0] "v"(d0), [s0] "v"(s0), [d1] "v"(d1), [s1] "v"(s1), [nO] "v"(nO), [nE] "v"(nE));
+}
+#endif
 SSW_DEV u32 pkf_from_int(int v) { const _Float16 h = (_Float16)((float)v * (1.0f / 2048.0f)); return (u32)__builtin_bit_cast(unsigned short, h); }
 SSW_DEV u32 pkf_make(int lo, int hi) { return pkf_from_int(lo) | (pkf_from_int(hi) << 16); }
 SSW_DEV u32 pkf_to_int2(u32 v)   /* two scaled f16 -> two 16-bit integers */

@@ -73,23 +73,47 @@ SSW_DEV void build_profile(unsigned char* lds, u32 base, int first, int nthreads
 }
 
 /* one DP step of a chain lane: R rows of one target column for two packed queries */
+/* f16 form of rows [R0, R1) of a lane (see lanes.h): pairs of rows, 7.5 instructions per row */
+template <int R, int R0, int R1>
+SSW_DEV void chain_rows_f16(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32& d, u32& f, u32& cm, u32 nO, u32 nE)
+{
+#pragma unroll
+	for (int r = R0; r + 1 < R1; r += 2) {
+		const u32 d1 = H[r], hold = H[r + 1];
+		u32 h0, h1;
+		pkf_cell2(d, sc[r >> 2][r & 3], d1, sc[(r + 1) >> 2][(r + 1) & 3], E[r], E[r + 1], f, cm, h0, h1, nO, nE);
+		H[r] = h0; H[r + 1] = h1;
+		d = hold;
+	}
+	if ((R1 - R0) & 1) {
+		constexpr int r = R1 - 1 >= 0 ? R1 - 1 : 0;
+		const u32 hold = H[r];
+		u32 h;
+		pkf_cell(d, sc[r >> 2][r & 3], E[r], f, cm, h, nO, nE);
+		H[r] = h;
+		d = hold;
+	}
+}
+
 template <int R, bool TRACK8, bool F16 = false>
 SSW_DEV void chain_rows(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f, u32& cm, u32& ck,
                         u32 gapO2, u32 gapE2)
 {
 	constexpr int K8 = ChainGeom<R>::K8;
+	if (F16) {   /* scores / 2048 in f16, gapO2 / gapE2 hold the NEGATIVE penalties; H = max(0, d + s, E, F); gaps open from H:
+	                same H matrix as opening from the F-free value */
+		if (TRACK8) {
+			chain_rows_f16<R, 0, K8>(sc, H, E, d, f, cm, gapO2, gapE2);
+			ck = cm;
+			chain_rows_f16<R, K8, R>(sc, H, E, d, f, cm, gapO2, gapE2);
+		} else chain_rows_f16<R, 0, R>(sc, H, E, d, f, cm, gapO2, gapE2);
+		return;
+	}
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
 		if (TRACK8 && r == K8) ck = cm;
 		const u32 hold = H[r];
 		const u32 s = sc[r >> 2][r & 3];
-		if (F16) {   /* 8 instructions: scores / 2048 in f16, gapO2 / gapE2 hold the NEGATIVE penalties; H = max(0, d + s, E, F) */
-			u32 h;                                        /* gaps open from H: same H matrix as opening from the F-free value */
-			pkf_cell(d, s, E[r], f, cm, h, gapO2, gapE2);
-			H[r] = h;
-			d = hold;
-			continue;
-		}
 		const u32 h0 = pk_max(pk_adds(d, s), E[r]);   /* E >= 0 supplies the max(0, .) of local alignment */
 		const u32 h = pk_max(h0, f);
 		const u32 t0 = pk_subu(h0, gapO2);            /* gap opened from the F-free value */
