@@ -275,11 +275,11 @@ def main(argv=None):
             fill_kernel = "k_chainx<%d, false, 64> x %d strips" % ((p16 + 64 * strips - 1) // (64 * strips), strips)
             bytes_per_aln += 16 * args.ref_len * (strips - 1)      # written once, read once, shared by the two queries of a pair
         achieved_gbs = aln_per_launch * bytes_per_aln / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        # VALU view: 9 packed int16 instructions per (row, column) for two queries -> 4.5 lane-ops per evaluated cell; 8 in the
+        # VALU view: 9 packed int16 instructions per (row, column) for two queries -> 4.5 lane-ops per evaluated cell; 7.5 in the
         # f16 form that csrc/ssw_host.c selects when no score of the bucket can reach 2048 (short reads, small match scores)
         f16_form = (args.read_len <= 384 and 16 * ((args.read_len + 15) // 16) * max(args.match, 0) <= 2047
                     and os.environ.get("SSW_GPU_FILL_F16", "1") != "0")
-        ops_per_pair_cell = 8 if f16_form else 9
+        ops_per_pair_cell = 7.5 if f16_form else 9      # f16: rows in pairs, 15 instructions per two rows
         valu_ops = fill_cells * ops_per_pair_cell / 2.0
         achieved_valu = valu_ops / (fill_ms * 1e-3) if fill_ms > 0 else 0.0
         probe = ctx.valu_probe(8192, 4000) if args.lib is None else 0.0   # (skipped on the test emulator)
