@@ -165,7 +165,13 @@ def cli_goldens():
             "config1_plain": ["target.fastq", "query.fastq"], "config1_cr": ["-c", "-r", "target.fastq", "query.fastq"],
             "protein_pc": ["-p", "-c", "protein1.fa", "protein2.fa"], "r1_cr": ["-c", "-r", "r1.fa", "r1_query.fq"],
             "r1_csr": ["-c", "-s", "-r", "r1.fa", "r1_query.fq"], "readme_1k_cs": ["-c", "-s", "1k.fa", "query.fastq"],
-            "config1_f15": ["-c", "-f", "15", "target.fastq", "query.fastq"]}
+            "config1_f15": ["-c", "-f", "15", "target.fastq", "query.fastq"],
+            # option values are given with two characters and followed by another option: the reference's hand-written parser
+            # (main.c:253-300) keeps scanning the characters after a consumed value, past the end of a one-character string
+            "scoring_m1x3o5e2": ["-m", "01", "-x", "03", "-o", "05", "-e", "02", "-c", "target.fastq", "query.fastq"],
+            "matrix_file_csh": ["-a", "wt.tbl", "-c", "-s", "-h", "target.fastq", "query.fastq"],   # (a file name without option letters)
+            "gap_o10_e10": ["-m", "05", "-x", "04", "-o", "10", "-e", "10", "-c", "target.fastq", "query.fastq"],
+            "protein_o11e1": ["-o", "11", "-e", "01", "-p", "-c", "protein1.fa", "protein2.fa"]}
     for name, args in runs.items():
         r = subprocess.run([exe] + args, cwd=out, capture_output=True, text=True)
         with open(os.path.join(out, name + ".stdout"), "w") as f:
