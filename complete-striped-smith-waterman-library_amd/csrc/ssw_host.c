@@ -490,7 +490,8 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 		for (int b = 0; b < nb; ++b) { if (bk[b].use_x && bk[b].P16 > 640) any_long = 1; else any_short = 1; }
 		for (int32_t ti = 0; ti < tcount; ++ti) { int64_t L = T->h_off[tfirst + ti + 1] - T->h_off[tfirst + ti]; if (L > maxt) maxt = L; }
 		const char* dis = getenv("SSW_GPU_NO_DB");
-		if (!literal && prm->flag == 0 && tcount >= 4 && any_short && maxt <= 65536 && !(dis && dis[0] == '1')) {
+		/* (k_filldb takes the column maximum of two rows with a 16-bit float max3, valid below 31744: 640 rows x max(mat) <= 49) */
+		if (!literal && prm->flag == 0 && tcount >= 4 && any_short && maxt <= 65536 && maxmat <= 49 && !(dis && dis[0] == '1')) {
 			for (int b = 0; b < nb; ++b) if (!bk[b].use_x || bk[b].P16 <= 640) for (int32_t k = 0; k < bk[b].nq; ++k) qdone[order[bk[b].first_q + k]] = 1;
 			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone)) goto done;
 			d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq);   /* align_db may have regrown the record buffer */
