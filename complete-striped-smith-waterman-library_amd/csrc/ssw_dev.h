@@ -56,7 +56,8 @@ typedef struct {
 	uint32_t* cm16;          /* [npairs][cm_stride]: column max over all 16R rows   (8-bit rules) */
 	uint32_t* cm8;           /* [npairs][cm_stride]: column max over the first 16R-8 rows (16-bit rules, padded queries) */
 	int64_t cm_stride;
-	int32_t f16;             /* 1: no score can reach 2048 -> the 8-instruction f16 form of the recurrence (scores / 2048, exact) */
+	int32_t f16;             /* form of the recurrence: 1: no score can reach 2048 -> f16 (scores / 2048, exact), 7.5 instructions per row;
+	                            2: no score can reach 31744 -> int16 with a two-row column maximum, 8.5; 0: plain int16, 9 */
 } ssw_fill_args;
 
 /* byte-for-byte the layout of ssw_gpu_result (include/ssw_gpu.h); checked by a static assertion in ssw_host.c */

@@ -600,7 +600,10 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 					fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.tile = tile; fa.halo = halo; fa.ntiles = ntiles;
 					fa.bpp = (ntiles + 15) / 16; fa.cm16 = d_cm16; fa.cm8 = d_cm8; fa.cm_stride = stride;
 					/* no cell of this bucket can score 2048 or more -> f16 form of the recurrence (8 instead of 9 instructions per cell) */
-					fa.f16 = fill_f16 && (int64_t)16 * B->R * (maxmat > 0 ? maxmat : 0) <= 2047;
+					{
+						const int64_t top = (int64_t)16 * B->R * (maxmat > 0 ? maxmat : 0);     /* no cell of the bucket scores more */
+						fa.f16 = !fill_f16 ? 0 : top <= 2047 ? 1 : top < 31744 ? 2 : 0;
+					}
 					void* e0 = next_event(c); void* e1 = next_event(c);
 					ssw_shim_event_record(e0, c->stream);
 					if (use_x) {

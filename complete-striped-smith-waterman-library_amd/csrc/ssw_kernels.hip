@@ -177,9 +177,11 @@ SSW_DEV void chain_rows_masked(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d,
 /* ================================================================================================
  * k_fill: forward fill, column maxima only.  grid = npairs * bpp workgroups of 256 threads.
  * ================================================================================================ */
-template <int R, bool F16>
+/* FORM 0: int16, 9 instructions per row; 1: f16 (scores < 2048), 7.5; 2: int16 with the two-row column maximum (scores < 31744), 8.5 */
+template <int R, int FORM>
 __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 {
+	constexpr bool F16 = FORM == 1;
 	typedef ChainGeom<R> G;
 	constexpr int C = G::C;
 	SSW_DYN_LDS(lds);
@@ -278,7 +280,7 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 				lds_st32(lds, ob8 + 4u * j, x8);
 				cm = 0;
 			}
-			chain_rows<R, true, F16>(sc, H, E, hsave, f, cm, ck, gO, gE);
+			chain_rows<R, true, F16, FORM == 2>(sc, H, E, hsave, f, cm, ck, gO, gE);
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
 		}
 	}
@@ -2001,8 +2003,9 @@ extern "C" int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream)
 	if (grid <= 0) return 0;
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
-		if (args.f16) SSW_LAUNCH((k_fill<r, true>), ssw_fill_args, args, grid, 256, ldsb, stream); \
-		else SSW_LAUNCH((k_fill<r, false>), ssw_fill_args, args, grid, 256, ldsb, stream); } break;
+		if (args.f16 == 1) SSW_LAUNCH((k_fill<r, 1>), ssw_fill_args, args, grid, 256, ldsb, stream); \
+		else if (args.f16 == 2) SSW_LAUNCH((k_fill<r, 2>), ssw_fill_args, args, grid, 256, ldsb, stream); \
+		else SSW_LAUNCH((k_fill<r, 0>), ssw_fill_args, args, grid, 256, ldsb, stream); } break;
 		FOR_EACH_R(X)
 #undef X
 		default: return -2;
@@ -2020,8 +2023,8 @@ extern "C" int ssw_shim_fill_resident_blocks(int R, int n)
 	int per_cu = 0, dev = 0, cus = 0;
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = (size_t)(n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
-		shim_allow_lds(k_fill<r, false>, ldsb); \
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fill<r, false>, 256, ldsb) != hipSuccess) per_cu = 0; } break;
+		shim_allow_lds(k_fill<r, 0>, ldsb); \
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fill<r, 0>, 256, ldsb) != hipSuccess) per_cu = 0; } break;
 		FOR_EACH_R(X)
 #undef X
 		default: return 0;
