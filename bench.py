@@ -267,8 +267,9 @@ def main(argv=None):
         aln_per_launch = args.reads * args.steps / max(1, fill_launches)
         bytes_per_aln = args.ref_len + args.read_len + 25 + 40 + 4 * args.ref_len
         if args.read_len <= 384:
-            fill_kernel = "k_fill<%d, %s>" % ((args.read_len + 15) // 16, "f16" if (16 * ((args.read_len + 15) // 16) * max(args.match, 0) <= 2047
-                                                                                      and os.environ.get("SSW_GPU_FILL_F16", "1") != "0") else "int16")
+            _top = 16 * ((args.read_len + 15) // 16) * max(args.match, 0)
+            _on = os.environ.get("SSW_GPU_FILL_F16", "1") != "0"
+            fill_kernel = "k_fill<%d, %s>" % ((args.read_len + 15) // 16, "f16" if (_on and _top <= 2047) else "int16+max3" if (_on and _top < 31744) else "int16")
         else:   # long queries: row strips of 64 x R rows (csrc/ssw_host.c); boundary records of 16 B per column and pair between strips
             p16 = (args.read_len + 15) // 16 * 16
             strips = (p16 + 64 * 12 - 1) // (64 * 12)
@@ -277,9 +278,11 @@ def main(argv=None):
         achieved_gbs = aln_per_launch * bytes_per_aln / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         # VALU view: 9 packed int16 instructions per (row, column) for two queries -> 4.5 lane-ops per evaluated cell; 7.5 in the
         # f16 form that csrc/ssw_host.c selects when no score of the bucket can reach 2048 (short reads, small match scores)
-        f16_form = (args.read_len <= 384 and 16 * ((args.read_len + 15) // 16) * max(args.match, 0) <= 2047
-                    and os.environ.get("SSW_GPU_FILL_F16", "1") != "0")
-        ops_per_pair_cell = 7.5 if f16_form else 9      # f16: rows in pairs, 15 instructions per two rows
+        top = 16 * ((args.read_len + 15) // 16) * max(args.match, 0)          # no cell of the batch scores more
+        forms_on = os.environ.get("SSW_GPU_FILL_F16", "1") != "0"
+        f16_form = args.read_len <= 384 and top <= 2047 and forms_on
+        cm3_form = args.read_len <= 384 and not f16_form and top < 31744 and forms_on
+        ops_per_pair_cell = 7.5 if f16_form else 8.5 if cm3_form else 9     # csrc/ssw_kernels.hip k_fill<R, FORM>
         valu_ops = fill_cells * ops_per_pair_cell / 2.0
         achieved_valu = valu_ops / (fill_ms * 1e-3) if fill_ms > 0 else 0.0
         probe = ctx.valu_probe(8192, 4000) if args.lib is None else 0.0   # (skipped on the test emulator)
