@@ -58,6 +58,10 @@ static void init_tables(void)
 }
 
 /* ---------------------------------------------------------------- FASTA / FASTQ reader (plain or gz) */
+/* a command-line tool: running out of memory ends the run with a message */
+static void* xmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) { fprintf(stderr, "ssw_test_gpu: out of memory\n"); exit(EXIT_FAILURE); } return p; }
+static void* xrealloc(void* q, size_t n) { void* p = realloc(q, n ? n : 1); if (!p) { fprintf(stderr, "ssw_test_gpu: out of memory\n"); exit(EXIT_FAILURE); } return p; }
+
 typedef struct { char* name; char* seq; char* qual; int32_t len; } record;
 typedef struct { gzFile f; unsigned char buf[1 << 16]; int n, pos, eof, last_header; } reader;
 
@@ -75,7 +79,7 @@ static int rd_getc(reader* r)
 typedef struct { char* s; size_t l, cap; } str;
 static void str_push(str* s, int ch)
 {
-	if (s->l + 2 > s->cap) { s->cap = s->cap ? s->cap * 2 : 256; s->s = (char*)realloc(s->s, s->cap); }
+	if (s->l + 2 > s->cap) { s->cap = s->cap ? s->cap * 2 : 256; s->s = (char*)xrealloc(s->s, s->cap); }
 	s->s[s->l++] = (char)ch; s->s[s->l] = 0;
 }
 
@@ -207,7 +211,7 @@ static int load_matrix(const char* path, int8_t** mat, int32_t* n)
 {
 	FILE* f = fopen(path, "r");
 	if (!f) { fprintf(stderr, "Failed to open the weight matrix file.\n"); return 1; }
-	int8_t* m = (int8_t*)malloc(1024);
+	int8_t* m = (int8_t*)xmalloc(1024);
 	char line[128];
 	int32_t k = 0, rows = 0;
 	while (fgets(line, sizeof line, f)) {
@@ -278,7 +282,10 @@ int main(int argc, char* const argv[])
 	const int8_t* mat = dna; int8_t* mat_file = 0; const int8_t* table = nt_code;
 	if (protein && !mat_name) { n = 24; table = aa_code; mat = blosum50; }
 	else if (mat_name) { if (load_matrix(mat_name, &mat_file, &n)) return 1; mat = mat_file; table = aa_code; }
-	if (reverse && n != 5) { fprintf(stderr, "Reverse complement alignment is not available for protein sequences. \n"); return 1; }
+	/* -r follows the reference's conditions (src/main.c:457-490): reverse-complement profiles exist only for a 5-letter matrix
+	   and are only aligned without -p; with the 24-letter matrices the run stops at the first read; other sizes ignore -r */
+	const int reverse_fatal = reverse && n == 24;
+	if (reverse && (n != 5 || protein)) reverse = 0;
 
 	/* the target file is read once */
 	reader tr; memset(&tr, 0, sizeof tr);
@@ -286,7 +293,7 @@ int main(int argc, char* const argv[])
 	if (!tr.f) { fprintf(stderr, "gzopen of '%s' failed.\n", files[0]); return EXIT_FAILURE; }
 	record* targets = 0; int32_t nt = 0, capt = 0;
 	for (record rec; read_record(&tr, &rec); ) {
-		if (nt == capt) { capt = capt ? capt * 2 : 16; targets = (record*)realloc(targets, sizeof(record) * capt); }
+		if (nt == capt) { capt = capt ? capt * 2 : 16; targets = (record*)xrealloc(targets, sizeof(record) * capt); }
 		targets[nt++] = rec;
 	}
 	gzclose(tr.f);
@@ -297,10 +304,10 @@ int main(int argc, char* const argv[])
 		fprintf(stderr, "SAM format output is only available together with option -c.\n");
 		sam = 0;
 	}
-	int64_t* toff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)nt + 1));
+	int64_t* toff = (int64_t*)xmalloc(sizeof(int64_t) * ((size_t)nt + 1));
 	toff[0] = 0;
 	for (int32_t t = 0; t < nt; ++t) toff[t + 1] = toff[t] + targets[t].len;
-	int8_t* tcodes = (int8_t*)malloc((size_t)toff[nt] + 1);
+	int8_t* tcodes = (int8_t*)xmalloc((size_t)toff[nt] + 1);
 	for (int32_t t = 0; t < nt; ++t) for (int32_t i = 0; i < targets[t].len; ++i) tcodes[toff[t] + i] = table[(int)targets[t].seq[i] & 127];
 
 	ssw_gpu_ctx* g = ssw_gpu_open(getenv("SSW_GPU_DEVICE") ? atoi(getenv("SSW_GPU_DEVICE")) : 0);
@@ -312,21 +319,22 @@ int main(int argc, char* const argv[])
 	qr.f = gzopen(files[1], "r");
 	if (!qr.f) { fprintf(stderr, "gzopen of '%s' failed.\n", files[1]); exit(EXIT_FAILURE); }
 	const clock_t t_start = clock();
-	record* reads = (record*)malloc(sizeof(record) * (size_t)batch);
+	record* reads = (record*)xmalloc(sizeof(record) * (size_t)batch);
 	for (;;) {
 		int32_t nr = 0; int64_t total = 0;
 		while (nr < batch && read_record(&qr, &reads[nr])) { total += reads[nr].len; ++nr; }
 		if (nr == 0) break;
-		int64_t* qoff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)nr + 1));
-		int8_t* qcodes = (int8_t*)malloc((size_t)total + 1);
-		int8_t* rcodes = reverse ? (int8_t*)malloc((size_t)total + 1) : 0;
-		char** rcseq = reverse ? (char**)malloc(sizeof(char*) * (size_t)nr) : 0;
+		if (reverse_fatal) { fprintf(stderr, "Reverse complement alignment is not available for protein sequences. \n"); return 1; }
+		int64_t* qoff = (int64_t*)xmalloc(sizeof(int64_t) * ((size_t)nr + 1));
+		int8_t* qcodes = (int8_t*)xmalloc((size_t)total + 1);
+		int8_t* rcodes = reverse ? (int8_t*)xmalloc((size_t)total + 1) : 0;
+		char** rcseq = reverse ? (char**)xmalloc(sizeof(char*) * (size_t)nr) : 0;
 		qoff[0] = 0;
 		for (int32_t q = 0; q < nr; ++q) {
 			qoff[q + 1] = qoff[q] + reads[q].len;
 			for (int32_t i = 0; i < reads[q].len; ++i) qcodes[qoff[q] + i] = table[(int)reads[q].seq[i] & 127];
 			if (reverse) {
-				rcseq[q] = (char*)malloc((size_t)reads[q].len + 1);
+				rcseq[q] = (char*)xmalloc((size_t)reads[q].len + 1);
 				reverse_complement(reads[q].seq, reads[q].len, rcseq[q]);
 				for (int32_t i = 0; i < reads[q].len; ++i) rcodes[qoff[q] + i] = table[(int)rcseq[q][i] & 127];
 			}
@@ -334,18 +342,19 @@ int main(int argc, char* const argv[])
 		ssw_gpu_params p;
 		p.mat = mat; p.n = n; p.gapO = (uint8_t)gap_open; p.gapE = (uint8_t)gap_ext; p.flag = path ? 2 : 0; p.filters = (uint16_t)filter;
 		p.filterd = 0; p.maskLen = -1; p.score_size = 2; p.mark_mismatch = sam ? 1 : 0;
-		ssw_gpu_result* res = (ssw_gpu_result*)malloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1));
-		ssw_gpu_result* res_rc = reverse ? (ssw_gpu_result*)malloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1)) : 0;
+		ssw_gpu_result* res = (ssw_gpu_result*)xmalloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1));
+		ssw_gpu_result* res_rc = reverse ? (ssw_gpu_result*)xmalloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1)) : 0;
 		uint32_t *pool = 0, *pool_rc = 0; int64_t words = 0;
 		/* residue translation and (with -r) the reverse complement run on the device; the host copies made
 		   above are only used for printing (SAM needs the codes for mark_mismatch) */
-		char* qtext = (char*)malloc((size_t)total + 1);
+		char* qtext = (char*)xmalloc((size_t)total + 1);
 		for (int32_t q = 0; q < nr; ++q) memcpy(qtext + qoff[q], reads[q].seq, (size_t)reads[q].len);
 		ssw_gpu_seqs* Qs = ssw_gpu_seqs_upload_ascii(g, qtext, qoff, nr, table);
 		free(qtext);
 		if (!Qs || ssw_gpu_align_batch(g, Qs, T, 0, nt, &p, res, &pool, &words)) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
 		if (reverse) {
-			ssw_gpu_seqs* Qr = ssw_gpu_seqs_revcomp(g, Qs);
+			/* (the device reverse complement works on nucleotide codes; with a matrix file the table is the file's own) */
+			ssw_gpu_seqs* Qr = table == nt_code ? ssw_gpu_seqs_revcomp(g, Qs) : ssw_gpu_seqs_upload(g, rcodes, qoff, nr);
 			if (!Qr || ssw_gpu_align_batch(g, Qr, T, 0, nt, &p, res_rc, &pool_rc, &words)) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
 			ssw_gpu_seqs_free(Qr);
 		}
@@ -361,12 +370,12 @@ int main(int argc, char* const argv[])
 				if (rr && rr->status == 0 && rr->score1 > r->score1 && rr->score1 >= filter) {
 					s_align* a = ssw_gpu_result_to_align(rr, pool_rc);
 					if (a->flag == 2) fprintf(stderr, "Warning: The reverse compliment alignment of the following sequences may miss a small part.\nref_seq: %s\nread_seq: %s\n\n", targets[t].name, reads[q].name);
-					write_alignment(a, &targets[t], &reads[q], rcseq[q], tcodes + toff[t], rcodes + qoff[q], table, 1, sam, sam ? rr->edit_distance : -1);
+					write_alignment(a, &targets[t], &reads[q], rcseq[q], tcodes + toff[t], rcodes + qoff[q], table, 1, sam, sam && rr->cigarLen > 0 ? rr->edit_distance : -1);
 					align_destroy(a);
 				} else if (r->score1 > 0 && r->score1 >= filter) {
 					s_align* a = ssw_gpu_result_to_align(r, pool);
 					if (a->flag == 2) fprintf(stderr, "Warning: The alignment of the following sequences may miss a small part.\nref_seq: %s\nread_seq: %s\n\n", targets[t].name, reads[q].name);
-					write_alignment(a, &targets[t], &reads[q], reads[q].seq, tcodes + toff[t], qcodes + qoff[q], table, 0, sam, sam ? r->edit_distance : -1);
+					write_alignment(a, &targets[t], &reads[q], reads[q].seq, tcodes + toff[t], qcodes + qoff[q], table, 0, sam, sam && r->cigarLen > 0 ? r->edit_distance : -1);
 					align_destroy(a);
 				} else if (r->score1 <= 0) {
 					fprintf(stderr, "There is no identical residue between the following reference and read seqeunces.\nref_name: %s\nread_name: %s\n\n", targets[t].name, reads[q].name);

@@ -15,6 +15,7 @@ extern "C" {
 
 #define SSW_RMAX 24            /* rows per lane supported by the 16-lane chains: queries up to 16*24 = 384 residues */
 #define SSW_MAX_N 32           /* alphabet size limit (profile residues held in LDS) */
+#define SSW_LDS_LIMIT (160 * 1024)   /* LDS per workgroup on gfx950 */
 
 /* two queries that share one systolic chain (low / high 16-bit half of every VGPR) */
 typedef struct {
@@ -283,6 +284,7 @@ int ssw_shim_fill_resident_blocks(int R, int n);
 int ssw_shim_launch_filldb(int R, const ssw_filldb_args* a, void* stream);
 int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream);
 int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* stream);
+int64_t ssw_shim_capture_lds_need(int R, int n);   /* dynamic LDS of one k_capture<R> workgroup */
 int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args* a, void* stream);
 int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream);
 int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);

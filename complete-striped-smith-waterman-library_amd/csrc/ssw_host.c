@@ -89,14 +89,20 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
 	if (device < 0 || device >= n) { fail(0, "device index out of range%s", ""); return 0; }
 	if (ssw_shim_set_device(device)) { fail(0, "hipSetDevice failed: %s", ssw_shim_last_error()); return 0; }
 	ssw_gpu_ctx* c = (ssw_gpu_ctx*)calloc(1, sizeof(*c));
+	if (!c) { fail(0, "out of host memory%s", ""); return 0; }
 	c->device = device;
 	c->stream = ssw_shim_stream_create();
 	c->stream2 = ssw_shim_stream_create();
-	for (int i = 0; i < SSW_TSTREAMS; ++i) { c->tstream[i] = ssw_shim_stream_create(); c->tev[i] = ssw_shim_event_create(); }
-	for (int i = 0; i < 2; ++i) { c->ev_fill[i] = ssw_shim_event_create(); c->ev_red[i] = ssw_shim_event_create(); }
+	int ok = c->stream && c->stream2;
+	for (int i = 0; i < SSW_TSTREAMS; ++i) { c->tstream[i] = ssw_shim_stream_create(); c->tev[i] = ssw_shim_event_create(); ok = ok && c->tstream[i] && c->tev[i]; }
+	for (int i = 0; i < 2; ++i) { c->ev_fill[i] = ssw_shim_event_create(); c->ev_red[i] = ssw_shim_event_create(); ok = ok && c->ev_fill[i] && c->ev_red[i]; }
 	c->ev_t0 = ssw_shim_event_create(); c->ev_a = ssw_shim_event_create(); c->ev_b = ssw_shim_event_create();
 	c->ev_c = ssw_shim_event_create(); c->ev_d = ssw_shim_event_create();
-	if (!c->stream || !c->ev_t0 || !c->ev_d) { fail(0, "stream/event creation failed: %s", ssw_shim_last_error()); free(c); return 0; }
+	if (!ok || !c->ev_t0 || !c->ev_a || !c->ev_b || !c->ev_c || !c->ev_d) {
+		fail(0, "stream/event creation failed: %s", ssw_shim_last_error());
+		ssw_gpu_close(c);      /* destroys whatever was created (NULL handles are skipped) */
+		return 0;
+	}
 	const char* e = getenv("SSW_GPU_CM_BUDGET_MB");
 	c->cm_budget = e ? (size_t)atoll(e) << 20 : (size_t)64 << 30;
 	if (!e) { size_t fr = ssw_shim_mem_free_bytes(); if (fr && c->cm_budget > fr / 2) c->cm_budget = fr / 2; }
@@ -107,7 +113,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 {
 	if (!c) return;
 	ssw_shim_set_device(c->device);
-	ssw_shim_stream_sync(c->stream);
+	if (c->stream) ssw_shim_stream_sync(c->stream);
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
 	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->cigar2); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand); dbuf_free(&c->tresume);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
@@ -121,17 +127,28 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	free(c);
 }
 
-ssw_gpu_seqs* ssw_gpu_seqs_upload(ssw_gpu_ctx* c, const int8_t* codes, const int64_t* offsets, int32_t count)
+/* host-side shell of a sequence set + its two device arrays (codes, offsets); NULL with the error set on failure */
+static ssw_gpu_seqs* seqs_new(ssw_gpu_ctx* c, const int64_t* offsets, int32_t count)
 {
-	if (!c || count < 0 || !offsets) { fail(c, "seqs_upload: bad arguments%s", ""); return 0; }
-	ssw_shim_set_device(c->device);
 	ssw_gpu_seqs* s = (ssw_gpu_seqs*)calloc(1, sizeof(*s));
+	if (!s) { fail(c, "out of host memory%s", ""); return 0; }
 	s->ctx = c; s->count = count; s->total = offsets[count] - offsets[0];
 	s->h_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)count + 1));
+	if (!s->h_off || s->total < 0) { fail(c, s->h_off ? "seqs: offsets must not decrease%s" : "out of host memory%s", ""); ssw_gpu_seqs_free(s); return 0; }
 	for (int32_t i = 0; i <= count; ++i) s->h_off[i] = offsets[i] - offsets[0];
+	for (int32_t i = 0; i < count; ++i) if (s->h_off[i + 1] < s->h_off[i]) { fail(c, "seqs: offsets must not decrease%s", ""); ssw_gpu_seqs_free(s); return 0; }
 	s->d_codes = (int8_t*)ssw_shim_malloc((size_t)s->total + 64);   /* +64: ring prefetch may not run past the end, but keep slack */
 	s->d_off = (int64_t*)ssw_shim_malloc(sizeof(int64_t) * ((size_t)count + 1));
 	if (!s->d_codes || !s->d_off) { fail(c, "device allocation failed: %s", ssw_shim_last_error()); ssw_gpu_seqs_free(s); return 0; }
+	return s;
+}
+
+ssw_gpu_seqs* ssw_gpu_seqs_upload(ssw_gpu_ctx* c, const int8_t* codes, const int64_t* offsets, int32_t count)
+{
+	if (!c || count < 0 || !offsets || (!codes && offsets[count] != offsets[0])) { fail(c, "seqs_upload: bad arguments%s", ""); return 0; }
+	ssw_shim_set_device(c->device);
+	ssw_gpu_seqs* s = seqs_new(c, offsets, count);
+	if (!s) return 0;
 	if (ssw_shim_h2d(s->d_codes, codes + offsets[0], (size_t)s->total, c->stream) ||
 	    ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * ((size_t)count + 1), c->stream) ||
 	    ssw_shim_stream_sync(c->stream)) {
@@ -149,17 +166,13 @@ void ssw_gpu_seqs_free(ssw_gpu_seqs* s)
 
 ssw_gpu_seqs* ssw_gpu_seqs_upload_ascii(ssw_gpu_ctx* c, const char* text, const int64_t* offsets, int32_t count, const int8_t* table128)
 {
-	if (!c || count < 0 || !offsets || !table128) { fail(c, "seqs_upload_ascii: bad arguments%s", ""); return 0; }
+	if (!c || count < 0 || !offsets || !table128 || (!text && offsets[count] != offsets[0])) { fail(c, "seqs_upload_ascii: bad arguments%s", ""); return 0; }
 	ssw_shim_set_device(c->device);
-	ssw_gpu_seqs* s = (ssw_gpu_seqs*)calloc(1, sizeof(*s));
-	s->ctx = c; s->count = count; s->total = offsets[count] - offsets[0];
-	s->h_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)count + 1));
-	for (int32_t i = 0; i <= count; ++i) s->h_off[i] = offsets[i] - offsets[0];
-	s->d_codes = (int8_t*)ssw_shim_malloc((size_t)s->total + 64);
-	s->d_off = (int64_t*)ssw_shim_malloc(sizeof(int64_t) * ((size_t)count + 1));
+	ssw_gpu_seqs* s = seqs_new(c, offsets, count);
+	if (!s) return 0;
 	uint8_t* d_text = (uint8_t*)ssw_shim_malloc((size_t)s->total + 64);
 	int8_t* d_tab = (int8_t*)ssw_shim_malloc(128);
-	int ok = s->d_codes && s->d_off && d_text && d_tab;
+	int ok = d_text && d_tab;
 	if (ok) {
 		ssw_prep_args pa; memset(&pa, 0, sizeof pa);
 		pa.text = d_text; pa.table = d_tab; pa.off = s->d_off; pa.count = count; pa.total = s->total; pa.out = s->d_codes; pa.mode = 0;
@@ -176,20 +189,14 @@ ssw_gpu_seqs* ssw_gpu_seqs_revcomp(ssw_gpu_ctx* c, const ssw_gpu_seqs* in)
 {
 	if (!c || !in || in->ctx != c) { fail(c, "seqs_revcomp: bad arguments%s", ""); return 0; }
 	ssw_shim_set_device(c->device);
-	ssw_gpu_seqs* s = (ssw_gpu_seqs*)calloc(1, sizeof(*s));
-	s->ctx = c; s->count = in->count; s->total = in->total;
-	s->h_off = (int64_t*)malloc(sizeof(int64_t) * ((size_t)in->count + 1));
-	memcpy(s->h_off, in->h_off, sizeof(int64_t) * ((size_t)in->count + 1));
-	s->d_codes = (int8_t*)ssw_shim_malloc((size_t)s->total + 64);
-	s->d_off = (int64_t*)ssw_shim_malloc(sizeof(int64_t) * ((size_t)in->count + 1));
-	int ok = s->d_codes && s->d_off;
-	if (ok) {
-		ssw_prep_args pa; memset(&pa, 0, sizeof pa);
-		pa.codes_in = in->d_codes; pa.off = in->d_off; pa.count = in->count; pa.total = in->total; pa.out = s->d_codes; pa.mode = 1;
-		ok = !(ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * ((size_t)in->count + 1), c->stream) ||
-		       ssw_shim_launch_prep(&pa, c->stream) || ssw_shim_stream_sync(c->stream));
+	ssw_gpu_seqs* s = seqs_new(c, in->h_off, in->count);
+	if (!s) return 0;
+	ssw_prep_args pa; memset(&pa, 0, sizeof pa);
+	pa.codes_in = in->d_codes; pa.off = in->d_off; pa.count = in->count; pa.total = in->total; pa.out = s->d_codes; pa.mode = 1;
+	if (ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * ((size_t)in->count + 1), c->stream) ||
+	    ssw_shim_launch_prep(&pa, c->stream) || ssw_shim_stream_sync(c->stream)) {
+		fail(c, "revcomp failed: %s", ssw_shim_last_error()); ssw_gpu_seqs_free(s); return 0;
 	}
-	if (!ok) { fail(c, "revcomp failed: %s", ssw_shim_last_error()); ssw_gpu_seqs_free(s); return 0; }
 	return s;
 }
 
@@ -219,7 +226,9 @@ static void* next_event(ssw_gpu_ctx* c)
 {
 	if (c->nev == c->capev) {
 		int nc = c->capev ? c->capev * 2 : 64;
-		c->ev = (void**)realloc(c->ev, sizeof(void*) * nc);
+		void** ne = (void**)realloc(c->ev, sizeof(void*) * nc);
+		if (!ne) return 0;     /* no memory for another timing event: this launch goes untimed (a NULL event is refused by the runtime) */
+		c->ev = ne;
 		for (int i = c->capev; i < nc; ++i) c->ev[i] = ssw_shim_event_create();
 		c->capev = nc;
 	}
@@ -268,6 +277,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 	tkey* tk = (tkey*)malloc(sizeof(tkey) * (size_t)tcount);
 	int32_t* tl = (int32_t*)malloc(sizeof(int32_t) * (size_t)tcount);
 	ssw_dres* hres = 0;
+	if (!tk || !tl) { free(tk); free(tl); return fail(c, "out of host memory%s", ""); }
 	/* queries of 385..640 residues: size classes R' in {28, 32, 36, 40} (k_filldb<R', masked>), paired by length */
 	bucket mid[4]; int nmid = 0;
 	ssw_pair* midpairs = 0; const ssw_pair* d_midpairs = 0;
@@ -277,6 +287,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		if (nm > 0) {
 			keyed* mk = (keyed*)malloc(sizeof(keyed) * (size_t)nm);
 			midpairs = (ssw_pair*)malloc(sizeof(ssw_pair) * (size_t)nm);
+			if (!mk || !midpairs) { free(mk); free(midpairs); free(tk); free(tl); return fail(c, "out of host memory%s", ""); }
 			int32_t k = 0, np = 0;
 			for (int32_t q = 0; q < nq; ++q) { const int64_t L = Q->h_off[q + 1] - Q->h_off[q]; if (L > 16 * SSW_RMAX && L <= 640) { mk[k].key = (int32_t)L; mk[k].q = q; ++k; } }
 			qsort(mk, (size_t)nm, sizeof(keyed), keyed_cmp);
@@ -305,7 +316,6 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 	int64_t tsub = (int64_t)(c->cm_budget / 2) / ((int64_t)nq * (int64_t)sizeof(ssw_dres));
 	if (tsub < 16) tsub = 16;
 	if (tsub > tcount) tsub = tcount;
-	hres = (ssw_dres*)malloc(sizeof(ssw_dres) * (size_t)nq * (size_t)tsub);
 	for (int32_t t0 = 0; t0 < tcount; t0 += (int32_t)tsub) {
 		const int32_t nt = tcount - t0 < tsub ? tcount - t0 : (int32_t)tsub;
 		for (int32_t k = 0; k < nt; ++k) { tk[k].t = tfirst + t0 + k; tk[k].len = (int32_t)(T->h_off[tfirst + t0 + k + 1] - T->h_off[tfirst + t0 + k]); }
@@ -370,7 +380,14 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 				c->tm.cells += qsum * L;
 				if (L == 0) for (int32_t q = 0; q < nq; ++q) { ssw_gpu_result* o = &results[(int64_t)q * tcount + k]; o->ref_begin1 = -1; o->read_begin1 = -1; o->cigar_off = -1; }
 			}
+			for (int32_t q = 0; q < nq; ++q)      /* empty queries: no kernel wrote their rows */
+				if (Q->h_off[q + 1] == Q->h_off[q])
+					for (int32_t k = 0; k < nt; ++k) { ssw_gpu_result* o = &results[(int64_t)q * tcount + k]; o->ref_begin1 = -1; o->read_begin1 = -1; o->cigar_off = -1; }
 			continue;
+		}
+		if (!hres) {     /* only the sub-batched path converts records on the host (the direct path downloads final-layout records) */
+			hres = (ssw_dres*)malloc(sizeof(ssw_dres) * (size_t)nq * (size_t)tsub);
+			if (!hres) { fail(c, "out of host memory (%s)", "database-search record staging"); goto done; }
 		}
 		if (ssw_shim_d2h(hres, d_res, sizeof(ssw_dres) * (size_t)nq * (size_t)nt, c->stream) || ssw_shim_stream_sync(c->stream)) {
 			fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
@@ -412,35 +429,52 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 	for (int32_t i = 0; i < n * n; ++i) { if (prm->mat[i] < bias) bias = prm->mat[i]; if (prm->mat[i] > maxmat) maxmat = prm->mat[i]; }
 	bias = (prm->score_size == 0 || prm->score_size == 2) ? -bias : 0;
 
-	/* bucket the queries by chain geometry, pair neighbours inside a bucket */
+	/* bucket the queries by chain geometry, pair neighbours inside a bucket.  Empty queries take no part: the reference gives
+	   them the empty record (score 0, begins -1; src/ssw.c:900-903), which is what an untouched result record reads as. */
 	int32_t* order = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
 	uint8_t* qdone = (uint8_t*)calloc((size_t)nq, 1);   /* queries whose records came out of the fused database-search path */
 	ssw_pair* pairs = (ssw_pair*)malloc(sizeof(ssw_pair) * ((size_t)nq + 1));
 	keyed* keys = (keyed*)malloc(sizeof(keyed) * (size_t)nq);
 	bucket* bk = 0; int nb = 0;
-	int32_t maxlen = 0, npairs_total = 0;
+	int32_t maxlen = 0, npairs_total = 0, nqa = 0;    /* nqa: non-empty queries = entries of `order` */
+	if (!order || !qdone || !pairs || !keys) { free(order); free(pairs); free(keys); free(qdone); return fail(c, "out of host memory%s", ""); }
 	for (int32_t q = 0; q < nq; ++q) {
 		int64_t len = Q->h_off[q + 1] - Q->h_off[q];
-		if (len < 1 || len > 0x3fffff00) {
+		if (len > 0x3fffff00) {
 			free(order); free(pairs); free(keys); free(qdone);
-			return fail(c, "align_batch: empty (or absurdly long) query%s", "");
+			return fail(c, "align_batch: query longer than 2^30 residues%s", "");
 		}
+		if (len == 0) continue;
 		if (len > maxlen) maxlen = (int32_t)len;
-		keys[q].q = q;
-		keys[q].key = len <= 16 * SSW_RMAX ? (int32_t)((len + 15) / 16) : (int32_t)(SSW_RMAX + (len + 15) / 16);
+		keys[nqa].q = q;
+		keys[nqa].key = len <= 16 * SSW_RMAX ? (int32_t)((len + 15) / 16) : (int32_t)(SSW_RMAX + (len + 15) / 16);
+		++nqa;
 	}
-	qsort(keys, (size_t)nq, sizeof(keyed), keyed_cmp);
+	if (nqa == 0) {     /* nothing but empty queries */
+		for (int64_t k = 0; k < (int64_t)nq * tcount; ++k) {
+			ssw_gpu_result* o = &results[k];
+			memset(o, 0, sizeof *o); o->ref_begin1 = -1; o->read_begin1 = -1; o->cigar_off = -1;
+		}
+		memset(&c->tm, 0, sizeof c->tm);
+		free(order); free(pairs); free(keys); free(qdone);
+		return 0;
+	}
+	qsort(keys, (size_t)nqa, sizeof(keyed), keyed_cmp);
 	/* long queries: the wavefront is one chain of 64 lanes; rows per lane bounded so that one profile stays near 24 KiB
 	   of LDS (several waves per CU).  SSW_GPU_XLANES=16 / SSW_GPU_XR=<rows per lane> override (experiments). */
 	int32_t xlanes = 64, xrmax = 4 * (24 / (n + 1) < 1 ? 1 : 24 / (n + 1) > 3 ? 3 : 24 / (n + 1));
 	{
 		const char* e = getenv("SSW_GPU_XLANES"); if (e && atoi(e) == 16) xlanes = 16;
 		e = getenv("SSW_GPU_XR"); if (e && atoi(e) >= 1 && atoi(e) <= 16) xrmax = atoi(e);
+		/* the target rings hold profile offsets as 16-bit values: residue n (the null column) x ceil(R/4) KiB must stay below 64 KiB */
+		while (xlanes == 64 && xrmax > 4 && (int64_t)n * ((xrmax + 3) / 4) * 1024 > 65535) xrmax -= 4;
 	}
-	for (int32_t i = 0; i < nq; ) {
+	for (int32_t i = 0; i < nqa; ) {
 		int32_t j = i;
-		while (j < nq && keys[j].key == keys[i].key) ++j;
-		bk = (bucket*)realloc(bk, sizeof(bucket) * (size_t)(nb + 1));
+		while (j < nqa && keys[j].key == keys[i].key) ++j;
+		bucket* nbk = (bucket*)realloc(bk, sizeof(bucket) * (size_t)(nb + 1));
+		if (!nbk) { free(bk); free(order); free(pairs); free(keys); free(qdone); return fail(c, "out of host memory%s", ""); }
+		bk = nbk;
 		bucket b;
 		if (keys[i].key <= SSW_RMAX) { b.R = keys[i].key; b.strips = 1; b.P16 = 16 * b.R; b.lanes = 16; b.use_x = 0; }
 		else {
@@ -469,6 +503,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 	int32_t* hneed = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
 	memset(&c->tm, 0, sizeof c->tm);
 	c->nev = 0;
+	if (!hres || !hneed) { fail(c, "out of host memory%s", ""); goto done; }
 
 	int8_t* d_mat = (int8_t*)ensure(c, &c->mat, (size_t)n * n);
 	ssw_pair* d_pairs = (ssw_pair*)ensure(c, &c->pairs, sizeof(ssw_pair) * (size_t)npairs_total);
@@ -478,7 +513,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 	ssw_shim_event_record(c->ev_t0, c->stream);
 	if (ssw_shim_h2d(d_mat, prm->mat, (size_t)n * n, c->stream) ||
 	    ssw_shim_h2d(d_pairs, pairs, sizeof(ssw_pair) * (size_t)npairs_total, c->stream) ||
-	    ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nq, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
+	    ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nqa, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
 
 	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
 	double fill_ms = 0, reduce_ms = 0, locate_ms = 0, trace_ms = 0;
@@ -493,6 +528,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 		/* (k_filldb takes the column maximum of two rows with a 16-bit float max3, valid below 31744: 640 rows x max(mat) <= 49) */
 		if (!literal && prm->flag == 0 && tcount >= 4 && any_short && maxt <= 65536 && maxmat <= 49 && !(dis && dis[0] == '1')) {
 			for (int b = 0; b < nb; ++b) if (!bk[b].use_x || bk[b].P16 <= 640) for (int32_t k = 0; k < bk[b].nq; ++k) qdone[order[bk[b].first_q + k]] = 1;
+			for (int32_t q = 0; q < nq; ++q) if (Q->h_off[q + 1] == Q->h_off[q]) qdone[q] = 1;     /* empty queries: empty records, written there */
 			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone)) goto done;
 			d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq);   /* align_db may have regrown the record buffer */
 			if (!d_res) goto done;
@@ -651,7 +687,11 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 				for (int b = 0; b < nb; ++b) {
 					const bucket* B = &bk[b];
 					if (qdone[order[B->first_q]]) continue;
-					if (B->use_x) {
+					/* short-query buckets whose four per-chain profiles would not fit the LDS of a workgroup (alphabets near 32
+					   symbols with many rows per lane) take the strip kernel's window mode: one profile per wavefront */
+					const int cap_x = B->use_x || ssw_shim_capture_lds_need(B->R, n) > SSW_LDS_LIMIT;
+					const int32_t capR = B->use_x ? B->R : ((B->P16 + 63) / 64 < xrmax ? (B->P16 + 63) / 64 : xrmax), capL = B->use_x ? B->lanes : xlanes;
+					if (cap_x) {
 						const int32_t hw = halo_for(B->P16, maxmat, prm->gapE);
 						const int64_t wcols = (((int64_t)(hw < refLen ? hw : refLen) + 1) + 31) / 16 * 16;
 						int64_t per = (int64_t)(c->cm_budget / (size_t)(16 * wcols)); if (per < 1) per = 1;
@@ -663,7 +703,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 							xa.tgt = d_tgt; xa.refLen = refLen; xa.qcodes = Q->d_codes; xa.qoff = Q->d_off; xa.mat = d_mat; xa.n = n;
 							xa.gapO2 = gapO2; xa.gapE2 = gapE2; xa.gapE = prm->gapE; xa.maxmat = maxmat; xa.njobs = cnt_q;
 							xa.qlist = d_qlist + B->first_q + q0; xa.reverse = pass; xa.flag = prm->flag; xa.filters = prm->filters;
-							xa.filterd = prm->filterd; xa.res = d_res; xa.bnd = d_bnd; xa.bnd_stride = wcols; xa.lanes = B->lanes;
+							xa.filterd = prm->filterd; xa.res = d_res; xa.bnd = d_bnd; xa.bnd_stride = wcols; xa.lanes = capL;
 							/* reverse pass: a window of rows + 25 % almost always contains the whole alignment; the exact
 							   halo bound (3x the rows for DNA defaults) is only paid by the alignments that miss */
 							int32_t* d_retry = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * (size_t)nq);
@@ -671,12 +711,12 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 							int32_t missed = 0;
 							xa.window_extra = pass ? 64 : -1; xa.retry_count = d_retry;
 							if (ssw_shim_memset(d_retry, 0, sizeof(int32_t), c->stream) ||
-							    ssw_shim_launch_chainx(B->R, 1, &xa, c->stream)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
+							    ssw_shim_launch_chainx(capR, 1, &xa, c->stream)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
 							if (pass) {
 								if (ssw_shim_d2h(&missed, d_retry, sizeof(int32_t), c->stream) || ssw_shim_stream_sync(c->stream)) { fail(c, "download failed: %s", ssw_shim_last_error()); goto done; }
 								if (missed > 0) {
 									xa.window_extra = -1;
-									if (ssw_shim_launch_chainx(B->R, 1, &xa, c->stream)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
+									if (ssw_shim_launch_chainx(capR, 1, &xa, c->stream)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
 								}
 							}
 						}
@@ -717,14 +757,16 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 			tpend* pend = (tpend*)malloc(sizeof(tpend) * (size_t)nq);     /* key = band that did not fit, need in 4-KiB units, q = query */
 			int32_t* lst = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
 			int32_t* hband = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
-			int32_t npend = nq;
-			for (int32_t k = 0; k < nq; ++k) { pend[k].key = 0; pend[k].need = 0; pend[k].q = order[k]; }
+			if (!pend || !lst || !hband) { free(pend); free(lst); free(hband); fail(c, "out of host memory%s", ""); goto done; }
+			int32_t npend = nqa;
+			for (int32_t k = 0; k < nqa; ++k) { pend[k].key = 0; pend[k].need = 0; pend[k].q = order[k]; }
 			const int64_t full = (int64_t)maxlen + (halo_max < refLen ? halo_max : refLen);
 			const int64_t worst = (3 * (2 * full + 8) * 4 + (2 * full + 1) * (int64_t)maxlen * 3 + 64 + 15) / 16 * 16;
 			int trace_ok = 1;
 			for (int round = 0; round < 10 && npend > 0 && trace_ok; ++round) {
 				tpend* nextp = (tpend*)malloc(sizeof(tpend) * (size_t)npend);
 				int32_t nnext = 0;
+				if (!nextp) { fail(c, "out of host memory%s", ""); trace_ok = 0; break; }
 				if (round > 0) qsort(pend, (size_t)npend, sizeof(tpend), tpend_cmp);
 				if (round == 0) {
 					int64_t per_launch = (int64_t)((size_t)32 << 30) / sstride; if (per_launch < 1) per_launch = 1;
@@ -758,6 +800,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 					   (each is bound by the latency of its longest alignment, not by throughput). */
 					int64_t* hoff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)npend * 2 + 2));
 					int32_t* hall = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)npend);
+					if (!hoff || !hall) { free(hoff); free(hall); free(nextp); fail(c, "out of host memory%s", ""); trace_ok = 0; break; }
 					const int64_t budget = (int64_t)c->cm_budget * 2;
 					for (int32_t k = 0; k < npend; ++k) lst[k] = pend[k].q;
 					int64_t* d_soff = (int64_t*)ensure(c, &c->goff, sizeof(int64_t) * ((size_t)npend * 2 + 2));
@@ -838,7 +881,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 			free(pend); free(lst); free(hband);
 			if (!trace_ok) goto done;
 			if (npend > 0) { fail(c, "internal error: traceback scratch negotiation did not converge%s", ""); goto done; }
-			if (did_trace && ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nq, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
+			if (did_trace && ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nqa, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
 		}
 		if (did_trace && prm->mark_mismatch) {   /* SAM-style CIGARs + edit distance, rewritten on the device */
 			const int64_t m_stride = (cig_stride + maxlen + 8 + 3) / 4 * 4;
@@ -859,6 +902,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 		for (int32_t q = 0; q < nq; ++q) if (hres[q].cigarLen > 0 && hres[q].status == 0) gwords += hres[q].cigarLen;
 		if (gwords > 0) {
 			goffs = (int64_t*)malloc(sizeof(int64_t) * (size_t)nq);
+			if (!goffs) { fail(c, "out of host memory%s", ""); goto done; }
 			int64_t at = 0;
 			for (int32_t q = 0; q < nq; ++q) { goffs[q] = at; if (hres[q].cigarLen > 0 && hres[q].status == 0) at += hres[q].cigarLen; }
 			int64_t* d_goff = (int64_t*)ensure(c, &c->goff, sizeof(int64_t) * (size_t)nq);
@@ -866,7 +910,9 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 			if (!d_goff || !d_gpool) { free(goffs); goto done; }
 			if (pool_words + gwords > pool_cap) {
 				pool_cap = (pool_words + gwords) * 2 + 1024;
-				pool = (uint32_t*)realloc(pool, sizeof(uint32_t) * (size_t)pool_cap);
+				uint32_t* npool = (uint32_t*)realloc(pool, sizeof(uint32_t) * (size_t)pool_cap);
+				if (!npool) { fail(c, "out of host memory (%s)", "CIGAR pool"); free(goffs); goto done; }
+				pool = npool;
 			}
 			ssw_gather_args ga; ga.src = d_cig; ga.res = d_res; ga.dst_off = d_goff; ga.dst = d_gpool; ga.nq = nq;
 			if (ssw_shim_h2d(d_goff, goffs, sizeof(int64_t) * (size_t)nq, c->stream) || ssw_shim_launch_gather(&ga, c->stream) ||
@@ -995,7 +1041,14 @@ static ssw_gpu_ctx* default_ctx(void)
 
 s_profile* ssw_init(const int8_t* read, const int32_t readLen, const int8_t* mat, const int32_t n, const int8_t score_size)
 {
+	/* the reference has no error return here and reads `readLen` residues unconditionally; a negative length or missing
+	   arrays can only be a caller bug, so they are refused (ssw_align then reports the missing profile) */
+	if (readLen < 0 || (readLen > 0 && !read) || !mat || n < 1) {
+		fprintf(stderr, "ssw_init: invalid arguments (readLen %d, n %d).\n", (int)readLen, (int)n);
+		return 0;
+	}
 	s_profile* p = (s_profile*)calloc(1, sizeof(struct _profile));
+	if (!p) return 0;
 	p->read = read; p->mat = mat; p->readLen = readLen; p->n = n; p->score_size = score_size;
 	return p;
 }

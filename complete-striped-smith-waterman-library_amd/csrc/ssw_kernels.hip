@@ -1982,15 +1982,21 @@ static int shim_check(hipError_t e, const char* what)
 	snprintf(g_shim_err, sizeof g_shim_err, "%s: %s", what, hipGetErrorString(e));
 	return -1;
 }
-/* dynamic LDS above 64 KiB (large protein profiles: up to 160 KiB per workgroup on gfx950) needs an opt-in per kernel */
+/* dynamic LDS above 64 KiB (large protein profiles: up to 160 KiB per workgroup on gfx950) needs an opt-in per kernel; a
+   refused opt-in (or a request beyond the device limit) makes the launch fail with a message instead of a late HIP error */
+#define SSW_LDS_MAX (160u * 1024u)
+static thread_local int g_lds_refused;
 template <class K> static void shim_allow_lds(K kern, size_t bytes)
 {
-	if (bytes > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if (bytes <= 65536) return;
+	if (bytes > SSW_LDS_MAX) { g_lds_refused = 1; snprintf(g_shim_err, sizeof g_shim_err, "kernel needs %zu bytes of LDS (limit %u)", bytes, SSW_LDS_MAX); return; }
+	const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+	if (e != hipSuccess) { g_lds_refused = 1; snprintf(g_shim_err, sizeof g_shim_err, "hipFuncSetAttribute(%zu bytes of LDS): %s", bytes, hipGetErrorString(e)); }
 }
 #define SSW_LAUNCH(kern, A, args, grid, block, ldsbytes, stream) \
-	do { shim_allow_lds(kern, (size_t)(ldsbytes)); \
-	     hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(ldsbytes), (hipStream_t)(stream), args); } while (0)
-#define SSW_LAUNCH_OK() shim_check(hipGetLastError(), "kernel launch")
+	do { g_lds_refused = 0; shim_allow_lds(kern, (size_t)(ldsbytes)); \
+	     if (!g_lds_refused) hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3((unsigned)(block)), (size_t)(ldsbytes), (hipStream_t)(stream), args); } while (0)
+#define SSW_LAUNCH_OK() (g_lds_refused ? -1 : shim_check(hipGetLastError(), "kernel launch"))
 #endif
 
 #define FOR_EACH_R(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) \
@@ -2075,6 +2081,15 @@ extern "C" int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* s
 		default: return -2;
 	}
 	return SSW_LAUNCH_OK();
+}
+
+/* dynamic LDS one k_capture<R> workgroup asks for (4 chains, each with its own profile): the host routes buckets whose
+   request exceeds the device limit (wide alphabets x many rows per lane) through k_chainx, one profile per wavefront */
+extern "C" int64_t ssw_shim_capture_lds_need(int R, int n)
+{
+	if (R < 1 || R > SSW_RMAX) return -1;
+	const int64_t C = (R + 3) / 4;
+	return 4 * ((int64_t)(n + 1) * C * 256 + CHAIN_BYTES);
 }
 
 extern "C" int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args* a, void* stream)

@@ -73,7 +73,16 @@ typedef struct {
 	const int8_t* ref; int32_t refLen; const int8_t* mat; int32_t n;
 	uint8_t gapO, gapE, flag; uint16_t filters; int32_t filterd; int32_t maskLen;
 	int32_t* res; int tid, nthreads;
+	uint32_t* cig_hash;                                  /* optional: FNV-1a over the CIGAR words of every alignment */
+	const int8_t* tcodes; const int64_t* toff; int32_t nt;   /* database mode: several targets per query */
 } refwrap_job;
+
+static uint32_t refwrap_fnv(const uint32_t* w, int32_t n)
+{
+	uint32_t h = 2166136261u;
+	for (int32_t i = 0; i < n; ++i) for (int b = 0; b < 4; ++b) { h ^= (w[i] >> (8 * b)) & 0xffu; h *= 16777619u; }
+	return h;
+}
 
 static void* refwrap_worker(void* arg)
 {
@@ -89,17 +98,65 @@ static void* refwrap_worker(void* arg)
 			r[0] = a->score1; r[1] = a->score2; r[2] = a->ref_begin1; r[3] = a->ref_end1;
 			r[4] = a->read_begin1; r[5] = a->read_end1; r[6] = a->ref_end2; r[7] = a->cigarLen;
 			r[8] = a->flag; r[9] = 0;
+			if (j->cig_hash) j->cig_hash[q] = a->cigarLen > 0 && a->cigar ? refwrap_fnv(a->cigar, a->cigarLen) : 0u;
 			align_destroy(a);
-		} else { for (int k = 0; k < 9; ++k) r[k] = 0; r[9] = 1; }
+		} else { for (int k = 0; k < 9; ++k) r[k] = 0; r[9] = 1; if (j->cig_hash) j->cig_hash[q] = 0u; }
 		init_destroy(p);
 	}
 	return 0;
 }
 
+/* database mode (the loop of reference src/main.c:462-526): one profile per query, every target; score-only records of
+   5 int32 (score1 score2 ref_end1 read_end1 ref_end2) at res[(q * nt + t) * 5] */
+static void* refwrap_db_worker(void* arg)
+{
+	refwrap_job* j = (refwrap_job*)arg;
+	for (int32_t q = j->tid; q < j->nq; q += j->nthreads) {
+		const int8_t* rd = j->qcodes + j->qoff[q];
+		int32_t len = (int32_t)(j->qoff[q + 1] - j->qoff[q]);
+		int32_t maskLen = j->maskLen >= 0 ? j->maskLen : len / 2;
+		s_profile* p = ssw_init(rd, len, j->mat, j->n, 2);
+		for (int32_t t = 0; t < j->nt; ++t) {
+			s_align* a = ssw_align(p, j->tcodes + j->toff[t], (int32_t)(j->toff[t + 1] - j->toff[t]), j->gapO, j->gapE, 0, 0, 0, maskLen);
+			int32_t* r = j->res + ((int64_t)q * j->nt + t) * 5;
+			if (a) { r[0] = a->score1; r[1] = a->score2; r[2] = a->ref_end1; r[3] = a->read_end1; r[4] = a->ref_end2; align_destroy(a); }
+			else { r[0] = r[1] = r[2] = r[3] = r[4] = -9; }
+		}
+		init_destroy(p);
+	}
+	return 0;
+}
+
+static double refwrap_run(refwrap_job proto, int32_t nthreads, void* (*worker)(void*));
+
 double refwrap_bench(const int8_t* qcodes, const int64_t* qoff, int32_t nq,
                      const int8_t* ref, int32_t refLen, const int8_t* mat, int32_t n,
                      uint8_t gapO, uint8_t gapE, uint8_t flag, uint16_t filters, int32_t filterd,
                      int32_t maskLen, int32_t nthreads, int32_t* res)
+{
+	refwrap_job j = { qcodes, qoff, nq, ref, refLen, mat, n, gapO, gapE, flag, filters, filterd, maskLen, res, 0, nthreads, 0, 0, 0, 0 };
+	return refwrap_run(j, nthreads, refwrap_worker);
+}
+
+/* same, additionally hash[q] = FNV-1a of the CIGAR words (0: no CIGAR) */
+double refwrap_bench_hash(const int8_t* qcodes, const int64_t* qoff, int32_t nq,
+                          const int8_t* ref, int32_t refLen, const int8_t* mat, int32_t n,
+                          uint8_t gapO, uint8_t gapE, uint8_t flag, uint16_t filters, int32_t filterd,
+                          int32_t maskLen, int32_t nthreads, int32_t* res, uint32_t* hash)
+{
+	refwrap_job j = { qcodes, qoff, nq, ref, refLen, mat, n, gapO, gapE, flag, filters, filterd, maskLen, res, 0, nthreads, hash, 0, 0, 0 };
+	return refwrap_run(j, nthreads, refwrap_worker);
+}
+
+double refwrap_bench_db(const int8_t* qcodes, const int64_t* qoff, int32_t nq,
+                        const int8_t* tcodes, const int64_t* toff, int32_t nt, const int8_t* mat, int32_t n,
+                        uint8_t gapO, uint8_t gapE, int32_t maskLen, int32_t nthreads, int32_t* res5)
+{
+	refwrap_job j = { qcodes, qoff, nq, 0, 0, mat, n, gapO, gapE, 0, 0, 0, maskLen, res5, 0, nthreads, 0, tcodes, toff, nt };
+	return refwrap_run(j, nthreads, refwrap_db_worker);
+}
+
+static double refwrap_run(refwrap_job proto, int32_t nthreads, void* (*worker)(void*))
 {
 	if (nthreads < 1) nthreads = 1;
 	pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * nthreads);
@@ -107,9 +164,8 @@ double refwrap_bench(const int8_t* qcodes, const int64_t* qoff, int32_t nq,
 	struct timespec t0, t1;
 	clock_gettime(CLOCK_MONOTONIC, &t0);
 	for (int t = 0; t < nthreads; ++t) {
-		refwrap_job j = { qcodes, qoff, nq, ref, refLen, mat, n, gapO, gapE, flag, filters, filterd, maskLen, res, t, nthreads };
-		jobs[t] = j;
-		pthread_create(&th[t], 0, refwrap_worker, &jobs[t]);
+		jobs[t] = proto; jobs[t].tid = t; jobs[t].nthreads = nthreads;
+		pthread_create(&th[t], 0, worker, &jobs[t]);
 	}
 	for (int t = 0; t < nthreads; ++t) pthread_join(th[t], 0);
 	clock_gettime(CLOCK_MONOTONIC, &t1);

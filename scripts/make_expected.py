@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Reference results for the full-size parity runs (scripts/gpu_parity_full.py), computed HERE (build container) by the
+unmodified reference -- oracle/_ref/libssw_ref.so, built from /root/reference/src/ssw.c by oracle/Makefile -- on the
+seeded workloads of tests/workloads.py, and committed as compressed fixtures under tests/golden/full/.
+
+  config2_block0.npz  all 100 000 reads of BASELINE config 2, flag 2 (scores, ends, begins, CIGAR length + FNV-1a of the CIGAR)
+  config3_block0.npz  first 10 000 reads of read block 0 of config 3 (5 Mb target), flag 2
+  config4_block0.npz  first 1 500 reads of config 4 (10 kb reads, 100 kb target, maskLen 5000), flag 2
+  config5_block0.npz  first 2 048 queries of query block 0 against all 10 000 DB entries (2.05e7 alignments): one 64-bit
+                      checksum per query over its 10 000 x (score1 score2 ref_end1 read_end1 ref_end2), full records of
+                      the first 16 queries
+
+Flag-2 records also check score-only (flag 0) runs: score1, score2, ref_end1, read_end1, ref_end2 do not depend on the flag.
+Usage: python scripts/make_expected.py [2 3 4 5] [--threads N]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from sswutil import _ptr, dna_matrix, i8p, i32p, i64p, ref_lib, u32p   # noqa: E402
+import workloads as W   # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "full")
+FIELDS = "score1 score2 ref_begin1 ref_end1 read_begin1 read_end1 ref_end2 cigarLen flag"
+
+
+def run_dna(R, cfg, count, threads):
+    ref, reads, p = W.dna_config(cfg, 0)
+    reads = np.ascontiguousarray(reads[:count])
+    off = np.arange(count + 1, dtype=np.int64) * p["read_len"]
+    mat = dna_matrix(2, 2)
+    res = np.zeros((count, 10), dtype=np.int32)
+    hsh = np.zeros(count, dtype=np.uint32)
+    secs = R.refwrap_bench_hash(_ptr(reads, i8p), _ptr(off, i64p), count, _ptr(ref, i8p), len(ref), _ptr(mat, i8p), 5, 3, 1, 2, 0, 0,
+                                p["mask_len"], threads, _ptr(res, i32p), _ptr(hsh, u32p))
+    assert (res[:, 9] == 0).all()
+    cells = float(count) * p["read_len"] * p["ref_len"]
+    np.savez_compressed(os.path.join(OUT, "config%d_block0.npz" % cfg), fields=res[:, :9], cigar_fnv=hsh,
+                        meta=np.array([cfg, count, p["read_len"], p["ref_len"], p["seed_ref"], p["seed_reads"]], dtype=np.int64))
+    print("config %d: %d reads, %.1f s on %d threads, %.1f GCUPS; fields: %s" % (cfg, count, secs, threads, cells / secs / 1e9, FIELDS), flush=True)
+
+
+def run_protein(R, nq, threads):
+    db, qs, mat = W.protein_config(0)
+    qs = qs[:nq]
+    qc, qo = W.pack(qs); tc, to = W.pack(db)
+    res = np.zeros((nq, len(db), 5), dtype=np.int32)
+    secs = R.refwrap_bench_db(_ptr(qc, i8p), _ptr(qo, i64p), nq, _ptr(tc, i8p), _ptr(to, i64p), len(db), _ptr(mat, i8p), 24, 3, 1, -1, threads,
+                              _ptr(res, i32p))
+    assert (res != -9).all()
+    sums = W.row_checksums(res.reshape(nq, -1))
+    np.savez_compressed(os.path.join(OUT, "config5_block0.npz"), row_checksum=sums, first16=res[:16], nq=np.int64(nq), nt=np.int64(len(db)))
+    cells = float(qo[-1]) * float(to[-1])
+    print("config 5: %d queries x %d entries, %.1f s on %d threads, %.1f GCUPS" % (nq, len(db), secs, threads, cells / secs / 1e9), flush=True)
+
+
+def main():
+    args = sys.argv[1:]
+    threads = max(1, (os.cpu_count() or 2) - 1)
+    if "--threads" in args:
+        i = args.index("--threads"); threads = int(args[i + 1]); del args[i:i + 2]
+    which = [int(a) for a in args] or [4, 5, 3, 2]
+    R = ref_lib(required=True)
+    os.makedirs(OUT, exist_ok=True)
+    t0 = time.time()
+    for cfg in which:
+        if cfg == 2:
+            run_dna(R, 2, 100_000, threads)
+        elif cfg == 3:
+            run_dna(R, 3, 10_000, threads)
+        elif cfg == 4:
+            run_dna(R, 4, 1_500, threads)
+        elif cfg == 5:
+            run_protein(R, 2048, threads)
+    print("done in %.0f s" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

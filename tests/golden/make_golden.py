@@ -171,7 +171,21 @@ def cli_goldens():
             "scoring_m1x3o5e2": ["-m", "01", "-x", "03", "-o", "05", "-e", "02", "-c", "target.fastq", "query.fastq"],
             "matrix_file_csh": ["-a", "wt.tbl", "-c", "-s", "-h", "target.fastq", "query.fastq"],   # (a file name without option letters)
             "gap_o10_e10": ["-m", "05", "-x", "04", "-o", "10", "-e", "10", "-c", "target.fastq", "query.fastq"],
-            "protein_o11e1": ["-o", "11", "-e", "01", "-p", "-c", "protein1.fa", "protein2.fa"]}
+            "protein_o11e1": ["-o", "11", "-e", "01", "-p", "-c", "protein1.fa", "protein2.fa"],
+            # an empty record between two reads (common after adapter trimming): the reference reports it on stderr and goes on
+            "empty_read_c": ["-c", "target.fastq", "empty_read.fq"], "empty_read_cs": ["-c", "-s", "target.fastq", "empty_read.fq"],
+            # -r together with a matrix file that has neither 5 nor 24 rows: the reference ignores -r (src/main.c:457-490)
+            # -r with a 5-row matrix file: reverse complements are aligned, coded through the FILE's table (src/main.c:457-490);
+            # with -p and a matrix of neither 5 nor 24 rows -r is silently ignored
+            "matrix_file_r5": ["-a", "wt.tbl", "-c", "-r", "target.fastq", "query.fastq"],
+            "matrix_file_p_r_ignored": ["-p", "-a", "wt4.tbl", "-c", "-r", "target.fastq", "query.fastq"],
+            # alignments whose traceback fails (s_align.flag 1, no CIGAR; SURVEY 8.0 "Quirk"): SAM output still carries the soft
+            # clips that mark_mismatch adds (tbfail.fa / tbfail.fq are fixtures of this repo, found by random search)
+            "tbfail_cs": ["-m", "09", "-x", "04", "-c", "-s", "tbfail.fa", "tbfail.fq"], "tbfail_c": ["-m", "09", "-x", "04", "-c", "tbfail.fa", "tbfail.fq"]}
+    # fixture of this repo (not a reference file): the first two demo reads with an empty FASTQ record between them
+    q = open(os.path.join(DEMO, "query.fastq")).read().split("\n")
+    with open(os.path.join(out, "empty_read.fq"), "w") as f:
+        f.write("\n".join(q[:4]) + "\n@empty_after_trimming\n\n+\n\n" + "\n".join(q[4:8]) + "\n")
     for name, args in runs.items():
         r = subprocess.run([exe] + args, cwd=out, capture_output=True, text=True)
         with open(os.path.join(out, name + ".stdout"), "w") as f:

@@ -111,6 +111,12 @@ def ref_lib(required=False):
         L.refwrap_bench.argtypes = [i8p, i64p, C.c_int32, i8p, C.c_int32, i8p, C.c_int32, C.c_uint8, C.c_uint8,
                                     C.c_uint8, C.c_uint16, C.c_int32, C.c_int32, C.c_int32, i32p]
         L.refwrap_bench.restype = C.c_double
+        if hasattr(L, "refwrap_bench_hash"):     # (a prebuilt oracle/_ref of an older round lacks them)
+            L.refwrap_bench_hash.argtypes = L.refwrap_bench.argtypes + [u32p]
+            L.refwrap_bench_hash.restype = C.c_double
+            L.refwrap_bench_db.argtypes = [i8p, i64p, C.c_int32, i8p, i64p, C.c_int32, i8p, C.c_int32, C.c_uint8, C.c_uint8,
+                                           C.c_int32, C.c_int32, i32p]
+            L.refwrap_bench_db.restype = C.c_double
         _ref = L
     return _ref
 
