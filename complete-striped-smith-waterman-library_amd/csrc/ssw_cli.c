@@ -247,13 +247,14 @@ static void usage(void)
 	                "\t-r\tThe best alignment will be picked between the original read alignment and the reverse complement read alignment.\n"
 	                "\t-s\tOutput in SAM format. [default: no header]\n"
 	                "\t-h\tIf -s is used, include header in SAM output.\n"
-	                "\t-b N\tReads per GPU batch. [default: 65536]\n\n");
+	                "\t-b N\tReads per GPU batch. [default: 65536]\n"
+	                "\t-g N\tSpread every batch over N workers (one per device, round-robin over the visible devices). [default: one device]\n\n");
 }
 
 int main(int argc, char* const argv[])
 {
 	int32_t match = 2, mismatch = 2, gap_open = 3, gap_ext = 1, path = 0, reverse = 0, n = 5, sam = 0, protein = 0, header = 0, filter = 0;
-	int32_t batch = 65536;
+	int32_t batch = 65536, gpus = 0;
 	const char* mat_name = 0;
 	const char* files[2]; int nfiles = 0;
 	for (int i = 1; i < argc; ++i) {
@@ -262,11 +263,11 @@ int main(int argc, char* const argv[])
 			const char o = argv[i][j];
 			if (o == 'p') protein = 1; else if (o == 'c') path = 1; else if (o == 'r') reverse = 1;
 			else if (o == 's') sam = 1; else if (o == 'h') header = 1;
-			else if (o == 'm' || o == 'x' || o == 'o' || o == 'e' || o == 'f' || o == 'a' || o == 'b') {
+			else if (o == 'm' || o == 'x' || o == 'o' || o == 'e' || o == 'f' || o == 'a' || o == 'b' || o == 'g') {
 				const char* val = argv[i][j + 1] ? &argv[i][j + 1] : (i + 1 < argc ? argv[++i] : 0);
 				if (!val) { usage(); return 1; }
 				if (o == 'm') match = atoi(val); else if (o == 'x') mismatch = atoi(val); else if (o == 'o') gap_open = atoi(val);
-				else if (o == 'e') gap_ext = atoi(val); else if (o == 'f') filter = atoi(val); else if (o == 'b') batch = atoi(val);
+				else if (o == 'e') gap_ext = atoi(val); else if (o == 'f') filter = atoi(val); else if (o == 'b') batch = atoi(val); else if (o == 'g') gpus = atoi(val);
 				else mat_name = val;
 				break;
 			}
@@ -314,6 +315,17 @@ int main(int argc, char* const argv[])
 	if (!g) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(0)); return EXIT_FAILURE; }
 	ssw_gpu_seqs* T = ssw_gpu_seqs_upload(g, tcodes, toff, nt);
 	if (!T) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
+	/* -g N: the per-GPU work queues of the library (ssw_gpu_pool): the target set is replicated, read blocks are pulled by N workers */
+	ssw_gpu_pool* gp = 0;
+	if (gpus > 0) {
+		const int ndev = ssw_gpu_device_count();
+		int* devs = (int*)xmalloc(sizeof(int) * (size_t)gpus);
+		for (int i = 0; i < gpus; ++i) devs[i] = i % (ndev > 0 ? ndev : 1);
+		gp = ssw_gpu_pool_open(devs, gpus);
+		free(devs);
+		if (!gp) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(0)); return EXIT_FAILURE; }
+		if (ssw_gpu_pool_set_targets(gp, tcodes, toff, nt)) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_pool_last_error(gp)); return EXIT_FAILURE; }
+	}
 
 	reader qr; memset(&qr, 0, sizeof qr);
 	qr.f = gzopen(files[1], "r");
@@ -345,20 +357,27 @@ int main(int argc, char* const argv[])
 		ssw_gpu_result* res = (ssw_gpu_result*)xmalloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1));
 		ssw_gpu_result* res_rc = reverse ? (ssw_gpu_result*)xmalloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1)) : 0;
 		uint32_t *pool = 0, *pool_rc = 0; int64_t words = 0;
-		/* residue translation and (with -r) the reverse complement run on the device; the host copies made
-		   above are only used for printing (SAM needs the codes for mark_mismatch) */
-		char* qtext = (char*)xmalloc((size_t)total + 1);
-		for (int32_t q = 0; q < nr; ++q) memcpy(qtext + qoff[q], reads[q].seq, (size_t)reads[q].len);
-		ssw_gpu_seqs* Qs = ssw_gpu_seqs_upload_ascii(g, qtext, qoff, nr, table);
-		free(qtext);
-		if (!Qs || ssw_gpu_align_batch(g, Qs, T, 0, nt, &p, res, &pool, &words)) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
-		if (reverse) {
-			/* (the device reverse complement works on nucleotide codes; with a matrix file the table is the file's own) */
-			ssw_gpu_seqs* Qr = table == nt_code ? ssw_gpu_seqs_revcomp(g, Qs) : ssw_gpu_seqs_upload(g, rcodes, qoff, nr);
-			if (!Qr || ssw_gpu_align_batch(g, Qr, T, 0, nt, &p, res_rc, &pool_rc, &words)) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
-			ssw_gpu_seqs_free(Qr);
+		if (gp) {   /* reads stay on the host; every worker uploads the blocks it takes */
+			if (ssw_gpu_pool_align(gp, qcodes, qoff, nr, 0, 0, nt, &p, res, &pool, &words) ||
+			    (reverse && ssw_gpu_pool_align(gp, rcodes, qoff, nr, 0, 0, nt, &p, res_rc, &pool_rc, &words))) {
+				fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_pool_last_error(gp)); return EXIT_FAILURE;
+			}
+		} else {
+			/* residue translation and (with -r) the reverse complement run on the device; the host copies made
+			   above are only used for printing (SAM needs the codes for mark_mismatch) */
+			char* qtext = (char*)xmalloc((size_t)total + 1);
+			for (int32_t q = 0; q < nr; ++q) memcpy(qtext + qoff[q], reads[q].seq, (size_t)reads[q].len);
+			ssw_gpu_seqs* Qs = ssw_gpu_seqs_upload_ascii(g, qtext, qoff, nr, table);
+			free(qtext);
+			if (!Qs || ssw_gpu_align_batch(g, Qs, T, 0, nt, &p, res, &pool, &words)) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
+			if (reverse) {
+				/* (the device reverse complement works on nucleotide codes; with a matrix file the table is the file's own) */
+				ssw_gpu_seqs* Qr = table == nt_code ? ssw_gpu_seqs_revcomp(g, Qs) : ssw_gpu_seqs_upload(g, rcodes, qoff, nr);
+				if (!Qr || ssw_gpu_align_batch(g, Qr, T, 0, nt, &p, res_rc, &pool_rc, &words)) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
+				ssw_gpu_seqs_free(Qr);
+			}
+			ssw_gpu_seqs_free(Qs);
 		}
-		ssw_gpu_seqs_free(Qs);
 		for (int32_t q = 0; q < nr; ++q)
 			for (int32_t t = 0; t < nt; ++t) {
 				const ssw_gpu_result* r = &res[(int64_t)q * nt + t];
@@ -389,6 +408,7 @@ int main(int argc, char* const argv[])
 	gzclose(qr.f);
 	free(reads);
 	ssw_gpu_seqs_free(T);
+	ssw_gpu_pool_close(gp);
 	ssw_gpu_close(g);
 	for (int32_t t = 0; t < nt; ++t) free_record(&targets[t]);
 	free(targets); free(toff); free(tcodes); free(mat_file);

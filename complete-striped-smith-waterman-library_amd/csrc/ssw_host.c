@@ -45,6 +45,7 @@ struct ssw_gpu_ctx {
 	void** ev; int nev, capev;          /* event pairs around fill launches */
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
+	int busy;                           /* a batch call is running on this context (one call at a time per context) */
 };
 
 struct ssw_gpu_seqs {
@@ -56,7 +57,7 @@ struct ssw_gpu_seqs {
 	int64_t total;
 };
 
-static char g_open_err[512];
+static __thread char g_open_err[512];   /* error of the last failed ssw_gpu_open of this thread */
 
 static int fail(ssw_gpu_ctx* c, const char* fmt, const char* detail)
 {
@@ -409,10 +410,27 @@ done:
 	return rc;
 }
 
+static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
+                              const ssw_gpu_params* prm, ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words);
+
 int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
                         const ssw_gpu_params* prm, ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words)
 {
 	if (!c) return fail(0, "align_batch: NULL context%s", "");
+	/* the context's streams, events and workspaces serve one call at a time (include/ssw_gpu.h "Threads") */
+	if (__atomic_exchange_n(&c->busy, 1, __ATOMIC_ACQUIRE)) {
+		if (cigar_pool) *cigar_pool = 0;
+		if (cigar_words) *cigar_words = 0;
+		return -2;      /* (the error text of the running call is left alone) another thread is inside this context: open one context per thread */
+	}
+	const int rc = align_batch_locked(c, Q, T, tfirst, tcount, prm, results, cigar_pool, cigar_words);
+	__atomic_store_n(&c->busy, 0, __ATOMIC_RELEASE);
+	return rc;
+}
+
+static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
+                              const ssw_gpu_params* prm, ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words)
+{
 	if (!Q || !T || !prm || !results || !prm->mat) return fail(c, "align_batch: NULL argument%s", "");
 	if (Q->ctx != c || T->ctx != c) return fail(c, "align_batch: sequences belong to another context%s", "");
 	if (tfirst < 0 || tcount < 0 || tfirst + tcount > T->count) return fail(c, "align_batch: target range out of bounds%s", "");
@@ -1025,18 +1043,79 @@ s_align* ssw_gpu_result_to_align(const ssw_gpu_result* r, const uint32_t* cigar_
 }
 
 /* ------------------------------------------------------------------------------------------------
- * ssw.h single-pair ABI on top of the batch path
+ * ssw.h single-pair ABI on top of the batch path.
+ *
+ * The reference is re-entrant: no mutable global state, concurrent ssw_align on one const s_profile* is legal
+ * (src/ssw.c:855-977).  Here every calling thread gets its own implicit context on first use -- devices are handed out
+ * round-robin (SSW_GPU_DEVICE pins all of them to one) -- so calls from different threads never share streams or
+ * workspaces and run concurrently.  Per thread the context keeps pooled device buffers for the query and the target
+ * (no hipMalloc / hipFree per call) and remembers the last target: callers loop "for each read: for each target"
+ * (src/main.c:462-526) and hand in the same reference over and over; it is re-uploaded only when its bytes changed
+ * (compared against a host copy -- the caller may reuse one buffer for different targets, as main.c does).
  * ------------------------------------------------------------------------------------------------ */
-static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
-static ssw_gpu_ctx* g_ctx = 0;
+typedef struct {
+	ssw_gpu_ctx* ctx;
+	ssw_gpu_seqs q, t;              /* one-sequence sets over pooled device buffers */
+	int64_t q_hoff[2], t_hoff[2];
+	size_t qcap, tcap;              /* device code capacity */
+	int8_t* tcopy; size_t tcopy_cap; int t_valid;     /* bytes of the target that is resident in t */
+} implicit_ctx;
 
-static ssw_gpu_ctx* default_ctx(void)
+static pthread_key_t g_ictx_key;
+static pthread_once_t g_ictx_once = PTHREAD_ONCE_INIT;
+static int g_next_device = 0;
+
+static void implicit_destroy(void* p)
 {
-	if (!g_ctx) {
-		const char* e = getenv("SSW_GPU_DEVICE");
-		g_ctx = ssw_gpu_open(e ? atoi(e) : 0);
+	implicit_ctx* ic = (implicit_ctx*)p;
+	if (!ic) return;
+	if (ic->ctx) {
+		ssw_shim_set_device(ic->ctx->device);
+		ssw_shim_stream_sync(ic->ctx->stream);
+		ssw_shim_free(ic->q.d_codes); ssw_shim_free(ic->q.d_off); ssw_shim_free(ic->t.d_codes); ssw_shim_free(ic->t.d_off);
+		ssw_gpu_close(ic->ctx);
 	}
-	return g_ctx;
+	free(ic->tcopy); free(ic);
+}
+static void implicit_key_init(void) { pthread_key_create(&g_ictx_key, implicit_destroy); }
+
+static implicit_ctx* implicit_get(void)
+{
+	pthread_once(&g_ictx_once, implicit_key_init);
+	implicit_ctx* ic = (implicit_ctx*)pthread_getspecific(g_ictx_key);
+	if (ic) return ic;
+	const int ndev = ssw_shim_device_count();
+	const char* e = getenv("SSW_GPU_DEVICE");
+	const int dev = e ? atoi(e) : (ndev > 0 ? __atomic_fetch_add(&g_next_device, 1, __ATOMIC_RELAXED) % ndev : 0);
+	ssw_gpu_ctx* c = ssw_gpu_open(dev);
+	if (!c) return 0;
+	ic = (implicit_ctx*)calloc(1, sizeof *ic);
+	if (!ic) { ssw_gpu_close(c); fail(0, "out of host memory%s", ""); return 0; }
+	ic->ctx = c;
+	ic->q.ctx = c; ic->q.count = 1; ic->q.h_off = ic->q_hoff;
+	ic->t.ctx = c; ic->t.count = 1; ic->t.h_off = ic->t_hoff;
+	ic->q.d_off = (int64_t*)ssw_shim_malloc(2 * sizeof(int64_t));
+	ic->t.d_off = (int64_t*)ssw_shim_malloc(2 * sizeof(int64_t));
+	if (!ic->q.d_off || !ic->t.d_off) { fail(0, "device allocation failed: %s", ssw_shim_last_error()); implicit_destroy(ic); return 0; }
+	pthread_setspecific(g_ictx_key, ic);
+	return ic;
+}
+
+/* (re)fill a pooled one-sequence set; the copies are ordered before the kernels of the batch call on the same stream */
+static int implicit_load(implicit_ctx* ic, ssw_gpu_seqs* s, size_t* cap, const int8_t* codes, int32_t len)
+{
+	ssw_gpu_ctx* c = ic->ctx;
+	if (!s->d_codes || *cap < (size_t)len + 64) {
+		if (s->d_codes) { ssw_shim_stream_sync(c->stream); ssw_shim_free(s->d_codes); s->d_codes = 0; *cap = 0; }
+		const size_t want = (size_t)len + (size_t)len / 4 + 4096;
+		s->d_codes = (int8_t*)ssw_shim_malloc(want);
+		if (!s->d_codes) return fail(c, "device allocation failed: %s", ssw_shim_last_error());
+		*cap = want;
+	}
+	s->h_off[0] = 0; s->h_off[1] = len; s->total = len;
+	if (ssw_shim_h2d(s->d_codes, codes, (size_t)len, c->stream) || ssw_shim_h2d(s->d_off, s->h_off, 2 * sizeof(int64_t), c->stream))
+		return fail(c, "upload failed: %s", ssw_shim_last_error());
+	return 0;
 }
 
 s_profile* ssw_init(const int8_t* read, const int32_t readLen, const int8_t* mat, const int32_t n, const int8_t score_size)
@@ -1068,22 +1147,31 @@ s_align* ssw_align(const s_profile* prof, const int8_t* ref, int32_t refLen, con
 	}
 	if (maskLen < 15)
 		fprintf(stderr, "When maskLen < 15, the function ssw_align doesn't return 2nd best alignment information.\n");
-	pthread_mutex_lock(&g_lock);
-	ssw_gpu_ctx* c = default_ctx();
-	if (!c) {
+	if (refLen < 0 || (refLen > 0 && !ref)) { fprintf(stderr, "ssw_align: invalid reference (refLen %d).\n", (int)refLen); return 0; }
+	implicit_ctx* ic = implicit_get();
+	if (!ic) {
 		fprintf(stderr, "ssw_align: %s\n", ssw_gpu_last_error(0));
-		pthread_mutex_unlock(&g_lock);
 		return 0;
 	}
-	int64_t qo[2] = { 0, prof->readLen }, to[2] = { 0, refLen };
-	ssw_gpu_seqs* Q = ssw_gpu_seqs_upload(c, prof->read, qo, 1);
-	ssw_gpu_seqs* T = Q ? ssw_gpu_seqs_upload(c, ref, to, 1) : 0;
-	if (Q && T) {
+	ssw_gpu_ctx* c = ic->ctx;
+	ssw_shim_set_device(c->device);
+	int ok = implicit_load(ic, &ic->q, &ic->qcap, prof->read, prof->readLen) == 0;
+	if (ok && !(ic->t_valid && ic->t.total == refLen && (refLen == 0 || memcmp(ic->tcopy, ref, (size_t)refLen) == 0))) {
+		ic->t_valid = 0;
+		if (ic->tcopy_cap < (size_t)refLen) {
+			free(ic->tcopy);
+			ic->tcopy = (int8_t*)malloc((size_t)refLen + (size_t)refLen / 4 + 64);
+			ic->tcopy_cap = ic->tcopy ? (size_t)refLen + (size_t)refLen / 4 + 64 : 0;
+		}
+		ok = implicit_load(ic, &ic->t, &ic->tcap, ref, refLen) == 0;
+		if (ok && ic->tcopy) { memcpy(ic->tcopy, ref, (size_t)refLen); ic->t_valid = 1; }   /* no host copy: the target is simply uploaded every time */
+	}
+	if (ok) {
 		ssw_gpu_params prm;
 		prm.mat = prof->mat; prm.n = prof->n; prm.gapO = weight_gapO; prm.gapE = weight_gapE; prm.flag = flag;
 		prm.filters = filters; prm.filterd = filterd; prm.maskLen = maskLen < 0 ? 0 : maskLen; prm.score_size = prof->score_size; prm.mark_mismatch = 0;
 		ssw_gpu_result r; uint32_t* pool = 0; int64_t words = 0;
-		if (ssw_gpu_align_batch(c, Q, T, 0, 1, &prm, &r, &pool, &words) == 0) {
+		if (ssw_gpu_align_batch(c, &ic->q, &ic->t, 0, 1, &prm, &r, &pool, &words) == 0) {
 			if (r.status == 1)
 				fprintf(stderr, "Please set 2 to the score_size parameter of the function ssw_init, otherwise the alignment results will be incorrect.\n");
 			else {
@@ -1091,10 +1179,8 @@ s_align* ssw_align(const s_profile* prof, const int8_t* ref, int32_t refLen, con
 				if (out && out->flag == 2)
 					fprintf(stderr, "Warning: The alignment path of one pair of sequences may miss a small part. [ssw.c ssw_align]\n");
 			}
-		} else fprintf(stderr, "ssw_align: %s\n", ssw_gpu_last_error(c));
+		} else { fprintf(stderr, "ssw_align: %s\n", ssw_gpu_last_error(c)); ic->t_valid = 0; }
 		free(pool);
-	} else fprintf(stderr, "ssw_align: %s\n", ssw_gpu_last_error(c));
-	ssw_gpu_seqs_free(Q); ssw_gpu_seqs_free(T);
-	pthread_mutex_unlock(&g_lock);
+	} else { fprintf(stderr, "ssw_align: %s\n", ssw_gpu_last_error(c)); ic->t_valid = 0; }
 	return out;
 }

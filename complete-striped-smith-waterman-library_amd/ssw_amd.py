@@ -51,6 +51,11 @@ class Timing(C.Structure):
                 ("trace_ms", C.c_double), ("n_word", C.c_int64), ("n_byte", C.c_int64)]
 
 
+class PoolStat(C.Structure):
+    """ssw_gpu_pool_stat (include/ssw_gpu.h)."""
+    _fields_ = [("device", C.c_int32), ("blocks", C.c_int64), ("queries", C.c_int64), ("cells", C.c_int64), ("busy_ms", C.c_double)]
+
+
 RESULT_DTYPE = np.dtype([("score1", "<u2"), ("score2", "<u2"), ("ref_begin1", "<i4"), ("ref_end1", "<i4"),
                          ("read_begin1", "<i4"), ("read_end1", "<i4"), ("ref_end2", "<i4"), ("cigarLen", "<i4"),
                          ("edit_distance", "<i4"), ("cigar_off", "<i8"), ("flag", "<u2"), ("status", "<u2")], align=True)
@@ -104,6 +109,17 @@ def load(path=None):
     L.ssw_gpu_selftest_lanes.restype = C.c_int
     L.ssw_gpu_valu_probe.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.ssw_gpu_valu_probe.restype = C.c_double
+    L.ssw_gpu_pool_open.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.ssw_gpu_pool_open.restype = C.c_void_p
+    L.ssw_gpu_pool_close.argtypes = [C.c_void_p]
+    L.ssw_gpu_pool_close.restype = None
+    L.ssw_gpu_pool_size.argtypes = [C.c_void_p]
+    L.ssw_gpu_pool_last_error.argtypes = [C.c_void_p]
+    L.ssw_gpu_pool_last_error.restype = C.c_char_p
+    L.ssw_gpu_pool_set_targets.argtypes = [C.c_void_p, _i8p, _i64p, C.c_int32]
+    L.ssw_gpu_pool_align.argtypes = [C.c_void_p, _i8p, _i64p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Params),
+                                     C.c_void_p, C.POINTER(_u32p), _i64p]
+    L.ssw_gpu_pool_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(PoolStat)]
     return L
 
 
@@ -215,4 +231,71 @@ class Context(object):
                 self.lib.ssw_gpu_host_free(self.h, p)
             self._pinned = []
             self.lib.ssw_gpu_close(self.h)
+            self.h = None
+
+
+def _pack(seqs):
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    for i, x in enumerate(seqs):
+        off[i + 1] = off[i] + len(x)
+    codes = np.concatenate([np.asarray(x, dtype=np.int8) for x in seqs]) if len(seqs) else np.zeros(0, dtype=np.int8)
+    return np.ascontiguousarray(codes, dtype=np.int8), off
+
+
+class Pool(object):
+    """Several devices, one batch (include/ssw_gpu.h ssw_gpu_pool): per-GPU work queues over host-resident reads."""
+
+    def __init__(self, devices=None, lib=None):
+        self.lib = lib if lib is not None and not isinstance(lib, str) else load(lib)
+        if devices is None:
+            self.h = self.lib.ssw_gpu_pool_open(None, 0)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            self.h = self.lib.ssw_gpu_pool_open(arr, len(devices))
+        if not self.h:
+            raise RuntimeError("ssw_gpu_pool_open: " + self.lib.ssw_gpu_last_error(None).decode())
+        self.ntargets = 0
+
+    def size(self):
+        return int(self.lib.ssw_gpu_pool_size(self.h))
+
+    def error(self):
+        return self.lib.ssw_gpu_pool_last_error(self.h).decode()
+
+    def set_targets(self, seqs):
+        codes, off = _pack(seqs)
+        if self.lib.ssw_gpu_pool_set_targets(self.h, codes.ctypes.data_as(_i8p), off.ctypes.data_as(_i64p), len(seqs)) != 0:
+            raise RuntimeError("ssw_gpu_pool_set_targets: " + self.error())
+        self.ntargets = len(seqs)
+
+    def align(self, reads, mat, n, gapO=3, gapE=1, flag=0, filters=0, filterd=0, maskLen=-1, score_size=2, block=0,
+              want_cigar=True, mark_mismatch=False, packed=None):
+        """reads: list of code arrays, or packed=(codes int8, offsets int64).  -> (records [nq, nt], CIGAR pool)"""
+        codes, off = packed if packed is not None else _pack(reads)
+        nq = len(off) - 1
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        p = Params(mat.ctypes.data_as(_i8p), n, gapO, gapE, flag, filters, filterd, maskLen, score_size, 1 if mark_mismatch else 0)
+        res = np.zeros((nq, self.ntargets), dtype=RESULT_DTYPE)
+        pool = _u32p()
+        words = C.c_int64(0)
+        rc = self.lib.ssw_gpu_pool_align(self.h, codes.ctypes.data_as(_i8p), off.ctypes.data_as(_i64p), nq, block, 0, self.ntargets,
+                                         C.byref(p), res.ctypes.data_as(C.c_void_p), C.byref(pool) if want_cigar else None, C.byref(words))
+        if rc != 0:
+            raise RuntimeError("ssw_gpu_pool_align: " + self.error())
+        cig = np.ctypeslib.as_array(pool, shape=(words.value,)).copy() if want_cigar and words.value > 0 else np.zeros(0, dtype=np.uint32)
+        if want_cigar and pool:
+            C.CDLL(None).free(pool)
+        return res, cig
+
+    def stats(self):
+        out = []
+        for w in range(self.size()):
+            st = PoolStat()
+            self.lib.ssw_gpu_pool_stats(self.h, w, C.byref(st))
+            out.append({k: getattr(st, k) for k, _ in PoolStat._fields_})
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.ssw_gpu_pool_close(self.h)
             self.h = None

@@ -104,6 +104,36 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* queries, const ssw
 
 int ssw_gpu_last_timing(const ssw_gpu_ctx* ctx, ssw_gpu_timing* out);
 
+/*
+ * Threads.  A context owns one stream set and its workspaces: ONE call at a time per context (a second thread entering
+ * ssw_gpu_align_batch on a busy context gets an error, not a race).  Different contexts -- on the same or on different
+ * devices -- are independent and may be driven from different threads concurrently.  The single-pair functions of ssw.h
+ * use an implicit context per calling thread (devices assigned round-robin, or SSW_GPU_DEVICE), so concurrent ssw_align
+ * calls on one const s_profile* are legal, as with the reference (src/ssw.c has no mutable global state).
+ */
+
+/*
+ * Several devices, one batch: per-GPU work queues (the loop of reference src/main.c:462-526 spread over a node).
+ * A pool holds one worker (context + host thread) per entry of `devices`; the target set is replicated on every worker's
+ * device, the queries stay on the host and are pulled in blocks of `block` reads from a shared queue, each block is
+ * uploaded and aligned by whichever worker is free, and every record lands in its own slot results[q * target_count + t]
+ * -- output order does not depend on which device did what.  No inter-device traffic at all.
+ */
+typedef struct ssw_gpu_pool ssw_gpu_pool;
+/* devices == NULL: one worker per visible device (n ignored); else n entries, an index may repeat (several workers on one
+   device share it through separate streams). */
+ssw_gpu_pool* ssw_gpu_pool_open(const int* devices, int n);      /* NULL on failure: ssw_gpu_last_error(NULL) */
+void ssw_gpu_pool_close(ssw_gpu_pool* pool);
+int ssw_gpu_pool_size(const ssw_gpu_pool* pool);
+const char* ssw_gpu_pool_last_error(const ssw_gpu_pool* pool);
+int ssw_gpu_pool_set_targets(ssw_gpu_pool* pool, const int8_t* codes, const int64_t* offsets, int32_t count);
+int ssw_gpu_pool_align(ssw_gpu_pool* pool, const int8_t* qcodes, const int64_t* qoffsets, int32_t nq, int32_t block,
+                       int32_t target_first, int32_t target_count, const ssw_gpu_params* params,
+                       ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words);
+/* per worker, accumulated over the last ssw_gpu_pool_align: blocks taken, DP cells (readLen x refLen), device milliseconds */
+typedef struct { int32_t device; int64_t blocks; int64_t queries; int64_t cells; double busy_ms; } ssw_gpu_pool_stat;
+int ssw_gpu_pool_stats(const ssw_gpu_pool* pool, int worker, ssw_gpu_pool_stat* out);
+
 /* Page-locked host memory for result arrays (optional): a database search returns nq x nt records, and their download
    runs at PCIe rate only into pinned pages.  Any host pointer is accepted by ssw_gpu_align_batch; this one is faster. */
 void* ssw_gpu_host_alloc(ssw_gpu_ctx* ctx, size_t bytes);

@@ -11,7 +11,8 @@
 #include "ssw_dev.h"
 
 extern "C" {
-int ssw_shim_device_count(void) { return 1; }
+/* SSW_EMU_DEVICES=<n>: pretend to have n devices (round-robin / pool tests); they all are this process's memory */
+int ssw_shim_device_count(void) { const char* e = getenv("SSW_EMU_DEVICES"); const int n = e ? atoi(e) : 1; return n >= 1 && n <= 64 ? n : 1; }
 int ssw_shim_set_device(int) { return 0; }
 const char* ssw_shim_last_error(void) { return "emulator"; }
 void* ssw_shim_stream_create(void) { return (void*)1; }

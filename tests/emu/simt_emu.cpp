@@ -7,14 +7,16 @@
 
 namespace emu {
 
-Fiber* cur = 0;
-Block blk;
-dim3_t block_idx, block_dim, grid_dim;
+/* all scheduler state is per host thread: every thread that launches a kernel runs its own fibres (the library's
+   per-thread implicit contexts and the pool's workers launch concurrently) */
+thread_local Fiber* cur = 0;
+thread_local Block blk;
+thread_local dim3_t block_idx, block_dim, grid_dim;
 
-static void* sched_sp = 0;
-static unsigned long progress = 0;
-static kernel_thunk g_fn = 0;
-static void* g_args = 0;
+static thread_local void* sched_sp = 0;
+static thread_local unsigned long progress = 0;
+static thread_local kernel_thunk g_fn = 0;
+static thread_local void* g_args = 0;
 
 extern "C" void emu_ctx_switch(void** save_sp, void* load_sp);
 asm(

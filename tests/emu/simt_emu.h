@@ -55,9 +55,9 @@ struct Fiber {
 	Wave* wave;
 };
 
-extern Fiber* cur;
-extern Block blk;
-extern dim3_t block_idx, block_dim, grid_dim;
+extern thread_local Fiber* cur;
+extern thread_local Block blk;
+extern thread_local dim3_t block_idx, block_dim, grid_dim;
 
 void yield();
 void wave_sync();

@@ -13,8 +13,12 @@ CLI_DIR = os.path.join(HERE, "golden", "cli")
 CASES = sorted(os.path.basename(p)[:-len(".args")] for p in glob.glob(os.path.join(CLI_DIR, "*.args")))
 
 
-def _check(exe, name):
-    args = open(os.path.join(CLI_DIR, name + ".args")).read().split()
+# -g N (per-GPU work queues, csrc/ssw_pool.c) must not change a byte of the output: N workers share the visible devices
+POOLED = [("config1_cr", "2"), ("r1_csr", "3"), ("empty_read_cs", "2"), ("protein_pc", "2")]
+
+
+def _check(exe, name, extra=()):
+    args = list(extra) + open(os.path.join(CLI_DIR, name + ".args")).read().split()
     r = subprocess.run([exe] + args, cwd=CLI_DIR, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout == open(os.path.join(CLI_DIR, name + ".stdout")).read(), name
@@ -24,6 +28,19 @@ def _check(exe, name):
 def test_cli_stdout_matches_reference_on_emulator(emu_lib_path, name):
     subprocess.run(["make", "-C", os.path.join(HERE, "emu"), "-s", "ssw_test_emu"], check=True)
     _check(os.path.join(HERE, "emu", "ssw_test_emu"), name)
+
+
+@pytest.mark.parametrize("name,workers", POOLED)
+def test_cli_pooled_stdout_on_emulator(emu_lib_path, name, workers, monkeypatch):
+    monkeypatch.setenv("SSW_EMU_DEVICES", "2")
+    subprocess.run(["make", "-C", os.path.join(HERE, "emu"), "-s", "ssw_test_emu"], check=True)
+    _check(os.path.join(HERE, "emu", "ssw_test_emu"), name, ("-g", workers))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,workers", POOLED)
+def test_cli_pooled_stdout_on_gpu(product_lib_path, name, workers):
+    _check(os.path.join(os.path.dirname(product_lib_path), "ssw_test_gpu"), name, ("-g", workers))
 
 
 @pytest.mark.gpu
