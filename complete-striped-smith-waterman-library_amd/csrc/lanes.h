@@ -67,6 +67,15 @@ SSW_DEV void lds_st8(unsigned char* lds, u32 off, u32 v) { *(lds + off) = (unsig
 SSW_DEV void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 SSW_DEV void dev_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent"); }
 SSW_DEV void lds_st16(unsigned char* lds, u32 off, u32 v) { *(uint16_t*)(lds + off) = (uint16_t)v; }
+/* work queue of a persistent launch: one lane draws the next ticket for its wavefront; completion flags in HBM order the
+   items of one job (agent scope: the eight XCDs have their own L2s).  dev_flag_set comes after an agent-scope fence that
+   every lane executed (its own stores are then visible); dev_flag_wait is followed by one. */
+SSW_DEV int dev_ticket(int* counter) { return atomicAdd(counter, 1); }
+SSW_DEV void dev_flag_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+SSW_DEV void dev_flag_wait(int* flag)
+{
+	while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
+}
 #endif
 
 /* hand-off to the next lane of a chain of GL lanes (16: one DPP row, 64: the whole wavefront) */

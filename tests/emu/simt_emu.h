@@ -170,5 +170,10 @@ SSW_DEV void wg_fence() { emu::wave_sync(); }
 SSW_DEV void lds_st16(unsigned char* lds, u32 off, u32 v) { emu_lds_check(off, 2, 2, "st16"); uint16_t h = (uint16_t)v; memcpy(lds + off, &h, 2); }
 
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+/* work-queue primitives (csrc/lanes.h): blocks run one after the other here, so a workgroup drains the queue in ticket order
+   and every item's predecessor is complete when it is drawn */
+SSW_DEV int dev_ticket(int* counter) { return atomicAdd(counter, 1); }
+SSW_DEV void dev_flag_set(int* flag) { *flag = 1; }
+SSW_DEV void dev_flag_wait(int* flag) { if (*flag == 0) emu::fail("work queue: predecessor of a drawn item is not complete"); }
 
 #endif /* SIMT_EMU_H */

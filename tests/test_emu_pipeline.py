@@ -310,3 +310,23 @@ def test_device_mark_mismatch(ectx):
         assert int(b["edit_distance"]) == nm and list(got) == list(out[:olen.value])
         checked += 1
     assert checked >= 6
+
+
+def wide_alphabet_case(n, seed=9, nreads=6, reflen=900):
+    rng = np.random.default_rng(seed)
+    mat = rng.integers(-6, 3, size=(n, n)).astype(np.int8); mat = np.minimum(mat, mat.T)
+    np.fill_diagonal(mat, rng.integers(4, 9, size=n))
+    ref = rng.integers(0, n, size=reflen, dtype=np.int8)
+    lens = [384, 300, 273, 370, 200, 100] + list(rng.integers(257, 385, size=max(0, nreads - 6)))
+    reads = make_reads(rng, ref, nreads, lens[:nreads], n, sub=0.1)
+    return reads, ref, mat.reshape(-1).copy()
+
+
+@pytest.mark.parametrize("n", [25, 26, 32])
+def test_wide_alphabets_route_window_passes_by_lds_need(ectx, n):
+    """four per-chain profiles of k_capture<R> fit 160 KiB of LDS up to n = 25 at R = 24; beyond that the locate / reverse
+    passes of the bucket go through the strip kernel (one profile per wavefront, rows per lane bounded by the 16-bit
+    profile offsets of the target ring)"""
+    reads, ref, mat = wide_alphabet_case(n)
+    for flag in (0, 2):
+        _run(ectx, reads, [ref], mat, n, 9, 2, flag=flag)

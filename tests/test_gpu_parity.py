@@ -357,3 +357,13 @@ def test_traceback_kernels_and_band_growth(gpu_ctx, wave, monkeypatch):
     reads += make_reads(rng, ref, 40, rng.integers(30, 1200, size=40), 4, sub=0.04, ins=0.02, dele=0.02)
     _run(gpu_ctx, [np.ascontiguousarray(r, dtype=np.int8) for r in reads], [ref], dna_matrix(2, 2), 5, flag=2)
     _run(gpu_ctx, [np.ascontiguousarray(r, dtype=np.int8) for r in reads[:20]], [ref], dna_matrix(1, 3), 5, 2, 2, flag=1)
+
+
+@pytest.mark.parametrize("n", [25, 26, 32])
+def test_wide_alphabets_route_window_passes_by_lds_need(gpu_ctx, n):
+    """alphabets whose four per-chain profiles exceed the LDS of a k_capture workgroup (n >= 26 at 24 rows per lane) take the
+    strip kernel's window mode; the launch must neither fail nor differ from the reference"""
+    from test_emu_pipeline import wide_alphabet_case
+    reads, ref, mat = wide_alphabet_case(n, seed=10, nreads=60, reflen=5000)
+    for flag in (0, 2):
+        _run(gpu_ctx, reads, [ref], mat, n, 9, 2, flag=flag)
