@@ -72,9 +72,19 @@ SSW_DEV void lds_st16(unsigned char* lds, u32 off, u32 v) { *(uint16_t*)(lds + o
    every lane executed (its own stores are then visible); dev_flag_wait is followed by one. */
 SSW_DEV int dev_ticket(int* counter) { return atomicAdd(counter, 1); }
 SSW_DEV void dev_flag_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-SSW_DEV void dev_flag_wait(int* flag)
+/* The poll is a RELAXED agent-scope load: an acquire load puts a cache invalidate (buffer_inv sc1) into every iteration, and a
+   dozen wavefronts polling that way keep the L2 of their XCD busy invalidating -- the wavefront they are waiting for then
+   crawls (seen on MI355X: a test batch with more strips than jobs went from milliseconds to minutes).  One acquire fence after
+   the flag has been seen (the caller's dev_fence) is all that is needed.  Bounded: a flag that does not come within seconds
+   means a broken queue -- the caller raises the launch's error word and goes on, so that the host fails the call instead
+   of the device hanging. */
+SSW_DEV bool dev_flag_wait(int* flag)
 {
-	while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
+	for (int spin = 0; spin < (1 << 20); ++spin) {
+		if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+		__builtin_amdgcn_s_sleep(64);
+	}
+	return false;
 }
 #endif
 
@@ -228,7 +238,14 @@ SSW_DEV u32 pk_max3_nonneg(u32 a, u32 b, u32 c)
 	return ((c & 0xffffu) > lo ? (c & 0xffffu) : lo) | (((c >> 16) > hi ? (c >> 16) : hi) << 16);
 }
 #else
-SSW_DEV u32 pk_max3_nonneg(u32 a, u32 b, u32 c) { u32 r; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+/* written with the builtin (nested llvm.maximum.v2f16 folds into ONE v_pk_maximum3_f16 on gfx950) rather than inline asm: the
+   compiler then knows what the instruction is and schedules around it instead of padding every use with s_nop */
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+SSW_DEV u32 pk_max3_nonneg(u32 a, u32 b, u32 c)
+{
+	return __builtin_bit_cast(u32, __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
+	                                                             __builtin_bit_cast(f16x2, c)));
+}
 #endif
 SSW_DEV u32 pk_dup(int v) { return ((u32)v & 0xffffu) * 0x10001u; }
 SSW_DEV u32 pk_make(int lo, int hi) { return ((u32)lo & 0xffffu) | ((u32)hi << 16); }

@@ -57,6 +57,9 @@ typedef struct {
 	uint32_t* cm16;          /* [npairs][cm_stride]: column max over all 16R rows   (8-bit rules) */
 	uint32_t* cm8;           /* [npairs][cm_stride]: column max over the first 16R-8 rows (16-bit rules, padded queries) */
 	int64_t cm_stride;
+	uint32_t* sg16;          /* optional: [npairs][seg_stride] maxima of every aligned group of 16 columns of cm16 ... */
+	uint32_t* sg8;           /* ... and of cm8 (k_reduce_seg scans these instead of the columns) */
+	int64_t seg_stride;
 	int32_t f16;             /* form of the recurrence: 1: no score can reach 2048 -> f16 (scores / 2048, exact), 7.5 instructions per row;
 	                            2: no score can reach 31744 -> int16 with a two-row column maximum, 8.5; 0: plain int16, 9 */
 } ssw_fill_args;
@@ -67,6 +70,12 @@ struct ssw_out_rec {
 	int32_t ref_begin1, ref_end1, read_begin1, read_end1, ref_end2, cigarLen, edit_distance;
 	int64_t cigar_off;
 	uint16_t flag, status;
+};
+
+/* byte-for-byte the layout of ssw_gpu_hit (include/ssw_gpu.h) */
+struct ssw_hit_rec {
+	uint16_t score1, score2;
+	int32_t ref_end1, read_end1, ref_end2;
 };
 
 /*
@@ -93,6 +102,7 @@ typedef struct {
 	int32_t maskLen, bias, score_size;
 	ssw_dres* res;           /* [query][res_nt] (NULL when `out` is used) */
 	struct ssw_out_rec* out; /* optional: final ssw_gpu_result-layout records [query][res_nt], downloaded as they are */
+	struct ssw_hit_rec* hits;/* optional (takes precedence): compact 16-byte records [query][res_nt] of the streaming search */
 	int32_t* counters;       /* optional: [0] alignments decided under 16-bit rules, [1] under 8-bit rules */
 } ssw_filldb_args;
 
@@ -112,6 +122,9 @@ typedef struct {
 	ssw_dres* res;           /* indexed by query */
 	const int32_t* cand;     /* optional: best cell tracked by the fill, [pair * ntiles + tile][half][4] = value, column, row, - */
 	int32_t tile, ntiles;
+	const uint32_t* sg16;    /* optional: group-of-16-columns maxima written by k_fill -> k_reduce_seg */
+	const uint32_t* sg8;
+	int64_t seg_stride;
 } ssw_reduce_args;
 
 /* locate (read_end1) and reverse (begin position) passes: one 16-lane chain per alignment */
@@ -167,6 +180,13 @@ typedef struct {
 	uint32_t* bnd;
 	int64_t bnd_stride;
 	int32_t* cand;           /* fill mode, optional: best cell of every job, [job][half][4] = value, column, row, - */
+	/* work-queue form (k_chainq): njobs x strips items drawn from a ticket counter */
+	int32_t strips;          /* strips per job of this launch (jobs with fewer strips leave the rest of their items empty) */
+	int32_t* queue;          /* [0] ticket counter, [1 + job * strips + strip] completion flags, [1 + items] error word (a wait
+	                            that timed out); zeroed before the launch */
+	int32_t* cand_strip;     /* [job * strips + strip][half][4]: best cell of the job up to and including that strip */
+	int32_t form;            /* fill mode: 2 = no score of the bucket reaches 31744 (two-row column maximum), 0 = plain */
+	int32_t whole_jobs;      /* 1: a ticket is a whole job (its strips in sequence on one wavefront); 0: a ticket is one strip */
 } ssw_chainx_args;
 
 /*
@@ -276,6 +296,7 @@ size_t ssw_shim_mem_free_bytes(void);
 void* ssw_shim_event_create(void);
 void  ssw_shim_event_destroy(void* ev);
 int   ssw_shim_event_record(void* ev, void* stream);
+int   ssw_shim_event_sync(void* ev);                         /* host waits for the event */
 int   ssw_shim_stream_wait_event(void* stream, void* ev);   /* later work on `stream` waits for `ev` */
 float ssw_shim_event_elapsed_ms(void* start, void* stop);   /* both must have completed */
 
@@ -286,6 +307,8 @@ int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream);
 int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* stream);
 int64_t ssw_shim_capture_lds_need(int R, int n);   /* dynamic LDS of one k_capture<R> workgroup */
 int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args* a, void* stream);
+int ssw_shim_launch_chainq(int R, int capture, const ssw_chainx_args* a, int max_workgroups, void* stream);   /* 64-lane chains behind a work queue */
+int ssw_shim_chainq_resident(int R, int capture, int n);   /* wavefronts of k_chainq<R> the device holds at once (0: unknown) */
 int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream);
 int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);
 int ssw_shim_launch_trace_wave(const ssw_trace_args* a, void* stream);

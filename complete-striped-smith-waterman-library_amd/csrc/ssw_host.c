@@ -41,11 +41,12 @@ struct ssw_gpu_ctx {
 	void *ev_fill[2], *ev_red[2];
 	char err[512];
 	ssw_gpu_timing tm;
-	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, cigar2, need, goff, gpool, bnd, tlist, cand, tresume;
+	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, cigar2, need, goff, gpool, bnd, tlist, cand, tresume, queue, cands, sg16, sg8;
 	void** ev; int nev, capev;          /* event pairs around fill launches */
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
 	int busy;                           /* a batch call is running on this context (one call at a time per context) */
+	const int32_t* queue_err;           /* device error word of the last work-queue launch, not yet checked */
 };
 
 struct ssw_gpu_seqs {
@@ -116,7 +117,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_set_device(c->device);
 	if (c->stream) ssw_shim_stream_sync(c->stream);
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
-	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->cigar2); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand); dbuf_free(&c->tresume);
+	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->cigar2); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand); dbuf_free(&c->tresume); dbuf_free(&c->queue); dbuf_free(&c->cands); dbuf_free(&c->sg16); dbuf_free(&c->sg8);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
 	free(c->ev);
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
@@ -255,6 +256,71 @@ static int keyed_cmp(const void* a, const void* b)
 	return x->q < y->q ? -1 : (x->q > y->q);
 }
 
+/* remembers which fill kernel evaluated most cells of the call (ssw_gpu_timing.fill_kernel) */
+static void note_fill_kernel(ssw_gpu_ctx* c, int64_t cells, int64_t* best_cells, const char* name, double ops, int32_t R, int32_t strips)
+{
+	if (cells <= *best_cells) return;
+	*best_cells = cells;
+	snprintf(c->tm.fill_kernel, sizeof c->tm.fill_kernel, "%s", name);
+	c->tm.fill_ops_per_row = ops; c->tm.fill_rows_per_lane = R; c->tm.fill_strips = strips;
+}
+
+/* the last queue launch's error word: a strip that waited for the one above it for seconds gave up (never seen; it would
+   mean a broken queue) -- checked before the queue is reused and before results are handed out */
+static int chainq_check(ssw_gpu_ctx* c)
+{
+	if (!c->queue_err) return 0;
+	int32_t e = 0;
+	const int32_t* p = c->queue_err;
+	c->queue_err = 0;
+	if (ssw_shim_d2h(&e, p, sizeof e, c->stream) || ssw_shim_stream_sync(c->stream)) return fail(c, "download failed: %s", ssw_shim_last_error());
+	return e ? fail(c, "internal error: a strip of the work queue timed out waiting for the strip above it%s", "") : 0;
+}
+
+/* work-queue launches of the 64-lane strip kernel (k_chainq): zeroed ticket counter + completion flags, one best-cell
+   record per (job, strip) item */
+static int chainq_prepare(ssw_gpu_ctx* c, ssw_chainx_args* xa, int32_t strips, int64_t jobs, int64_t slots_hint)
+{
+	const int64_t items = jobs * strips;
+	if (chainq_check(c)) return -1;        /* error word of the previous queue launch (the buffer is about to be reused) */
+	int32_t* q = (int32_t*)ensure(c, &c->queue, sizeof(int32_t) * (size_t)(items + 2));
+	int32_t* cs = (int32_t*)ensure(c, &c->cands, sizeof(int32_t) * 8 * (size_t)(items > 0 ? items : 1));
+	if (!q || !cs) return -1;
+	if (ssw_shim_memset(q, 0, sizeof(int32_t) * (size_t)(items + 2), c->stream)) return fail(c, "memset failed: %s", ssw_shim_last_error());
+	xa->strips = strips; xa->queue = q; xa->cand_strip = cs;
+	c->queue_err = q + 1 + items;
+	/* strip-level tickets pay off when there are more jobs than wavefront slots (the last round of whole jobs would leave slots
+	   idle); with fewer jobs every wavefront keeps its job: SSW_GPU_QUEUE=strips / jobs forces one or the other */
+	{
+		const char* e = getenv("SSW_GPU_QUEUE");
+		const int64_t slots = slots_hint > 0 ? slots_hint : 2048;
+		xa->whole_jobs = e && e[0] == 'j' ? 1 : e && e[0] == 's' ? 0 : jobs <= slots;
+	}
+	return 0;
+}
+
+/* wavefronts of the persistent launch: what the device holds at once (a wavefront that finds the queue empty just ends) */
+static int chainq_grid(int R, int capture, int n)
+{
+	const char* e = getenv("SSW_GPU_QUEUE_WAVES");
+	if (e && atoi(e) > 0) return atoi(e);
+	const int res = ssw_shim_chainq_resident(R, capture, n);
+	if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] k_chainq<%d,%s>: %d wavefronts resident on the device\n", R, capture ? "window" : "fill", res);
+	return res > 0 ? res : 4096;
+}
+
+static int launch_window_pass(ssw_gpu_ctx* c, int32_t R, int32_t lanes, int32_t strips, ssw_chainx_args* xa, int32_t n)
+{
+	if (lanes != 64) return ssw_shim_launch_chainx(R, 1, xa, c->stream);
+	const int qgrid = chainq_grid(R, 1, n);
+	if (chainq_prepare(c, xa, strips, ((int64_t)xa->njobs + 1) / 2, qgrid)) return -1;
+	if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] chainq window pass (reverse %d): R %d, %d queries x %d strips, %d wavefronts, %s tickets\n",
+	                                     xa->reverse, R, xa->njobs, strips, qgrid, xa->whole_jobs ? "job" : "strip");
+	const int rc = ssw_shim_launch_chainq(R, 1, xa, qgrid, c->stream);
+	if (getenv("SSW_GPU_DEBUG")) { const int src = ssw_shim_stream_sync(c->stream); fprintf(stderr, "[ssw_gpu] chainq window pass done (sync rc %d: %s)\n", src, src ? ssw_shim_last_error() : "ok"); }
+	return rc;
+}
+
 /*
  * Database-search path: many short targets, flag == 0.  One fused launch (k_filldb) per (bucket, target chunk) instead
  * of three launches per target; targets are sorted by length so that the 16 chains of a workgroup finish together.
@@ -267,18 +333,29 @@ static int tkey_cmp(const void* a, const void* b)
 	return x->t < y->t ? -1 : (x->t > y->t);
 }
 
+/* streamed database search (ssw_gpu_search_db): compact records of one target chunk go to one of two device buffers, are
+   downloaded on the second stream into one of two page-locked host buffers while the next chunk is computed, and are handed
+   to the caller's function */
+typedef struct {
+	int32_t chunk;                      /* targets per chunk */
+	ssw_gpu_hits_fn fn; void* user;
+	struct ssw_hit_rec* d_hits[2];
+	ssw_gpu_hit* h_hits[2];
+	int fn_rc;                          /* non-zero: the caller's function asked to stop */
+} db_stream;
+
 static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
                     const ssw_gpu_params* prm, ssw_gpu_result* results, const bucket* bk, int nb, const ssw_pair* d_pairs,
-                    const int8_t* d_mat, int32_t bias, int32_t maxtlen, const uint8_t* qdone)
+                    const int8_t* d_mat, int32_t bias, int32_t maxtlen, const uint8_t* qdone, db_stream* ds)
 {
 	const int32_t nq = Q->count, n = prm->n;
 	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
 	const int64_t stride = ((int64_t)maxtlen + 15) / 16 * 16 + 16;
 	int rc = -1;
 	tkey* tk = (tkey*)malloc(sizeof(tkey) * (size_t)tcount);
-	int32_t* tl = (int32_t*)malloc(sizeof(int32_t) * (size_t)tcount);
+	int32_t* tl_all = (int32_t*)malloc(sizeof(int32_t) * (size_t)tcount);
 	ssw_dres* hres = 0;
-	if (!tk || !tl) { free(tk); free(tl); return fail(c, "out of host memory%s", ""); }
+	if (!tk || !tl_all) { free(tk); free(tl_all); return fail(c, "out of host memory%s", ""); }
 	/* queries of 385..640 residues: size classes R' in {28, 32, 36, 40} (k_filldb<R', masked>), paired by length */
 	bucket mid[4]; int nmid = 0;
 	ssw_pair* midpairs = 0; const ssw_pair* d_midpairs = 0;
@@ -288,7 +365,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		if (nm > 0) {
 			keyed* mk = (keyed*)malloc(sizeof(keyed) * (size_t)nm);
 			midpairs = (ssw_pair*)malloc(sizeof(ssw_pair) * (size_t)nm);
-			if (!mk || !midpairs) { free(mk); free(midpairs); free(tk); free(tl); return fail(c, "out of host memory%s", ""); }
+			if (!mk || !midpairs) { free(mk); free(midpairs); free(tk); free(tl_all); return fail(c, "out of host memory%s", ""); }
 			int32_t k = 0, np = 0;
 			for (int32_t q = 0; q < nq; ++q) { const int64_t L = Q->h_off[q + 1] - Q->h_off[q]; if (L > 16 * SSW_RMAX && L <= 640) { mk[k].key = (int32_t)L; mk[k].q = q; ++k; } }
 			qsort(mk, (size_t)nm, sizeof(keyed), keyed_cmp);
@@ -309,25 +386,37 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 			}
 			free(mk);
 			ssw_pair* dmp = (ssw_pair*)ensure(c, &c->pairs2, sizeof(ssw_pair) * (size_t)np);
-			if (!dmp || ssw_shim_h2d(dmp, midpairs, sizeof(ssw_pair) * (size_t)np, c->stream)) { free(midpairs); free(tk); free(tl); return fail(c, "upload failed: %s", ssw_shim_last_error()); }
+			if (!dmp || ssw_shim_h2d(dmp, midpairs, sizeof(ssw_pair) * (size_t)np, c->stream)) { free(midpairs); free(tk); free(tl_all); return fail(c, "upload failed: %s", ssw_shim_last_error()); }
 			d_midpairs = dmp;
 		}
 	}
 	/* result records of a sub-batch of targets stay in HBM until the sub-batch is done */
 	int64_t tsub = (int64_t)(c->cm_budget / 2) / ((int64_t)nq * (int64_t)sizeof(ssw_dres));
 	if (tsub < 16) tsub = 16;
+	if (ds) tsub = ds->chunk;
 	if (tsub > tcount) tsub = tcount;
-	for (int32_t t0 = 0; t0 < tcount; t0 += (int32_t)tsub) {
+	int32_t* d_tl_all = (int32_t*)ensure(c, &c->tlist, sizeof(int32_t) * (size_t)tcount);     /* every sub-batch has its own slice (uploads stay in flight) */
+	int32_t* d_cnt_s = ds ? (int32_t*)ensure(c, &c->need, 2 * sizeof(int32_t)) : 0;
+	if (!d_tl_all || (ds && (!d_cnt_s || ssw_shim_memset(d_cnt_s, 0, 2 * sizeof(int32_t), c->stream)))) { fail(c, "device allocation failed: %s", ssw_shim_last_error()); goto done; }
+	int32_t prev_t0 = -1, prev_nt = 0, chunk_i = 0;
+	int64_t db_cells[64]; memset(db_cells, 0, sizeof db_cells);      /* per bucket (nb <= 24 short buckets + 4 size classes) */
+	for (int32_t t0 = 0; t0 < tcount; t0 += (int32_t)tsub, ++chunk_i) {
 		const int32_t nt = tcount - t0 < tsub ? tcount - t0 : (int32_t)tsub;
+		int32_t* const tl = tl_all + t0;
 		for (int32_t k = 0; k < nt; ++k) { tk[k].t = tfirst + t0 + k; tk[k].len = (int32_t)(T->h_off[tfirst + t0 + k + 1] - T->h_off[tfirst + t0 + k]); }
 		qsort(tk, (size_t)nt, sizeof(tkey), tkey_cmp);
 		int32_t nz = 0;
 		for (int32_t k = 0; k < nt; ++k) if (tk[k].len > 0) tl[nz++] = tk[k].t;      /* empty targets keep their zeroed records */
 		/* one sub-batch covering every target and every query handled here: the kernel writes final-layout records that are
 		   downloaded straight into the caller's array (no host-side conversion pass over nq x nt records) */
-		int direct = nt == tcount;
+		int direct = nt == tcount && !ds;
 		for (int32_t q = 0; q < nq && direct; ++q) if (!qdone[q]) direct = 0;
-		ssw_dres* d_res = 0; struct ssw_out_rec* d_out = 0; int32_t* d_cnt = 0;
+		ssw_dres* d_res = 0; struct ssw_out_rec* d_out = 0; int32_t* d_cnt = 0; struct ssw_hit_rec* d_hits = 0;
+		const int buf = chunk_i & 1;
+		if (ds) {      /* all-zero bytes ARE the empty compact record (score 0, ends 0): empty queries / targets need no patching */
+			d_hits = ds->d_hits[buf]; d_cnt = d_cnt_s;
+			if (ssw_shim_memset(d_hits, 0, sizeof(struct ssw_hit_rec) * (size_t)nq * (size_t)nt, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
+		} else
 		if (direct) {
 			d_out = (struct ssw_out_rec*)ensure(c, &c->res, sizeof(struct ssw_out_rec) * (size_t)nq * (size_t)nt);
 			d_cnt = (int32_t*)ensure(c, &c->need, 2 * sizeof(int32_t));
@@ -339,8 +428,8 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 			d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq * (size_t)nt);
 			if (!d_res || ssw_shim_memset(d_res, 0, sizeof(ssw_dres) * (size_t)nq * (size_t)nt, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
 		}
-		int32_t* d_tl = (int32_t*)ensure(c, &c->tlist, sizeof(int32_t) * (size_t)(nz > 0 ? nz : 1));
-		if (!d_tl || ssw_shim_h2d(d_tl, tl, sizeof(int32_t) * (size_t)nz, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
+		int32_t* d_tl = d_tl_all + t0;
+		if (ssw_shim_h2d(d_tl, tl, sizeof(int32_t) * (size_t)nz, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
 		for (int b = 0; b < nb + nmid && nz > 0; ++b) {
 			bucket midb;
 			const bucket* B = b < nb ? &bk[b] : &midb;
@@ -359,14 +448,30 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 				fa.tfirst = tfirst + t0; fa.res_nt = nt; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off; fa.pairs = bpairs + B->first_pair;
 				fa.npairs = B->npairs; fa.mat = d_mat; fa.n = n; fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.cm16 = d_cm16; fa.cm8 = d_cm8;
 				fa.cm_stride = stride; fa.maskLen = prm->maskLen; fa.bias = bias; fa.score_size = prm->score_size; fa.res = d_res; fa.out = d_out; fa.counters = d_cnt;
+				fa.hits = d_hits;
 				void* e0 = next_event(c); void* e1 = next_event(c);
 				ssw_shim_event_record(e0, c->stream);
 				if (ssw_shim_launch_filldb(B->R, &fa, c->stream)) { fail(c, "filldb launch failed: %s", ssw_shim_last_error()); goto done; }
 				ssw_shim_event_record(e1, c->stream);
 				c->tm.fill_launches++;
+				int64_t lc = 0;
 				for (int32_t k = 0; k < fa.ntl; ++k)
-					c->tm.fill_cells += (T->h_off[tl[k0 + k] + 1] - T->h_off[tl[k0 + k]]) * (int64_t)B->P16 * 2 * B->npairs;
+					lc += (T->h_off[tl[k0 + k] + 1] - T->h_off[tl[k0 + k]]) * (int64_t)B->P16 * 2 * B->npairs;
+				c->tm.fill_cells += lc;
+				db_cells[b] += lc;
 			}
+		}
+		if (ds) {   /* download of this chunk on the second stream; meanwhile hand the previous chunk to the caller */
+			if (ssw_shim_event_record(c->ev_fill[buf], c->stream) || ssw_shim_stream_wait_event(c->stream2, c->ev_fill[buf]) ||
+			    ssw_shim_d2h(ds->h_hits[buf], d_hits, sizeof(struct ssw_hit_rec) * (size_t)nq * (size_t)nt, c->stream2) ||
+			    ssw_shim_event_record(c->ev_red[buf], c->stream2)) { fail(c, "result download failed: %s", ssw_shim_last_error()); goto done; }
+			if (prev_t0 >= 0) {
+				if (ssw_shim_event_sync(c->ev_red[buf ^ 1])) { fail(c, "result download failed: %s", ssw_shim_last_error()); goto done; }
+				ds->fn_rc = ds->fn(ds->user, tfirst + prev_t0, prev_nt, ds->h_hits[buf ^ 1]);
+				if (ds->fn_rc) { ssw_shim_stream_sync(c->stream); ssw_shim_stream_sync(c->stream2); rc = 0; goto done; }
+			}
+			prev_t0 = t0; prev_nt = nt;
+			continue;
 		}
 		if (direct) {
 			int32_t cnt[2] = { 0, 0 };
@@ -404,14 +509,33 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 				c->tm.cells += (Q->h_off[q + 1] - Q->h_off[q]) * (T->h_off[tfirst + t0 + k + 1] - T->h_off[tfirst + t0 + k]);
 			}
 	}
+	{
+		int64_t bestc = 0;
+		for (int b = 0; b < nb + nmid && b < 64; ++b) {
+			const bucket* B = b < nb ? &bk[b] : &mid[b - nb];
+			char nm[48];
+			snprintf(nm, sizeof nm, b < nb ? "k_filldb<%d>" : "k_filldb<%d,masked>", B->R);
+			note_fill_kernel(c, db_cells[b], &bestc, nm, b < nb ? 8.5 : 11.0, B->R, 1);
+		}
+	}
+	if (ds && prev_t0 >= 0) {     /* the last chunk */
+		const int buf = (chunk_i - 1) & 1;
+		int32_t cnt[2] = { 0, 0 };
+		if (ssw_shim_event_sync(c->ev_red[buf]) || ssw_shim_d2h(cnt, d_cnt_s, sizeof cnt, c->stream) || ssw_shim_stream_sync(c->stream)) {
+			fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
+		}
+		c->tm.n_word += cnt[0]; c->tm.n_byte += cnt[1];
+		c->tm.cells += (Q->h_off[nq] - Q->h_off[0]) * (T->h_off[tfirst + tcount] - T->h_off[tfirst]);
+		ds->fn_rc = ds->fn(ds->user, tfirst + prev_t0, prev_nt, ds->h_hits[buf]);
+	}
 	rc = 0;
 done:
-	free(tk); free(tl); free(hres); free(midpairs);
+	free(tk); free(tl_all); free(hres); free(midpairs);
 	return rc;
 }
 
 static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
-                              const ssw_gpu_params* prm, ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words);
+                              const ssw_gpu_params* prm, ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words, db_stream* ds);
 
 int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
                         const ssw_gpu_params* prm, ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words)
@@ -423,15 +547,17 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 		if (cigar_words) *cigar_words = 0;
 		return -2;      /* (the error text of the running call is left alone) another thread is inside this context: open one context per thread */
 	}
-	const int rc = align_batch_locked(c, Q, T, tfirst, tcount, prm, results, cigar_pool, cigar_words);
+	const int rc = align_batch_locked(c, Q, T, tfirst, tcount, prm, results, cigar_pool, cigar_words, 0);
 	__atomic_store_n(&c->busy, 0, __ATOMIC_RELEASE);
 	return rc;
 }
 
+#define SSW_NOT_STREAMABLE (-3)     /* the fused database-search kernel does not cover this batch: ssw_gpu_search_db takes the generic path */
+
 static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
-                              const ssw_gpu_params* prm, ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words)
+                              const ssw_gpu_params* prm, ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words, db_stream* ds)
 {
-	if (!Q || !T || !prm || !results || !prm->mat) return fail(c, "align_batch: NULL argument%s", "");
+	if (!Q || !T || !prm || (!results && !ds) || !prm->mat) return fail(c, "align_batch: NULL argument%s", "");
 	if (Q->ctx != c || T->ctx != c) return fail(c, "align_batch: sequences belong to another context%s", "");
 	if (tfirst < 0 || tcount < 0 || tfirst + tcount > T->count) return fail(c, "align_batch: target range out of bounds%s", "");
 	if (prm->n < 1 || prm->n > SSW_MAX_N) return fail(c, "align_batch: alphabet size must be 1..32%s", "");
@@ -468,6 +594,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		keys[nqa].key = len <= 16 * SSW_RMAX ? (int32_t)((len + 15) / 16) : (int32_t)(SSW_RMAX + (len + 15) / 16);
 		++nqa;
 	}
+	if (nqa == 0 && ds) { free(order); free(pairs); free(keys); free(qdone); return SSW_NOT_STREAMABLE; }
 	if (nqa == 0) {     /* nothing but empty queries */
 		for (int64_t k = 0; k < (int64_t)nq * tcount; ++k) {
 			ssw_gpu_result* o = &results[k];
@@ -544,10 +671,12 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		for (int32_t ti = 0; ti < tcount; ++ti) { int64_t L = T->h_off[tfirst + ti + 1] - T->h_off[tfirst + ti]; if (L > maxt) maxt = L; }
 		const char* dis = getenv("SSW_GPU_NO_DB");
 		/* (k_filldb takes the column maximum of two rows with a 16-bit float max3, valid below 31744: 640 rows x max(mat) <= 49) */
-		if (!literal && prm->flag == 0 && tcount >= 4 && any_short && maxt <= 65536 && maxmat <= 49 && !(dis && dis[0] == '1')) {
+		const int db_ok = !literal && prm->flag == 0 && any_short && maxt <= 65536 && maxmat <= 49 && !(dis && dis[0] == '1');
+		if (ds && (!db_ok || any_long)) { rc = SSW_NOT_STREAMABLE; goto done; }
+		if (db_ok && (tcount >= 4 || ds)) {
 			for (int b = 0; b < nb; ++b) if (!bk[b].use_x || bk[b].P16 <= 640) for (int32_t k = 0; k < bk[b].nq; ++k) qdone[order[bk[b].first_q + k]] = 1;
 			for (int32_t q = 0; q < nq; ++q) if (Q->h_off[q + 1] == Q->h_off[q]) qdone[q] = 1;     /* empty queries: empty records, written there */
-			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone)) goto done;
+			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone, ds)) goto done;
 			d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq);   /* align_db may have regrown the record buffer */
 			if (!d_res) goto done;
 			if (!any_long) {
@@ -561,8 +690,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 			}
 		}
 	}
-	const int ev_base = c->nev;
-	(void)ev_base;
+	int64_t best_fill_cells = 0;
 
 	for (int32_t ti = 0; ti < tcount; ++ti) {
 		const int32_t t = tfirst + ti;
@@ -613,7 +741,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 					if (want > maxt) want = maxt;
 					want = (want + gran - 1) / gran * gran; if (want < gran) want = gran;
 					tile = (int32_t)(((refLen + want - 1) / want + 15) / 16 * 16);
-					ntiles = (refLen + tile - 1) / tile; halo = halo_full;
+					ntiles = (refLen + tile - 1) / tile; halo = (halo_full + 15) / 16 * 16;     /* (more halo is always exact; multiples of 16 keep the 16-column groups inside one tile) */
 				}
 				const int64_t maxcols = (((int64_t)tile + halo < refLen ? (int64_t)tile + halo : refLen) + 31) / 16 * 16;
 				int64_t per_pair = 8 * stride + (use_x ? 16 * maxcols * ntiles : 0);
@@ -642,6 +770,17 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 				uint32_t* d_cmB16 = dbl ? (uint32_t*)ensure(c, &c->cm16b, (size_t)(4 * stride * chunk)) : d_cmA16;
 				uint32_t* d_cmB8 = dbl ? (uint32_t*)ensure(c, &c->cm8b, (size_t)(4 * stride * chunk)) : d_cmA8;
 				if (!d_cmA16 || !d_cmA8 || !d_cmB16 || !d_cmB8) goto done;
+				/* short-query buckets: k_fill also leaves the maxima of 16-column groups, which is all the reduction reads */
+				const int64_t seg_stride = stride / 16 + 1;
+				uint32_t *d_sg16 = 0, *d_sg8 = 0;
+				{
+					const char* e = getenv("SSW_GPU_SEG_REDUCE");
+					if (!use_x && !dbl && !(e && e[0] == '0')) {
+						d_sg16 = (uint32_t*)ensure(c, &c->sg16, (size_t)(4 * seg_stride * chunk));
+						d_sg8 = (uint32_t*)ensure(c, &c->sg8, (size_t)(4 * seg_stride * chunk));
+						if (!d_sg16 || !d_sg8) goto done;
+					}
+				}
 				int launch_i = 0;
 				for (int32_t p0 = 0; p0 < B->npairs; p0 += (int32_t)chunk, ++launch_i) {
 					const int32_t np = B->npairs - p0 < chunk ? B->npairs - p0 : (int32_t)chunk;
@@ -653,11 +792,14 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 					fa.pairs = d_pairs + B->first_pair + p0; fa.npairs = np; fa.mat = d_mat; fa.n = n;
 					fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.tile = tile; fa.halo = halo; fa.ntiles = ntiles;
 					fa.bpp = (ntiles + 15) / 16; fa.cm16 = d_cm16; fa.cm8 = d_cm8; fa.cm_stride = stride;
+					fa.sg16 = d_sg16; fa.sg8 = d_sg8; fa.seg_stride = seg_stride;
 					/* no cell of this bucket can score 2048 or more -> f16 form of the recurrence (8 instead of 9 instructions per cell) */
 					{
 						const int64_t top = (int64_t)16 * B->R * (maxmat > 0 ? maxmat : 0);     /* no cell of the bucket scores more */
 						fa.f16 = !fill_f16 ? 0 : top <= 2047 ? 1 : top < 31744 ? 2 : 0;
 					}
+					/* strip kernel: two-row column maximum when no score of the bucket can reach 31744 */
+					const int xform = fill_f16 && (int64_t)B->P16 * (maxmat > 0 ? maxmat : 0) < 31744 ? 2 : 0;
 					void* e0 = next_event(c); void* e1 = next_event(c);
 					ssw_shim_event_record(e0, c->stream);
 					if (use_x) {
@@ -666,6 +808,15 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 						xa.gapO2 = gapO2; xa.gapE2 = gapE2; xa.gapE = prm->gapE; xa.maxmat = maxmat; xa.njobs = np * ntiles;
 						xa.pairs = fa.pairs; xa.tile = tile; xa.halo = halo; xa.ntiles = ntiles; xa.cm16 = d_cm16; xa.cm8 = d_cm8;
 						xa.cm_stride = stride; xa.bnd = d_bnd; xa.bnd_stride = maxcols; xa.cand = d_cand; xa.lanes = B->lanes;
+						if (B->lanes == 64) {     /* strips of all jobs behind one work queue (k_chainq) */
+							const int qgrid = chainq_grid(B->R, 0, n);
+							if (chainq_prepare(c, &xa, B->strips, (int64_t)np * ntiles, qgrid)) goto done;
+							xa.form = xform;
+							if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] chainq fill: R %d, %d jobs x %d strips, %d wavefronts, %s tickets, form %d\n",
+							                                     B->R, np * ntiles, B->strips, qgrid, xa.whole_jobs ? "job" : "strip", xa.form);
+							if (ssw_shim_launch_chainq(B->R, 0, &xa, qgrid, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
+							if (getenv("SSW_GPU_DEBUG")) { const int src = ssw_shim_stream_sync(c->stream); fprintf(stderr, "[ssw_gpu] chainq fill done (sync rc %d: %s)\n", src, src ? ssw_shim_last_error() : "ok"); }
+						} else
 						if (ssw_shim_launch_chainx(B->R, 0, &xa, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
 					} else
 					if (ssw_shim_launch_fill(B->R, &fa, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
@@ -678,12 +829,19 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 							int64_t cf = lo - halo > 0 ? lo - halo : 0;
 							cols += hi - cf;
 						}
-						c->tm.fill_cells += cols * (int64_t)(B->lanes * B->R * B->strips) * 2 * np;
+						const int64_t lc = cols * (int64_t)(B->lanes * B->R * B->strips) * 2 * np;
+						c->tm.fill_cells += lc;
+						char nm[48];
+						if (!use_x) snprintf(nm, sizeof nm, "k_fill<%d,%s>", B->R, fa.f16 == 1 ? "f16" : fa.f16 == 2 ? "int16+max3" : "int16");
+						else if (B->lanes == 64) snprintf(nm, sizeof nm, "k_chainq<%d,%s> x %d strips", B->R, xform == 2 ? "int16+max3" : "int16", B->strips);
+						else snprintf(nm, sizeof nm, "k_chainx<%d,16 lanes> x %d strips", B->R, B->strips);
+						note_fill_kernel(c, lc, &best_fill_cells, nm, !use_x ? (fa.f16 == 1 ? 7.5 : fa.f16 == 2 ? 8.5 : 9.0) : (B->lanes == 64 && xform == 2 ? 8.5 : 9.0), B->R, B->strips);
 					}
 					ssw_reduce_args ra;
 					ra.cm16 = d_cm16; ra.cm8 = d_cm8; ra.cm_stride = stride; ra.refLen = refLen; ra.pairs = fa.pairs; ra.npairs = np;
 					ra.qoff = Q->d_off; ra.maskLen = prm->maskLen; ra.bias = bias; ra.score_size = prm->score_size;
 					ra.flag = prm->flag; ra.filters = prm->filters; ra.res = d_res; ra.cand = d_cand; ra.tile = tile; ra.ntiles = ntiles;
+					ra.sg16 = d_sg16; ra.sg8 = d_sg8; ra.seg_stride = seg_stride;
 					if (dbl) {
 						ssw_shim_event_record(c->ev_fill[bi], c->stream);
 						ssw_shim_stream_wait_event(c->stream2, c->ev_fill[bi]);
@@ -728,13 +886,14 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 							if (!d_retry) goto done;
 							int32_t missed = 0;
 							xa.window_extra = pass ? 64 : -1; xa.retry_count = d_retry;
+							const int32_t capS = (B->P16 + capL * capR - 1) / (capL * capR);
 							if (ssw_shim_memset(d_retry, 0, sizeof(int32_t), c->stream) ||
-							    ssw_shim_launch_chainx(capR, 1, &xa, c->stream)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
+							    launch_window_pass(c, capR, capL, capS, &xa, n)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
 							if (pass) {
 								if (ssw_shim_d2h(&missed, d_retry, sizeof(int32_t), c->stream) || ssw_shim_stream_sync(c->stream)) { fail(c, "download failed: %s", ssw_shim_last_error()); goto done; }
 								if (missed > 0) {
 									xa.window_extra = -1;
-									if (ssw_shim_launch_chainx(capR, 1, &xa, c->stream)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
+									if (launch_window_pass(c, capR, capL, capS, &xa, n)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
 								}
 							}
 						}
@@ -912,6 +1071,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		}
 		ssw_shim_event_record(c->ev_c, c->stream);
 
+		if (chainq_check(c)) goto done;
 		if (ssw_shim_d2h(hres, d_res, sizeof(ssw_dres) * (size_t)nq, c->stream) || ssw_shim_stream_sync(c->stream)) {
 			fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
 		}
@@ -975,6 +1135,55 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 	rc = 0;
 done:
 	free(pool); free(order); free(pairs); free(hres); free(hneed); free(bk); free(qdone);
+	return rc;
+}
+
+int ssw_gpu_search_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, const ssw_gpu_params* prm,
+                      int32_t targets_per_chunk, ssw_gpu_hits_fn fn, void* user)
+{
+	if (!c) return fail(0, "search_db: NULL context%s", "");
+	if (!Q || !T || !prm || !fn || !prm->mat) return fail(c, "search_db: NULL argument%s", "");
+	if (Q->ctx != c || T->ctx != c) return fail(c, "search_db: sequences belong to another context%s", "");
+	if (prm->flag != 0) return fail(c, "search_db: scores and end positions only (flag must be 0)%s", "");
+	if (__atomic_exchange_n(&c->busy, 1, __ATOMIC_ACQUIRE)) return -2;
+	ssw_shim_set_device(c->device);
+	const int32_t nq = Q->count, nt_all = T->count;
+	int rc = 0;
+	if (nq > 0 && nt_all > 0) {
+		int64_t chunk = targets_per_chunk > 0 ? targets_per_chunk : 512;
+		/* two device + two page-locked host buffers of nq x chunk compact records: keep each below 1 GiB */
+		while (chunk > 16 && (int64_t)nq * chunk * (int64_t)sizeof(ssw_gpu_hit) > ((int64_t)1 << 30)) chunk /= 2;
+		if (chunk > nt_all) chunk = nt_all;
+		const size_t bytes = sizeof(ssw_gpu_hit) * (size_t)nq * (size_t)chunk;
+		db_stream ds; memset(&ds, 0, sizeof ds);
+		ds.chunk = (int32_t)chunk; ds.fn = fn; ds.user = user;
+		for (int i = 0; i < 2; ++i) { ds.d_hits[i] = (struct ssw_hit_rec*)ssw_shim_malloc(bytes); ds.h_hits[i] = (ssw_gpu_hit*)ssw_shim_host_alloc(bytes); }
+		if (!ds.d_hits[0] || !ds.d_hits[1] || !ds.h_hits[0] || !ds.h_hits[1]) rc = fail(c, "search_db: buffer allocation failed: %s", ssw_shim_last_error());
+		else rc = align_batch_locked(c, Q, T, 0, nt_all, prm, 0, 0, 0, &ds);
+		if (rc == SSW_NOT_STREAMABLE) {
+			/* generic path (queries above 640 residues, matrices with entries above 49, gapO <= gapE, ...): full records per chunk,
+			   converted on the host -- same values, no overlap */
+			ssw_gpu_result* full = (ssw_gpu_result*)ssw_shim_host_alloc(sizeof(ssw_gpu_result) * (size_t)nq * (size_t)chunk);
+			rc = full ? 0 : fail(c, "search_db: buffer allocation failed: %s", ssw_shim_last_error());
+			for (int32_t t0 = 0; rc == 0 && t0 < nt_all; t0 += (int32_t)chunk) {
+				const int32_t nt = nt_all - t0 < chunk ? nt_all - t0 : (int32_t)chunk;
+				rc = align_batch_locked(c, Q, T, t0, nt, prm, full, 0, 0, 0);
+				if (rc) break;
+				for (int64_t k = 0; k < (int64_t)nq * nt; ++k) {
+					ssw_gpu_hit* h = &ds.h_hits[0][k]; const ssw_gpu_result* r = &full[k];
+					h->score1 = r->score1; h->score2 = r->score2; h->ref_end1 = r->ref_end1; h->read_end1 = r->read_end1;
+					h->ref_end2 = r->status == 1 ? -2 : r->ref_end2;
+				}
+				ds.fn_rc = fn(user, t0, nt, ds.h_hits[0]);
+				if (ds.fn_rc) break;
+			}
+			ssw_shim_host_free(full);
+		}
+		if (rc == 0 && ds.fn_rc) rc = ds.fn_rc;
+		ssw_shim_stream_sync(c->stream); ssw_shim_stream_sync(c->stream2);
+		for (int i = 0; i < 2; ++i) { ssw_shim_free(ds.d_hits[i]); ssw_shim_host_free(ds.h_hits[i]); }
+	}
+	__atomic_store_n(&c->busy, 0, __ATOMIC_RELEASE);
 	return rc;
 }
 

@@ -174,6 +174,32 @@ SSW_DEV void chain_rows_masked(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d,
 	}
 }
 
+/* the 16 lanes of a chain write the finished maxima of traversal columns [base, base + 16) (both padding rules) and the
+   maximum over the group: a 4-step row_ror butterfly on the packed values (all 16 lanes end up with it, lane 0 stores it) */
+template <int R, bool F16>
+SSW_DEV void fill_flush16(unsigned char* lds, u32 out16, u32 out8, int base, int l16, int store_from, int ncols,
+                          uint32_t* o16, uint32_t* o8, uint32_t* g16, uint32_t* g8)
+{
+	typedef ChainGeom<R> G;
+	const int tc = base + l16;
+	u32 i16 = 0, i8 = 0;
+	if (tc >= store_from && tc < ncols) {
+		const u32 v16 = lds_ld32(lds, out16 + 4u * (tc & 63)), v8 = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
+		i16 = F16 ? pkf_to_int2(v16) : v16;
+		i8 = F16 ? pkf_to_int2(v8) : v8;
+		o16[tc] = i16;
+		o8[tc] = i8;
+	}
+	if (g16) {
+		u32 m16 = i16, m8 = i8;
+		m16 = pk_max(m16, xl_row_ror<1>(m16)); m8 = pk_max(m8, xl_row_ror<1>(m8));
+		m16 = pk_max(m16, xl_row_ror<2>(m16)); m8 = pk_max(m8, xl_row_ror<2>(m8));
+		m16 = pk_max(m16, xl_row_ror<4>(m16)); m8 = pk_max(m8, xl_row_ror<4>(m8));
+		m16 = pk_max(m16, xl_row_ror<8>(m16)); m8 = pk_max(m8, xl_row_ror<8>(m8));
+		if (l16 == 0 && base >= store_from && base < ncols) { g16[base >> 4] = m16; g8[base >> 4] = m8; }
+	}
+}
+
 /* ================================================================================================
  * k_fill: forward fill, column maxima only.  grid = npairs * bpp workgroups of 256 threads.
  * ================================================================================================ */
@@ -213,6 +239,10 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 	uint32_t* o16 = a.cm16 + (int64_t)pair * a.cm_stride + c_first;
 	uint32_t* o8 = a.cm8 + (int64_t)pair * a.cm_stride + c_first;
 	const int store_from = tile_lo - c_first;   /* first traversal column whose maximum is kept */
+	/* maxima of every aligned group of 16 columns (tiles and halos are multiples of 16 columns, so a group belongs to one tile):
+	   k_reduce_seg scans these instead of the columns themselves */
+	uint32_t* g16 = a.sg16 ? a.sg16 + (int64_t)pair * a.seg_stride + (c_first >> 4) : (uint32_t*)0;
+	uint32_t* g8 = a.sg16 ? a.sg8 + (int64_t)pair * a.seg_stride + (c_first >> 4) : (uint32_t*)0;
 
 	/* target ring: columns -16..-1 are "null" columns, 0..15 loaded now, 16..31 in flight */
 	lds_st16(lds, ring + 2u * (48 + l16), nulloff);
@@ -252,14 +282,7 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 			nxt = (u32)code * G::PSTRIDE;
 		}
 		wave_lds_fence();   /* lane 0's ring writes of the previous 16 steps are visible to the chain */
-		if (s0 >= 32) {   /* columns [s0-32, s0-16) are complete in the out rings */
-			const int tc = s0 - 32 + l16;
-			if (tc >= store_from && tc < ncols) {
-				const u32 v16 = lds_ld32(lds, out16 + 4u * (tc & 63)), v8 = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
-				o16[tc] = F16 ? pkf_to_int2(v16) : v16;
-				o8[tc] = F16 ? pkf_to_int2(v8) : v8;
-			}
-		}
+		if (s0 >= 32) fill_flush16<R, F16>(lds, out16, out8, s0 - 32, l16, store_from, ncols, o16, o8, g16, g8);   /* columns [s0-32, s0-16) are complete in the out rings */
 		wave_lds_fence();
 		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
 		/* lane 0 parks finished maxima: column s-16 (all rows) and column s-1-TAP (rows < A8, stored in the slot of s-16) */
@@ -285,14 +308,8 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 		}
 	}
 	wave_lds_fence();
-	for (int base = nsteps - 32; base < nsteps; base += 16) {
-		const int tc = base + l16;
-		if (tc >= store_from && tc < ncols && tc >= 0) {
-			const u32 v16 = lds_ld32(lds, out16 + 4u * (tc & 63)), v8 = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
-			o16[tc] = F16 ? pkf_to_int2(v16) : v16;
-			o8[tc] = F16 ? pkf_to_int2(v8) : v8;
-		}
-	}
+	for (int base = nsteps - 32; base < nsteps; base += 16)
+		if (base >= 0) fill_flush16<R, F16>(lds, out16, out8, base, l16, store_from, ncols, o16, o8, g16, g8);
 }
 
 /* ================================================================================================
@@ -395,6 +412,13 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			}
 		}
 		wave_lds_fence();
+		{   /* once per 16 steps the lanes of a chain learn the chain's best so far: a lane's own creeping maximum below it is no
+		       candidate for the best cell, so it need not be recorded (>= the chain's best still is: the first column wins ties,
+		       and lanes higher up are ahead in columns) -- records per target drop from ~100 to the handful of true improvements */
+			u32 g = best;
+			g = pk_max(g, xl_row_ror<1>(g)); g = pk_max(g, xl_row_ror<2>(g)); g = pk_max(g, xl_row_ror<4>(g)); g = pk_max(g, xl_row_ror<8>(g));
+			best = pk_max(best, pk_subu(g, 0x00010001u));
+		}
 		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
 		const u32 ob16 = out16 + 4u * (u32)((s0 - 16) & 63), ob8 = out8 + 4u * (u32)((s0 - 16) & 63);
 #pragma unroll 4
@@ -421,7 +445,7 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			else chain_rows<R, true, false, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);   /* the host keeps max(mat) x 640 below 31744 on this path */
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
 			best = pk_max(best, cm);     /* = max(pre, own rows) */
-			const bool hit = best != pre && tc >= 0 && tc < ncols;
+			const bool hit = best != pre;   /* (columns outside the target score "dead": H = max(E, F) there, which decays and never sets a record) */
 			if (wave_any(hit)) {         /* a scalar branch: hipcc otherwise if-converts half of the row search into every step */
 				if (hit) {
 #pragma unroll
@@ -520,7 +544,13 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 				if (maskLen >= 15) { r.score2 = s2; r.ref_end2 = s2 > 0 ? i2 : 0; }
 				else { r.score2 = 0; r.ref_end2 = -1; }
 			}
-			if (a.out) {
+			if (a.hits) {      /* compact score-only record of the streaming database search (include/ssw_gpu.h ssw_gpu_hit) */
+				ssw_hit_rec o;
+				o.score1 = (uint16_t)r.score1; o.score2 = (uint16_t)r.score2; o.ref_end1 = r.ref_end1; o.read_end1 = r.read_end1;
+				o.ref_end2 = r.status == 1 ? -2 : r.ref_end2;
+				a.hits[(int64_t)q * a.res_nt + (t - a.tfirst)] = o;
+				if (a.counters && r.status == 0 && r.score1 > 0) atomicAdd(a.counters + (r.word ? 0 : 1), 1);
+			} else if (a.out) {
 				ssw_out_rec o;
 				o.score1 = (uint16_t)r.score1; o.score2 = (uint16_t)r.score2; o.ref_begin1 = -1; o.ref_end1 = r.ref_end1; o.read_begin1 = -1;
 				o.read_end1 = r.read_end1; o.ref_end2 = r.ref_end2; o.cigarLen = 0; o.edit_distance = 0; o.cigar_off = -1; o.flag = 0; o.status = (uint16_t)r.status;
@@ -646,6 +676,108 @@ __global__ void __launch_bounds__(256) k_reduce(ssw_reduce_args a)
 						r[h].loc_done = 1;
 					}
 				}
+			}
+			a.res[q] = r[h];
+		}
+	}
+}
+
+/* k_reduce_seg: the same reduction over the maxima of 16-column groups that k_fill leaves behind (1/16 of the words); the
+   columns themselves are only read in the group that holds the best column and in the (at most two per query) groups that the
+   edges of the mask window cut.  Results are identical to k_reduce's: "first column holding the maximum" = first group holding
+   it, then first column inside. */
+SSW_DEV void seg_first_column(const uint32_t* cols, int seg, int refLen, int hi, int value, int lo_edge, int up_from, bool masked, int& col)
+{
+	col = 0x7fffffff;
+	for (int k = 0; k < 16; ++k) {
+		const int c = seg * 16 + k;
+		if (c >= refLen) break;
+		if (masked && !(c < lo_edge || c >= up_from)) continue;
+		if (half16(cols[c], hi) == value) { col = c; break; }
+	}
+}
+
+__global__ void __launch_bounds__(256) k_reduce_seg(ssw_reduce_args a)
+{
+	SSW_DYN_LDS(lds);
+	const int tid = (int)threadIdx.x, pair = (int)blockIdx.x;
+	const ssw_pair pr = a.pairs[pair];
+	const uint32_t* c16 = a.cm16 + (int64_t)pair * a.cm_stride;
+	const uint32_t* c8 = a.cm8 + (int64_t)pair * a.cm_stride;
+	const uint32_t* g16 = a.sg16 + (int64_t)pair * a.seg_stride;
+	const uint32_t* g8 = a.sg8 + (int64_t)pair * a.seg_stride;
+	const int nseg = (a.refLen + 15) >> 4;
+
+	/* pass 1: best score and the first group that holds it, both queries in one sweep */
+	int best[2] = { 0, 0 }, bseg[2] = { 0x7fffffff, 0x7fffffff };
+	for (int g = tid; g < nseg; g += 256) {
+		const u32 w = g16[g];
+		const int lo = (int)(w & 0xffffu), hi = (int)(w >> 16);
+		if (lo > best[0]) { best[0] = lo; bseg[0] = g; }
+		if (hi > best[1]) { best[1] = hi; bseg[1] = g; }
+	}
+	block_argmax(lds, tid, best[0], bseg[0]);
+	block_argmax(lds, tid, best[1], bseg[1]);
+	int bidx[2] = { 0x7fffffff, 0x7fffffff };
+	for (int h = 0; h < 2; ++h) if (best[h] > 0) seg_first_column(c16, bseg[h], a.refLen, h, best[h], 0, 0, false, bidx[h]);
+
+	ssw_dres r[2];
+	int use8[2] = { 0, 0 }, lo_edge[2] = { 0, 0 }, up_from[2] = { 0, 0 }, live[2] = { 0, 0 }, mlen[2] = { 0, 0 };
+	for (int h = 0; h < 2; ++h) {
+		const int q = h ? pr.qb : pr.qa;
+		ssw_dres& x = r[h];
+		x.score1 = 0; x.score2 = 0; x.ref_begin1 = -1; x.ref_end1 = 0; x.read_begin1 = -1; x.read_end1 = 0;
+		x.ref_end2 = 0; x.cigarLen = 0; x.flag = 0; x.status = 0; x.word = 0; x.want_begin = 0; x.want_cigar = 0;
+		x.rev_score = 0; x.loc_done = 0; x.nm = 0; x.cigar_off = 0;
+		if (q < 0) continue;
+		const int len = (int)(a.qoff[q + 1] - a.qoff[q]);
+		const bool padded = (len & 15) >= 1 && (len & 15) <= 8;      /* 16-bit rules see 8 rows fewer */
+		mlen[h] = a.maskLen >= 0 ? a.maskLen : len / 2;
+		const bool have_byte = a.score_size == 0 || a.score_size == 2, have_word = a.score_size == 1 || a.score_size == 2;
+		int word = 0;
+		if (have_byte && best[h] < 255 - a.bias) word = 0;             /* ssw.c:881-899 */
+		else if (have_word) word = 1;
+		else x.status = 1;
+		x.word = word;
+		if (x.status == 0 && best[h] > 0) {
+			live[h] = 1;
+			use8[h] = word && padded;
+			lo_edge[h] = bidx[h] - mlen[h] > 0 ? bidx[h] - mlen[h] : 0;
+			const int hi_edge = bidx[h] + mlen[h] > a.refLen ? a.refLen : bidx[h] + mlen[h];
+			up_from[h] = word ? hi_edge : hi_edge + 1;                 /* ssw.c:376 vs 578 */
+		}
+	}
+
+	/* pass 2: masked second best.  A group entirely outside the mask window counts with its maximum; a group the window cuts
+	   is looked at column by column; ties go to the lowest group, then the lowest column (the reference scans upwards, strict >) */
+	int s2[2] = { 0, 0 }, g2[2] = { 0x7fffffff, 0x7fffffff };
+	for (int h = 0; h < 2; ++h) {
+		if (!live[h]) continue;
+		const uint32_t* gs = use8[h] ? g8 : g16;
+		const uint32_t* cs = use8[h] ? c8 : c16;
+		for (int g = tid; g < nseg; g += 256) {
+			const int c0 = g * 16, c1 = c0 + 16 < a.refLen ? c0 + 16 : a.refLen;      /* columns [c0, c1) */
+			int v = 0;
+			if (c1 <= lo_edge[h] || c0 >= up_from[h]) v = half16(gs[g], h);              /* wholly allowed */
+			else if (c0 >= lo_edge[h] && c1 <= up_from[h]) continue;                      /* wholly masked */
+			else for (int c = c0; c < c1; ++c) if (c < lo_edge[h] || c >= up_from[h]) { const int w = half16(cs[c], h); v = w > v ? w : v; }
+			if (v > s2[h]) { s2[h] = v; g2[h] = g; }
+		}
+	}
+	block_argmax(lds, tid, s2[0], g2[0]);
+	block_argmax(lds, tid, s2[1], g2[1]);
+	if (tid == 0) {
+		for (int h = 0; h < 2; ++h) {
+			const int q = h ? pr.qb : pr.qa;
+			if (q < 0) continue;
+			if (live[h]) {
+				r[h].score1 = best[h]; r[h].ref_end1 = bidx[h];
+				if (mlen[h] >= 15) {
+					int i2 = 0;
+					if (s2[h] > 0) seg_first_column(use8[h] ? c8 : c16, g2[h], a.refLen, h, s2[h], lo_edge[h], up_from[h], true, i2);
+					r[h].score2 = s2[h]; r[h].ref_end2 = s2[h] > 0 ? i2 : 0;
+				} else { r[h].score2 = 0; r[h].ref_end2 = -1; }
+				r[h].want_begin = !(a.flag == 0 || (a.flag == 2 && best[h] < a.filters));   /* ssw.c:916 */
 			}
 			a.res[q] = r[h];
 		}
@@ -845,6 +977,7 @@ struct StripCtx {
 	u32* o16; u32* o8; /* fill: column maxima of the last strip */
 	u32 gapO2, gapE2;
 	int n;
+	u32 bmask;         /* boundary-out ring: entries - 1 (63, or 31 in the LDS-trimmed queue kernel) */
 };
 
 template <int PS> SSW_DEV u32 strip_code_off(const StripCtx& x, int h, int tc, bool capture)
@@ -855,7 +988,7 @@ template <int PS> SSW_DEV u32 strip_code_off(const StripCtx& x, int h, int tc, b
 	return (u32)code * (u32)PS;
 }
 
-template <int R, bool CAPTURE, bool MASK8, int GL>
+template <int R, bool CAPTURE, bool MASK8, int GL, bool CM3 = false>
 SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st, const u32 (&m8)[R])
 {
 	typedef StripGeom<R, GL> G;
@@ -935,7 +1068,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 		if (s0 >= GL + 16 && stg) {   /* boundary-out records of columns [s0-GL-16, s0-GL) are complete */
 			const int tc = s0 - GL - 16 + l16;
 			if (x.mine && tc < x.ncols) {
-				const u32x4 rec = lds_ld128(lds, x.bout + 16u * (tc & 63));
+				const u32x4 rec = lds_ld128(lds, x.bout + 16u * ((u32)tc & x.bmask));
 				if (!x.last) *(u32x4*)(x.bnd + 4 * (int64_t)tc) = rec;
 				else if (!CAPTURE && tc >= x.store_from) { x.o16[tc] = rec[2]; x.o8[tc] = rec[3]; }
 			}
@@ -981,7 +1114,11 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 				const u32 t0 = pk_subu(h0, x.gapO2);
 				st.E[r] = pk_max(pk_subu(st.E[r], x.gapE2), t0);
 				f = pk_max(pk_subu(f, x.gapE2), t0);
-				if (CAPTURE) lm = pk_max(lm, h); else cm = pk_max(cm, h);
+				if (CAPTURE) lm = pk_max(lm, h);
+				else if (CM3 && !MASK8) {   /* column maximum of two rows in one instruction (scores below 31744: pk_max3_nonneg) */
+					if (r & 1) cm = pk_max3_nonneg(cm, st.H[r - 1 >= 0 ? r - 1 : 0], h);
+					else if (r == R - 1) cm = pk_max(cm, h);
+				} else cm = pk_max(cm, h);
 				if (MASK8) cm8 = pk_max(cm8, h & m8[r]);
 				st.H[r] = h;
 				d = hold;
@@ -1006,7 +1143,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			st.hsave = hin; st.Hlast = st.H[R - 1]; st.Fout = f; st.cmout = cm; st.cm8out = MASK8 ? cm8 : cm;
 			if (l16 == GL - 1) {
 				const u32x4 o = { st.Hlast, st.Fout, st.cmout, st.cm8out };
-				lds_st128(lds, x.bout + 16u * ((s - (GL - 1)) & 63), o);
+				lds_st128(lds, x.bout + 16u * ((u32)(s - (GL - 1)) & x.bmask), o);
 			}
 			if (CAPTURE) {   /* rarely taken: some half reaches (at least) its best so far -- sbest holds best - 1 per half */
 				if (pk_max(sbest, lm) != sbest && x.mine && tc >= 0) {
@@ -1028,7 +1165,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	for (int base = x.nsteps - GL - 16; base < x.nsteps - GL + 16; base += 16) {
 		const int tc = base + l16;
 		if (stg && x.mine && tc >= 0 && tc < x.ncols) {
-			const u32x4 rec = lds_ld128(lds, x.bout + 16u * (tc & 63));
+			const u32x4 rec = lds_ld128(lds, x.bout + 16u * ((u32)tc & x.bmask));
 			if (!x.last) *(u32x4*)(x.bnd + 4 * (int64_t)tc) = rec;
 			else if (!CAPTURE && tc >= x.store_from) { x.o16[tc] = rec[2]; x.o8[tc] = rec[3]; }
 		}
@@ -1109,7 +1246,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 	x.prof = (u32)grp * (prof_bytes + G::EXTRA); x.ring = x.prof + prof_bytes; x.ringb = x.ring + G::RINGB; x.bin = x.ringb + G::RINGB;
 	x.bout = x.bin + BND_RING_BYTES; x.nulloff = (u32)a.n * G::PSTRIDE;
 	const u32 red = x.bout + BND_RING_BYTES;
-	x.l16 = l16; x.gapO2 = a.gapO2; x.gapE2 = a.gapE2; x.n = a.n; x.tg = a.tgt;
+	x.l16 = l16; x.gapO2 = a.gapO2; x.gapE2 = a.gapE2; x.n = a.n; x.tg = a.tgt; x.bmask = 63u;
 	const int job = (int)blockIdx.x * (64 / GL) + grp;
 	const bool valid = job < a.njobs;
 
@@ -1212,6 +1349,155 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 				cap_half_finish(ch[h], a, bv, bc, br);
 			}
 			wave_lds_fence();
+		}
+	}
+}
+
+/* ================================================================================================
+ * k_chainq: the 64-lane strip kernel behind a work queue.  k_chainx gives a job (a query pair x a target tile, or two
+ * window passes) to one wavefront that walks the job's S row strips one after the other: a batch of J jobs is J
+ * wavefronts of S strips each, which fills 2048 wavefront slots in ceil(J / 2048) rounds -- 5000 long-read pairs leave a
+ * fifth of the device idle in the last round.  Here the unit of work is ONE STRIP: a persistent launch draws tickets
+ * (item k = strip k / J of job k % J, strip-major) and a strip only waits for the completion flag of the strip above it,
+ * which was drawn J tickets earlier and is normally long done.  What a wavefront carried in registers from strip to
+ * strip (the best cell so far) travels through a 32-byte record per item instead; the boundary rows travel through HBM as
+ * before.  LDS is trimmed (one target ring in fill mode, 32-entry boundary-out ring, reduction scratch aliased) so that
+ * 12 rows per lane leave room for 8 wavefronts per CU.  FORM 2: two-row column maximum (scores below 31744).
+ * ================================================================================================ */
+template <int R, bool CAPTURE> struct QueueGeom {
+	static constexpr int C = (R + 3) / 4;
+	static constexpr u32 PSTRIDE = (u32)C * 1024u;
+	static constexpr u32 RINGB = (128u + 32u) * 2u;
+	static constexpr u32 BOUT = 32u * 16u;
+	static constexpr u32 EXTRA = (CAPTURE ? 2u : 1u) * RINGB + BND_RING_BYTES + BOUT;   /* the 768-byte reduction scratch aliases the boundary-in ring */
+};
+
+template <int R, bool CAPTURE, int FORM>
+__global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
+{
+	constexpr int GL = 64;
+	typedef StripGeom<R, GL> G;
+	typedef QueueGeom<R, CAPTURE> QG;
+	SSW_DYN_LDS(lds);
+	const int tid = (int)threadIdx.x, l16 = tid;
+	const u32 prof_bytes = (u32)(a.n + 1) * G::PSTRIDE;
+	StripCtx x;
+	x.prof = 0; x.ring = prof_bytes; x.ringb = x.ring + (CAPTURE ? QG::RINGB : 0u); x.bin = x.ringb + QG::RINGB;
+	x.bout = x.bin + BND_RING_BYTES; x.nulloff = (u32)a.n * G::PSTRIDE; x.bmask = 31u;
+	const u32 red = x.bin;
+	x.l16 = l16; x.gapO2 = a.gapO2; x.gapE2 = a.gapE2; x.n = a.n; x.tg = a.tgt;
+	const int S = a.strips, nitems = a.njobs * S;
+	int* const ticket = a.queue; int* const flags = a.queue + 1;
+
+	/* a.whole_jobs: a ticket is a whole job whose strips this wavefront walks itself (no waiting on other wavefronts at all:
+	   for batches with fewer jobs than wavefront slots a strip-level queue would only make wavefronts wait for each other) */
+	const int nticket = a.whole_jobs ? a.njobs : nitems;
+	for (;;) {
+		int k = 0;
+		if (tid == 0) k = dev_ticket(ticket);
+		k = (int)xl_readlane((u32)k, 0);
+		if (k >= nticket) break;
+		const int s_first = a.whole_jobs ? 0 : k / a.njobs, s_end = a.whole_jobs ? S : s_first + 1;
+		const int job = a.whole_jobs ? k : k - s_first * a.njobs;
+		for (int sidx = s_first; sidx < s_end; ++sidx) {
+		int* const my_flag = flags + (int64_t)job * S + sidx;
+		int32_t* const my_cand = a.cand_strip + ((int64_t)job * S + sidx) * 8;
+
+		const int8_t *qa = a.qcodes, *qb = 0;
+		int lena = 0, lenb = 0, rev = 0, rowsa = 0, rowsb = 0, rows_total = 0, p8a = 0, p8b = 0;
+		bool active = false;
+		CapHalf ch[2];
+		x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0;
+		x.ncols2[0] = x.ncols2[1] = 0; x.c_edge2[0] = x.c_edge2[1] = 0;
+		if (sidx > 0) {   /* everything the strip above wrote -- boundary records, its best cell, and (window passes) the records */
+			if (!a.whole_jobs && tid == 0 && !dev_flag_wait(flags + (int64_t)job * S + sidx - 1)) atomicAdd(a.queue + 1 + nitems, 1);   /* error word: the host fails the call */
+			dev_fence();
+		}
+		if (!CAPTURE) {
+			const int pair = job / a.ntiles, t = job - pair * a.ntiles;
+			const ssw_pair pr = a.pairs[pair];
+			qa = a.qcodes + a.qoff[pr.qa]; lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
+			if (pr.qb >= 0) { qb = a.qcodes + a.qoff[pr.qb]; lenb = (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]); }
+			rows_total = ((lena > lenb ? lena : lenb) + 15) & ~15;
+			rowsa = rowsb = rows_total;
+			p8a = (lena + 7) & ~7; p8b = qb ? (lenb + 7) & ~7 : rows_total;
+			const int tile_lo = t * a.tile, tile_hi = tile_lo + a.tile < a.refLen ? tile_lo + a.tile : a.refLen;
+			const int c_first = tile_lo - a.halo > 0 ? tile_lo - a.halo : 0;
+			x.c_edge = c_first; x.ncols = tile_hi - c_first; x.store_from = tile_lo - c_first;
+			x.o16 = a.cm16 + (int64_t)pair * a.cm_stride + c_first; x.o8 = a.cm8 + (int64_t)pair * a.cm_stride + c_first;
+			active = true;
+		} else {
+			cap_half_setup(ch[0], a, a.qlist[2 * job]);
+			cap_half_setup(ch[1], a, 2 * job + 1 < a.nlist ? a.qlist[2 * job + 1] : -1);
+			active = ch[0].active || ch[1].active;
+			rev = a.reverse;
+			x.dirstep = a.reverse ? -1 : 1;
+			if (ch[0].active) { qa = ch[0].qc; lena = ch[0].lena; rowsa = ch[0].rows; }
+			if (ch[1].active) { qb = ch[1].qc; lenb = ch[1].lena; rowsb = ch[1].rows; }
+			rows_total = rowsa > rowsb ? rowsa : rowsb;
+			for (int h = 0; h < 2; ++h) { x.ncols2[h] = ch[h].active ? ch[h].ncols : 0; x.c_edge2[h] = ch[h].c_edge; }
+			x.ncols = x.ncols2[0] > x.ncols2[1] ? x.ncols2[0] : x.ncols2[1];
+		}
+		const int Sjob = active ? (rows_total + GL * R - 1) / (GL * R) : 0;
+		if (sidx >= Sjob) {   /* this job has fewer strips than the launch's S (window passes of short prefixes): nothing to do */
+			if (tid == 0) dev_flag_set(my_flag);
+			continue;
+		}
+		x.nsteps = (x.ncols + GL + 15) & ~15;
+		x.bnd = a.bnd + (int64_t)job * a.bnd_stride * 4;
+		x.mine = true; x.first = sidx == 0; x.last = sidx == Sjob - 1; x.row0 = sidx * GL * R;
+
+		/* the best cell so far of this job: what the strips above found (value, first column, smallest row per half) */
+		int cv[2] = { 0, 0 }, cc[2] = { 0x7fffffff, 0x7fffffff }, cr[2] = { CAPTURE ? 0 : 0x7fffffff, CAPTURE ? 0 : 0x7fffffff };
+		if (sidx > 0) {
+			const int32_t* pc = a.cand_strip + ((int64_t)job * S + sidx - 1) * 8;
+			for (int h = 0; h < 2; ++h) { cv[h] = pc[4 * h]; cc[h] = pc[4 * h + 1]; cr[h] = pc[4 * h + 2]; }
+		}
+		ChainState<R> st;
+		for (int h = 0; h < 2; ++h) {
+			st.best[h] = CAPTURE ? cv[h] : 0; st.btc[h] = CAPTURE ? cc[h] : 0x7fffffff; st.brow[h] = CAPTURE ? cr[h] : 0;
+			st.tv[h] = 0; st.ttc[h] = 0x7fffffff; st.trow[h] = 0x7fffffff;
+		}
+		build_profile_strip<R, GL>(lds, x.prof, l16, GL, a.mat, a.n, qa, lena, rev, rowsa, qb, lenb, rev, rowsb, x.row0);
+		u32 m8[R];
+		bool need_mask = false;
+		if (!CAPTURE) {
+			need_mask = x.last && (p8a < rows_total || p8b < rows_total);
+#pragma unroll
+			for (int q = 0; q < R; ++q) {
+				const int row = x.row0 + l16 * R + q;
+				m8[q] = (row < p8a ? 0xffffu : 0u) | (row < p8b ? 0xffff0000u : 0u);
+			}
+		} else {
+#pragma unroll
+			for (int q = 0; q < R; ++q) m8[q] = 0;
+		}
+		if (!CAPTURE && need_mask) run_strip<R, CAPTURE, true, GL, false>(lds, x, st, m8);
+		else run_strip<R, CAPTURE, false, GL, FORM == 2>(lds, x, st, m8);
+
+		/* chain-wide winner of this strip merged with the strips above: value, then first column, then smallest row */
+		for (int h = 0; h < 2; ++h) {
+			lds_st32(lds, red + 12u * l16, (u32)(CAPTURE ? st.best[h] : st.tv[h]));
+			lds_st32(lds, red + 12u * l16 + 4, (u32)(CAPTURE ? st.btc[h] : st.ttc[h]));
+			lds_st32(lds, red + 12u * l16 + 8, (u32)(CAPTURE ? st.brow[h] : st.trow[h]));
+			wave_lds_fence();
+			if (l16 == 0) {
+				int bv = cv[h], bc = cc[h], br = cr[h];
+				for (int q = 0; q < GL; ++q) {
+					const int v = (int)lds_ld32(lds, red + 12u * q), c = (int)lds_ld32(lds, red + 12u * q + 4), w = (int)lds_ld32(lds, red + 12u * q + 8);
+					if (v > bv || (v == bv && v > 0 && (c < bc || (c == bc && w < br)))) { bv = v; bc = c; br = w; }
+				}
+				my_cand[4 * h] = bv; my_cand[4 * h + 1] = bc; my_cand[4 * h + 2] = br; my_cand[4 * h + 3] = 0;
+				if (x.last) {
+					if (!CAPTURE) {
+						if (a.cand) { int32_t* cd = a.cand + ((int64_t)job * 2 + h) * 4; cd[0] = bv; cd[1] = bv > 0 ? x.c_edge + bc : -1; cd[2] = br; cd[3] = 0; }
+					} else if (ch[h].active) cap_half_finish(ch[h], a, bv, bc, br);
+				}
+			}
+			wave_lds_fence();
+		}
+		dev_fence();
+		if (tid == 0) dev_flag_set(my_flag);
 		}
 	}
 }
@@ -2064,7 +2350,8 @@ extern "C" int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream)
 {
 	ssw_reduce_args args = *a;
 	if (args.npairs <= 0) return 0;
-	SSW_LAUNCH(k_reduce, ssw_reduce_args, args, args.npairs, 256, 256 * 8, stream);
+	if (args.sg16) SSW_LAUNCH(k_reduce_seg, ssw_reduce_args, args, args.npairs, 256, 256 * 8, stream);
+	else SSW_LAUNCH(k_reduce, ssw_reduce_args, args, args.npairs, 256, 256 * 8, stream);
 	return SSW_LAUNCH_OK();
 }
 
@@ -2097,18 +2384,7 @@ extern "C" int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args*
 	ssw_chainx_args args = *a;
 	if (capture) { args.nlist = args.njobs; args.njobs = (args.njobs + 1) / 2; }   /* two queries of the list per job */
 	if (args.njobs <= 0) return 0;
-	if (args.lanes == 64) {   /* the whole wavefront is one chain: one job per workgroup */
-		const int grid = args.njobs;
-		switch (R) {
-#define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * StripGeom<r, 64>::PSTRIDE + StripGeom<r, 64>::EXTRA; \
-		if (capture) SSW_LAUNCH((k_chainx<r, true, 64>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
-		else SSW_LAUNCH((k_chainx<r, false, 64>), ssw_chainx_args, args, grid, 64, ldsb, stream); } break;
-			X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
-#undef X
-			default: return -2;
-		}
-		return SSW_LAUNCH_OK();
-	}
+	if (args.lanes != 16) return -2;      /* 64-lane chains run behind the work queue: ssw_shim_launch_chainq */
 	const int grid = (args.njobs + 3) / 4;
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = 4 * ((size_t)(args.n + 1) * StripGeom<r, 16>::PSTRIDE + StripGeom<r, 16>::EXTRA); \
@@ -2119,6 +2395,55 @@ extern "C" int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args*
 		default: return -2;
 	}
 	return SSW_LAUNCH_OK();
+}
+
+#define FOR_EACH_QR(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+
+/* 64-lane chains behind the work queue: a persistent launch of at most max_workgroups wavefronts (0: one per item) that
+   draws njobs x strips items; args.queue must be zeroed (1 + items + 1 words: ticket counter, flags, error word),
+   args.cand_strip holds 8 words per item */
+extern "C" int ssw_shim_launch_chainq(int R, int capture, const ssw_chainx_args* a, int max_workgroups, void* stream)
+{
+	ssw_chainx_args args = *a;
+	if (capture) { args.nlist = args.njobs; args.njobs = (args.njobs + 1) / 2; }
+	if (args.njobs <= 0 || args.strips <= 0) return 0;
+	const int64_t items = (int64_t)args.njobs * args.strips;
+	if (items > 0x7ffffff0) return -2;
+	int64_t grid = args.whole_jobs ? args.njobs : items;
+	if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;
+	switch (R) {
+#define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * StripGeom<r, 64>::PSTRIDE + (capture ? QueueGeom<r, true>::EXTRA : QueueGeom<r, false>::EXTRA); \
+		if (capture) SSW_LAUNCH((k_chainq<r, true, 0>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
+		else if (args.form == 2) SSW_LAUNCH((k_chainq<r, false, 2>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
+		else SSW_LAUNCH((k_chainq<r, false, 0>), ssw_chainx_args, args, grid, 64, ldsb, stream); } break;
+		FOR_EACH_QR(X)
+#undef X
+		default: return -2;
+	}
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_chainq_resident(int R, int capture, int n)
+{
+#ifdef SSW_SIMT_EMU
+	(void)R; (void)capture; (void)n; return 0;
+#else
+	static int cache[17][2][SSW_MAX_N + 1];      /* the occupancy query is not free and the answer does not change */
+	if (R < 1 || R > 16 || n < 1 || n > SSW_MAX_N) return 0;
+	if (cache[R][capture ? 1 : 0][n] > 0) return cache[R][capture ? 1 : 0][n];
+	int per_cu = 0, dev = 0, cus = 0;
+	switch (R) {
+#define X(r) case r: { const size_t ldsb = (size_t)(n + 1) * StripGeom<r, 64>::PSTRIDE + (capture ? QueueGeom<r, true>::EXTRA : QueueGeom<r, false>::EXTRA); \
+		if (capture) { shim_allow_lds(k_chainq<r, true, 0>, ldsb); if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chainq<r, true, 0>, 64, ldsb) != hipSuccess) per_cu = 0; } \
+		else { shim_allow_lds(k_chainq<r, false, 0>, ldsb); if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chainq<r, false, 0>, 64, ldsb) != hipSuccess) per_cu = 0; } } break;
+		FOR_EACH_QR(X)
+#undef X
+		default: return 0;
+	}
+	if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+	cache[R][capture ? 1 : 0][n] = per_cu * cus;
+	return per_cu * cus;
+#endif
 }
 
 extern "C" int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream)
@@ -2232,6 +2557,7 @@ extern "C" void* ssw_shim_event_create(void)
 }
 extern "C" void ssw_shim_event_destroy(void* e) { if (e) (void)hipEventDestroy((hipEvent_t)e); }
 extern "C" int ssw_shim_event_record(void* e, void* s) { return shim_check(hipEventRecord((hipEvent_t)e, (hipStream_t)s), "hipEventRecord"); }
+extern "C" int ssw_shim_event_sync(void* e) { return shim_check(hipEventSynchronize((hipEvent_t)e), "hipEventSynchronize"); }
 extern "C" int ssw_shim_stream_wait_event(void* s, void* e) { return shim_check(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0), "hipStreamWaitEvent"); }
 extern "C" float ssw_shim_event_elapsed_ms(void* a, void* b)
 {

@@ -48,7 +48,12 @@ class Timing(C.Structure):
     """ssw_gpu_timing (include/ssw_gpu.h)."""
     _fields_ = [("total_ms", C.c_double), ("fill_ms", C.c_double), ("fill_launches", C.c_int64),
                 ("fill_cells", C.c_int64), ("cells", C.c_int64), ("reduce_ms", C.c_double), ("locate_ms", C.c_double),
-                ("trace_ms", C.c_double), ("n_word", C.c_int64), ("n_byte", C.c_int64)]
+                ("trace_ms", C.c_double), ("n_word", C.c_int64), ("n_byte", C.c_int64), ("fill_kernel", C.c_char * 48),
+                ("fill_ops_per_row", C.c_double), ("fill_rows_per_lane", C.c_int32), ("fill_strips", C.c_int32)]
+
+
+HIT_DTYPE = np.dtype([("score1", "<u2"), ("score2", "<u2"), ("ref_end1", "<i4"), ("read_end1", "<i4"), ("ref_end2", "<i4")], align=True)
+HITS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p)     # ssw_gpu_hits_fn (include/ssw_gpu.h)
 
 
 class PoolStat(C.Structure):
@@ -109,6 +114,8 @@ def load(path=None):
     L.ssw_gpu_selftest_lanes.restype = C.c_int
     L.ssw_gpu_valu_probe.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     L.ssw_gpu_valu_probe.restype = C.c_double
+    L.ssw_gpu_search_db.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_int32, HITS_FN, C.c_void_p]
+    L.ssw_gpu_search_db.restype = C.c_int
     L.ssw_gpu_pool_open.argtypes = [C.POINTER(C.c_int), C.c_int]
     L.ssw_gpu_pool_open.restype = C.c_void_p
     L.ssw_gpu_pool_close.argtypes = [C.c_void_p]
@@ -201,6 +208,36 @@ class Context(object):
             C.CDLL(None).free(pool)
         return res, cig
 
+    def search_db(self, queries, targets, mat, n, gapO=3, gapE=1, maskLen=-1, score_size=2, chunk=0, on_chunk=None):
+        """streamed database search (ssw_gpu_search_db): on_chunk(target_first, hits[nq, target_count] of HIT_DTYPE) is called for
+        every chunk of targets while the device works on the next one (the array is only valid during the call; return a
+        non-zero int to stop).  Without on_chunk the chunks are assembled: -> hits [nq, nt]."""
+        assert HIT_DTYPE.itemsize == 16
+        mat = np.ascontiguousarray(mat, dtype=np.int8)
+        p = Params(mat.ctypes.data_as(_i8p), n, gapO, gapE, 0, 0, 0, maskLen, score_size, 0)
+        nq = queries.count
+        whole = None if on_chunk is not None else np.zeros((nq, targets.count), dtype=HIT_DTYPE)
+        err = []
+
+        def cb(_user, tfirst, tcount, ptr):
+            try:
+                buf = (C.c_char * (nq * tcount * 16)).from_address(ptr)
+                hits = np.frombuffer(buf, dtype=HIT_DTYPE).reshape(nq, tcount)
+                if on_chunk is not None:
+                    return int(on_chunk(tfirst, hits) or 0)
+                whole[:, tfirst:tfirst + tcount] = hits
+                return 0
+            except Exception as e:     # noqa: BLE001 -- an exception must not unwind through the C caller
+                err.append(e)
+                return -99
+
+        rc = self.lib.ssw_gpu_search_db(self.h, queries.h, targets.h, C.byref(p), chunk, HITS_FN(cb), None)
+        if err:
+            raise err[0]
+        if rc < 0:
+            raise RuntimeError("ssw_gpu_search_db: " + self.error())
+        return whole if on_chunk is None else rc
+
     def result_array(self, nq, nt):
         """[nq, nt] result records in page-locked host memory (freed with the context)"""
         nbytes = int(nq) * int(nt) * RESULT_DTYPE.itemsize
@@ -214,7 +251,9 @@ class Context(object):
     def timing(self):
         t = Timing()
         self.lib.ssw_gpu_last_timing(self.h, C.byref(t))
-        return {k: getattr(t, k) for k, _ in Timing._fields_}
+        d = {k: getattr(t, k) for k, _ in Timing._fields_}
+        d["fill_kernel"] = d["fill_kernel"].decode()
+        return d
 
     def selftest_lanes(self):
         out = np.zeros((16, 64), dtype=np.uint32)

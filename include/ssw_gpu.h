@@ -73,6 +73,11 @@ typedef struct {
 	double trace_ms;       /* banded traceback + CIGAR re-score */
 	int64_t n_word;        /* alignments decided under 16-bit semantics */
 	int64_t n_byte;        /* alignments decided under 8-bit semantics */
+	/* the fill kernel that evaluated most cells in the call (for roofline accounting) */
+	char fill_kernel[48];  /* e.g. "k_fill<10,f16>", "k_chainq<12,cm3> x 14 strips", "k_filldb<19>" */
+	double fill_ops_per_row; /* packed 16-bit VALU instructions per (row, column) of a query pair in that kernel: 7.5 / 8.5 / 9 */
+	int32_t fill_rows_per_lane;
+	int32_t fill_strips;
 } ssw_gpu_timing;
 
 int ssw_gpu_device_count(void);
@@ -103,6 +108,25 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* queries, const ssw
                         ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words);
 
 int ssw_gpu_last_timing(const ssw_gpu_ctx* ctx, ssw_gpu_timing* out);
+
+/*
+ * Database search with streamed results.  Every query against every target, scores and end positions only -- what the
+ * reference's loop (src/main.c:462-526) computes with flag 0 -- for sizes whose result matrix does not fit anywhere at once
+ * (BASELINE config 5: 50 000 x 10 000 = 5e8 alignments).  Targets are processed in chunks of `targets_per_chunk`; for every
+ * chunk `fn` receives the compact records hits[q * target_count + t] of targets [target_first, target_first + target_count)
+ * (valid only during the call) while the device already works on the next chunk.  fn returns 0 to go on, non-zero to stop
+ * (ssw_gpu_search_db then returns that value).  params->flag must be 0.
+ */
+typedef struct {
+	uint16_t score1;     /* as s_align */
+	uint16_t score2;
+	int32_t ref_end1;
+	int32_t read_end1;
+	int32_t ref_end2;    /* -2: the reference returns NULL for this pair (8-bit overflow with score_size 0) */
+} ssw_gpu_hit;
+typedef int (*ssw_gpu_hits_fn)(void* user, int32_t target_first, int32_t target_count, const ssw_gpu_hit* hits);
+int ssw_gpu_search_db(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* queries, const ssw_gpu_seqs* targets, const ssw_gpu_params* params,
+                      int32_t targets_per_chunk, ssw_gpu_hits_fn fn, void* user);
 
 /*
  * Threads.  A context owns one stream set and its workspaces: ONE call at a time per context (a second thread entering

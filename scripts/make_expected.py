@@ -58,6 +58,28 @@ def run_protein(R, nq, threads):
     print("config 5: %d queries x %d entries, %.1f s on %d threads, %.1f GCUPS" % (nq, len(db), secs, threads, cells / secs / 1e9), flush=True)
 
 
+def run_protein_full(R, threads, block=2048):
+    """all 50 000 x 10 000 alignments of config 5 (query block 0 of the bench = the stated size): order-independent checksums
+    per block of 2048 queries over all 10 000 entries (tests/workloads.py words_checksum)"""
+    db, qs, mat = W.protein_config(0)
+    tc, to = W.pack(db)
+    out = []
+    t0 = time.time()
+    for b0 in range(0, len(qs), block):
+        sub = qs[b0:b0 + block]
+        qc, qo = W.pack(sub)
+        res = np.zeros((len(sub), len(db), 5), dtype=np.int32)
+        R.refwrap_bench_db(_ptr(qc, i8p), _ptr(qo, i64p), len(sub), _ptr(tc, i8p), _ptr(to, i64p), len(db), _ptr(mat, i8p), 24, 3, 1, -1, threads,
+                           _ptr(res, i32p))
+        assert (res != -9).all()
+        w0, w1 = W.hit_words(res[..., 0], res[..., 1], res[..., 2], res[..., 3], res[..., 4])
+        out.append(W.words_checksum(w0, w1))
+        print("config 5 full: queries %d..%d done, %.0f s" % (b0, b0 + len(sub) - 1, time.time() - t0), flush=True)
+        np.savez_compressed(os.path.join(OUT, "config5_full_block0.npz"), block=np.int64(block), nq=np.int64(len(qs)), nt=np.int64(len(db)),
+                            done=np.int64(b0 + len(sub)), xor0=np.array([o[0] for o in out], dtype=np.uint64),
+                            xor1=np.array([o[1] for o in out], dtype=np.uint64), sums=np.array([o[2] for o in out], dtype=np.uint64))
+
+
 def main():
     args = sys.argv[1:]
     threads = max(1, (os.cpu_count() or 2) - 1)
@@ -76,6 +98,8 @@ def main():
             run_dna(R, 4, 1_500, threads)
         elif cfg == 5:
             run_protein(R, 2048, threads)
+        elif cfg == 50:
+            run_protein_full(R, threads)
     print("done in %.0f s" % (time.time() - t0))
 
 

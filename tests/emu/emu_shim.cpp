@@ -34,5 +34,6 @@ int ssw_shim_event_record(void* e, void*)
 	return 0;
 }
 int ssw_shim_stream_wait_event(void*, void*) { return 0; }
+int ssw_shim_event_sync(void*) { return 0; }
 float ssw_shim_event_elapsed_ms(void* a, void* b) { return (float)(*(double*)b - *(double*)a); }
 }

@@ -174,6 +174,6 @@ static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
    and every item's predecessor is complete when it is drawn */
 SSW_DEV int dev_ticket(int* counter) { return atomicAdd(counter, 1); }
 SSW_DEV void dev_flag_set(int* flag) { *flag = 1; }
-SSW_DEV void dev_flag_wait(int* flag) { if (*flag == 0) emu::fail("work queue: predecessor of a drawn item is not complete"); }
+SSW_DEV bool dev_flag_wait(int* flag) { return *flag != 0; }
 
 #endif /* SIMT_EMU_H */

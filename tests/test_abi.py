@@ -15,6 +15,7 @@ def declared_functions(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"static inline[^{]*\{.*?\n\}", "", src, flags=re.S)
+    src = re.sub(r"typedef[^;{]*\(\s*\*\s*\w+\s*\)[^;]*;", "", src)      # function-pointer types are not functions
     return sorted(set(re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{]*\)\s*;", src)))
 
 

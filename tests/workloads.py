@@ -103,3 +103,30 @@ def row_checksums(a):
         for k in range(a.shape[1]):
             h = (h ^ a[:, k]) * mul
     return h
+
+
+# ---- order-independent checksums over compact database-search records (ssw_gpu_hit: u16 score1, u16 score2, i32 ref_end1,
+#      i32 read_end1, i32 ref_end2 = two little-endian 64-bit words): XOR of the words and a wrap-around sum of their
+#      products with two odd constants.  Any partition of the records gives the same totals, so per-chunk values computed
+#      while results stream by can be compared with values computed elsewhere in another order.
+_K0 = np.uint64(0x9E3779B97F4A7C15)
+_K1 = np.uint64(0xC2B2AE3D27D4EB4F)
+
+
+def hit_words(score1, score2, ref_end1, read_end1, ref_end2):
+    """field arrays -> (w0, w1) uint64 arrays, the two words of each 16-byte record"""
+    u = lambda a: np.asarray(a).astype(np.int64).astype(np.uint64) & np.uint64(0xffffffff)
+    w0 = (np.asarray(score1).astype(np.uint64) & np.uint64(0xffff)) | ((np.asarray(score2).astype(np.uint64) & np.uint64(0xffff)) << np.uint64(16)) | (u(ref_end1) << np.uint64(32))
+    w1 = u(read_end1) | (u(ref_end2) << np.uint64(32))
+    return w0, w1
+
+
+def words_checksum(w0, w1):
+    """-> (xor0, xor1, sum) as Python ints"""
+    with np.errstate(over="ignore"):
+        s = (w0 * _K0 + w1 * _K1).sum(dtype=np.uint64)
+    return int(np.bitwise_xor.reduce(w0.ravel())), int(np.bitwise_xor.reduce(w1.ravel())), int(s)
+
+
+def combine_checksums(a, b):
+    return a[0] ^ b[0], a[1] ^ b[1], (a[2] + b[2]) & 0xffffffffffffffff
