@@ -104,7 +104,7 @@ def parse_args(argv=None):
     ap.add_argument("--indel", type=float, default=None, help="insertion rate = deletion rate of the synthetic reads")
     ap.add_argument("--mask-len", type=int, default=None, help="maskLen (-1: readLen/2 per read, like the reference CLI)")
     ap.add_argument("--db-targets", type=int, default=None, help="config 5: DB entries (default 10000)")
-    ap.add_argument("--db-chunk", type=int, default=512, help="config 5: targets per streamed chunk")
+    ap.add_argument("--db-chunk", type=int, default=2048, help="config 5: targets per streamed chunk")
     ap.add_argument("--pool", type=int, default=0,
                     help="> 0: drive the batch through the library's per-GPU work queues (ssw_gpu_pool) with this many workers "
                          "spread over the visible devices, reads on the host (single process)")
@@ -178,6 +178,7 @@ def bench_dna(args, world, rank, local_rank, dist):
         if a is not None:
             p[k] = a
     is_preset = not args.custom and all(p[k] == preset[k] for k in ("read_len", "ref_len", "sub", "indel", "mask_len"))
+    fixture_ok = is_preset and p["reads"] == preset["reads"]      # (the generator's stream depends on the read count: the fixtures cover the preset batch only)
     mat = dna_matrix(args.match, args.mismatch)
     ref = random_ref(p["ref_len"], p["seed_ref"], 4)
     reads = W.make_reads_fast(ref, p["reads"], p["read_len"], seed=p["seed_reads"] + rank, sub=p["sub"], ins=p["indel"], dele=p["indel"])
@@ -296,7 +297,7 @@ def bench_dna(args, world, rank, local_rank, dist):
             from sswutil import ref_lib, oracle_align, _ptr, i8p, i32p, i64p
             fix = os.path.join(FULL, "config%d_block0.npz" % args.config)
             default_scoring = (args.match, args.mismatch, args.gap_open, args.gap_extend) == (2, 2, 3, 1)
-            if is_preset and default_scoring and os.path.exists(fix):
+            if fixture_ok and default_scoring and os.path.exists(fix):
                 z = np.load(fix)
                 k = min(nreads, len(z["fields"]))
                 g = res[:k, 0]
@@ -383,7 +384,7 @@ def bench_db(args, world, rank, local_rank, dist):
     nq = args.reads if args.reads is not None else 50_000
     nt = args.db_targets if args.db_targets is not None else 10_000
     db, qs, mat = W.protein_config(rank, queries=nq, db_entries=nt)
-    is_preset = nt == 10_000 and (nq == 50_000 or nq <= 50_000)     # a prefix of query block 0 is still covered by the fixtures
+    is_preset = nt == 10_000 and nq == 50_000       # (the generators' streams depend on the counts: the fixtures cover the stated size only)
     Q = ctx.upload(qs); T = ctx.upload(db)
     keep = min(nq, 2048)                         # rows kept for the per-query parity check
     blk = 2048
@@ -394,7 +395,13 @@ def bench_db(args, world, rank, local_rank, dist):
         state["kept"] = np.zeros((keep, nt), dtype=ssw_amd.HIT_DTYPE)
         state["sums"] = [(0, 0, 0)] * nblk
 
-    def on_chunk(tfirst, hits):
+    def on_chunk_timed(tfirst, hits):
+        # the records are on the host (page-locked buffer of the library) when this is called: the timed steps only keep the rows
+        # of the first queries; folding all 5e8 records into checksums is verification work and runs in one extra, untimed step
+        state["kept"][:, tfirst:tfirst + hits.shape[1]] = hits[:keep]
+        return 0
+
+    def on_chunk_verify(tfirst, hits):
         state["kept"][:, tfirst:tfirst + hits.shape[1]] = hits[:keep]
         w = np.ascontiguousarray(hits).view("<u8").reshape(hits.shape[0], hits.shape[1], 2)
         for b in range(nblk):
@@ -402,9 +409,9 @@ def bench_db(args, world, rank, local_rank, dist):
             state["sums"][b] = W.combine_checksums(state["sums"][b], W.words_checksum(sl[..., 0], sl[..., 1]))
         return 0
 
-    def step():
+    def step(cb=on_chunk_timed):
         fresh()
-        ctx.search_db(Q, T, mat, 24, args.gap_open, args.gap_extend, -1, 2, args.db_chunk, on_chunk)
+        ctx.search_db(Q, T, mat, 24, args.gap_open, args.gap_extend, -1, 2, args.db_chunk, cb)
 
     for _ in range(args.warmup):
         step()
@@ -422,6 +429,8 @@ def bench_db(args, world, rank, local_rank, dist):
     tm = ctx.timing()
     cells = float(tm["cells"])
     out = None
+    if rank == 0 and world == 1:
+        step(on_chunk_verify)          # untimed: the same search once more, every record folded into the parity checksums
     if rank == 0:
         qsum = float(sum(len(x) for x in qs)); tsum = float(sum(len(x) for x in db))
         out = {"metric": "GCUPS", "value": round(cells * args.steps * world / dt / 1e9, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
@@ -441,7 +450,7 @@ def bench_db(args, world, rank, local_rank, dist):
         achieved = aln_per_launch * bytes_per_aln / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         tr = measured_traffic("config5") if is_preset else None
         traffic = round(tr["hbm_bytes_per_alignment"] * aln_per_launch / (launch_ms * 1e-3) / 1e9, 2) if tr and launch_ms > 0 else None
-        out["roofline"] = {"bound": "hbm", "kernel": tm["fill_kernel"] + " (largest of %d size-class launches)" % (launches // max(1, args.steps)),
+        out["roofline"] = {"bound": "hbm", "kernel": tm["fill_kernel"] + " (largest size class; a launch = all size classes of one chunk of DB entries, side by side on 4 streams)",
                            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                            "launch_ms": round(launch_ms, 3), "launches": int(launches), "algorithmic_bytes_per_alignment": round(bytes_per_aln, 1),
                            "note": "integer max-plus recurrence: HBM is not the binding resource, see roofline_valu"}
@@ -471,7 +480,7 @@ def bench_db(args, world, rank, local_rank, dist):
             fixf = os.path.join(FULL, "config5_full_block0.npz")
             if is_preset and os.path.exists(fixf):
                 z = np.load(fixf)
-                nb = min(nblk, int(z["done"]) // int(z["block"])) if nq == 50_000 else min(nq // blk, int(z["done"]) // int(z["block"]))
+                nb = min(nblk, int(z["done"]) // int(z["block"]))
                 if nb > 0:
                     wrong = sum(1 for b in range(nb) if state["sums"][b] != (int(z["xor0"][b]), int(z["xor1"][b]), int(z["sums"][b])))
                     par["full_size"] = {"alignments": nb * blk * nt, "query_blocks_checked": nb, "query_blocks_with_wrong_checksum": wrong,

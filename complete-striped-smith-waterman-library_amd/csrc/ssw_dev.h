@@ -102,6 +102,7 @@ typedef struct {
 	int32_t maskLen, bias, score_size;
 	ssw_dres* res;           /* [query][res_nt] (NULL when `out` is used) */
 	struct ssw_out_rec* out; /* optional: final ssw_gpu_result-layout records [query][res_nt], downloaded as they are */
+	int32_t chain_best;      /* 1: lanes learn the chain's best every 16 steps (fewer best-cell records); 0: lane-local records only (experiments) */
 	struct ssw_hit_rec* hits;/* optional (takes precedence): compact 16-byte records [query][res_nt] of the streaming search */
 	int32_t* counters;       /* optional: [0] alignments decided under 16-bit rules, [1] under 8-bit rules */
 } ssw_filldb_args;
@@ -235,6 +236,7 @@ typedef struct {
 	int32_t* resume;         /* k_trace_wave: 8 ints per QUERY {band, best, best_i, best_j, stage}; zeroed before round 0 */
 	int32_t lds_bytes;       /* k_trace_wave: dynamic LDS per workgroup; bands that fit keep their rows on chip */
 	int32_t waves;           /* k_trace_wave: wavefronts working on one alignment (1, 4 or 16): wide bands need the lanes */
+	int32_t unblocked;       /* k_trace_wave teams: 1 = one cell per thread and two barriers per 64 x waves cells (the first form; experiments / tests) */
 } ssw_trace_args;
 
 /* device-side mark_mismatch: M -> '=' / 'X' runs, soft clips, edit distance */

@@ -32,6 +32,7 @@ struct _profile {
 typedef struct { void* p; size_t cap; } dbuf;
 
 #define SSW_TSTREAMS 6
+#define DB_STREAMS 4                   /* side streams the size classes of a database-search chunk are spread over */
 
 struct ssw_gpu_ctx {
 	int device;
@@ -43,7 +44,7 @@ struct ssw_gpu_ctx {
 	ssw_gpu_timing tm;
 	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, cigar2, need, goff, gpool, bnd, tlist, cand, tresume, queue, cands, sg16, sg8;
 	void** ev; int nev, capev;          /* event pairs around fill launches */
-	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d;
+	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d, *ev_db;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
 	int busy;                           /* a batch call is running on this context (one call at a time per context) */
 	const int32_t* queue_err;           /* device error word of the last work-queue launch, not yet checked */
@@ -59,6 +60,13 @@ struct ssw_gpu_seqs {
 };
 
 static __thread char g_open_err[512];   /* error of the last failed ssw_gpu_open of this thread */
+
+#include <time.h>
+static double dbg_ms(void)      /* wall clock for the SSW_GPU_DEBUG progress lines */
+{
+	struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+	return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
 
 static int fail(ssw_gpu_ctx* c, const char* fmt, const char* detail)
 {
@@ -99,8 +107,8 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
 	for (int i = 0; i < SSW_TSTREAMS; ++i) { c->tstream[i] = ssw_shim_stream_create(); c->tev[i] = ssw_shim_event_create(); ok = ok && c->tstream[i] && c->tev[i]; }
 	for (int i = 0; i < 2; ++i) { c->ev_fill[i] = ssw_shim_event_create(); c->ev_red[i] = ssw_shim_event_create(); ok = ok && c->ev_fill[i] && c->ev_red[i]; }
 	c->ev_t0 = ssw_shim_event_create(); c->ev_a = ssw_shim_event_create(); c->ev_b = ssw_shim_event_create();
-	c->ev_c = ssw_shim_event_create(); c->ev_d = ssw_shim_event_create();
-	if (!ok || !c->ev_t0 || !c->ev_a || !c->ev_b || !c->ev_c || !c->ev_d) {
+	c->ev_c = ssw_shim_event_create(); c->ev_d = ssw_shim_event_create(); c->ev_db = ssw_shim_event_create();
+	if (!ok || !c->ev_t0 || !c->ev_a || !c->ev_b || !c->ev_c || !c->ev_d || !c->ev_db) {
 		fail(0, "stream/event creation failed: %s", ssw_shim_last_error());
 		ssw_gpu_close(c);      /* destroys whatever was created (NULL handles are skipped) */
 		return 0;
@@ -121,7 +129,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
 	free(c->ev);
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
-	ssw_shim_event_destroy(c->ev_c); ssw_shim_event_destroy(c->ev_d);
+	ssw_shim_event_destroy(c->ev_c); ssw_shim_event_destroy(c->ev_d); ssw_shim_event_destroy(c->ev_db);
 	for (int i = 0; i < 2; ++i) { ssw_shim_event_destroy(c->ev_fill[i]); ssw_shim_event_destroy(c->ev_red[i]); }
 	ssw_shim_stream_destroy(c->stream2);
 	for (int i = 0; i < SSW_TSTREAMS; ++i) { ssw_shim_stream_destroy(c->tstream[i]); ssw_shim_event_destroy(c->tev[i]); }
@@ -430,37 +438,76 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		}
 		int32_t* d_tl = d_tl_all + t0;
 		if (ssw_shim_h2d(d_tl, tl, sizeof(int32_t) * (size_t)nz, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
-		for (int b = 0; b < nb + nmid && nz > 0; ++b) {
-			bucket midb;
-			const bucket* B = b < nb ? &bk[b] : &midb;
-			const ssw_pair* bpairs = d_pairs;
-			if (b >= nb) { midb = mid[b - nb]; bpairs = d_midpairs; }
-			if (B->use_x) continue;     /* long queries go through the per-target strip path (or the size classes below) */
-			int64_t per = (int64_t)(c->cm_budget / 2) / (8 * stride * (int64_t)B->npairs);   /* targets per launch */
-			per = per / 16 * 16; if (per < 16) per = 16;
-			int64_t cap = per < nz ? per : nz;
-			uint32_t* d_cm16 = (uint32_t*)ensure(c, &c->cm16, (size_t)(4 * stride * cap * B->npairs));
-			uint32_t* d_cm8 = (uint32_t*)ensure(c, &c->cm8, (size_t)(4 * stride * cap * B->npairs));
-			if (!d_cm16 || !d_cm8) goto done;
-			for (int32_t k0 = 0; k0 < nz; k0 += (int32_t)per) {
-				ssw_filldb_args fa;
-				fa.tcodes = T->d_codes; fa.toff = T->d_off; fa.tlist = d_tl + k0; fa.ntl = nz - k0 < per ? nz - k0 : (int32_t)per;
-				fa.tfirst = tfirst + t0; fa.res_nt = nt; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off; fa.pairs = bpairs + B->first_pair;
-				fa.npairs = B->npairs; fa.mat = d_mat; fa.n = n; fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.cm16 = d_cm16; fa.cm8 = d_cm8;
-				fa.cm_stride = stride; fa.maskLen = prm->maskLen; fa.bias = bias; fa.score_size = prm->score_size; fa.res = d_res; fa.out = d_out; fa.counters = d_cnt;
-				fa.hits = d_hits;
-				void* e0 = next_event(c); void* e1 = next_event(c);
-				ssw_shim_event_record(e0, c->stream);
-				if (ssw_shim_launch_filldb(B->R, &fa, c->stream)) { fail(c, "filldb launch failed: %s", ssw_shim_last_error()); goto done; }
-				ssw_shim_event_record(e1, c->stream);
-				c->tm.fill_launches++;
-				int64_t lc = 0;
-				for (int32_t k = 0; k < fa.ntl; ++k)
-					lc += (T->h_off[tl[k0 + k] + 1] - T->h_off[tl[k0 + k]]) * (int64_t)B->P16 * 2 * B->npairs;
-				c->tm.fill_cells += lc;
-				db_cells[b] += lc;
+		/* The size classes of a chunk are independent launches (different query pairs, the same targets): they go round-robin
+		   to DB_STREAMS side streams, largest first, so that the tail of one class and the under-filled launches of the rare
+		   classes overlap with other classes' work (measured: 23 classes x 4 chunks one after the other cost 25 % more than the
+		   same work in 23 launches).  Every stream has its own slice of the column-maximum scratch. */
+		void* e0 = next_event(c); void* e1 = next_event(c);
+		ssw_shim_event_record(e0, c->stream);
+		if (nz > 0) {
+			int ord[64], nord = 0, used[DB_STREAMS];
+			for (int b = 0; b < nb + nmid && nord < 64; ++b) { const bucket* B = b < nb ? &bk[b] : &mid[b - nb]; if (!B->use_x) ord[nord++] = b; }
+			for (int i = 1; i < nord; ++i) {     /* by cells, descending */
+				const int v = ord[i]; int j = i;
+				const bucket* Bv = v < nb ? &bk[v] : &mid[v - nb];
+				while (j > 0) {
+					const bucket* Bj = ord[j - 1] < nb ? &bk[ord[j - 1]] : &mid[ord[j - 1] - nb];
+					if ((int64_t)Bj->npairs * Bj->P16 >= (int64_t)Bv->npairs * Bv->P16) break;
+					ord[j] = ord[j - 1]; --j;
+				}
+				ord[j] = v;
 			}
+			const int64_t slice = (int64_t)(c->cm_budget / 2) / (2 * DB_STREAMS) / 16 * 16;      /* bytes of one stream's cm16 (and cm8) slice */
+			int64_t need = 0;
+			for (int i = 0; i < nord; ++i) {
+				const bucket* B = ord[i] < nb ? &bk[ord[i]] : &mid[ord[i] - nb];
+				const int64_t w = 4 * stride * (int64_t)nz * B->npairs;
+				if (w > need) need = w;
+			}
+			if (need > slice) need = slice;
+			for (int i = 0; i < nord; ++i) {     /* ... but never less than one workgroup's 16 targets of the largest class */
+				const bucket* B = ord[i] < nb ? &bk[ord[i]] : &mid[ord[i] - nb];
+				if (need < 4 * stride * 16 * (int64_t)B->npairs) need = 4 * stride * 16 * (int64_t)B->npairs;
+			}
+			uint32_t* d_cm16_all = (uint32_t*)ensure(c, &c->cm16, (size_t)(need * DB_STREAMS));
+			uint32_t* d_cm8_all = (uint32_t*)ensure(c, &c->cm8, (size_t)(need * DB_STREAMS));
+			if (!d_cm16_all || !d_cm8_all) goto done;
+			if (ssw_shim_event_record(c->ev_db, c->stream)) { fail(c, "event record failed: %s", ssw_shim_last_error()); goto done; }
+			for (int sx = 0; sx < DB_STREAMS; ++sx) used[sx] = 0;
+			for (int i = 0; i < nord; ++i) {
+				const int b = ord[i], sx = i % DB_STREAMS;
+				const bucket* B = b < nb ? &bk[b] : &mid[b - nb];
+				const ssw_pair* bpairs = b < nb ? d_pairs : d_midpairs;
+				void* st = c->tstream[sx];
+				if (!used[sx]) { used[sx] = 1; if (ssw_shim_stream_wait_event(st, c->ev_db)) { fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; } }
+				int64_t per = need / (4 * stride * (int64_t)B->npairs);   /* targets per launch: what one slice holds */
+				per = per / 16 * 16; if (per < 16) per = 16;
+				if ((int64_t)4 * stride * per * B->npairs > need) { fail(c, "database search: %s", "a size class does not fit the column-maximum budget (SSW_GPU_CM_BUDGET_MB)"); goto done; }
+				uint32_t* d_cm16 = d_cm16_all + (need / 4) * sx;
+				uint32_t* d_cm8 = d_cm8_all + (need / 4) * sx;
+				for (int32_t k0 = 0; k0 < nz; k0 += (int32_t)per) {
+					ssw_filldb_args fa;
+					fa.tcodes = T->d_codes; fa.toff = T->d_off; fa.tlist = d_tl + k0; fa.ntl = nz - k0 < per ? nz - k0 : (int32_t)per;
+					fa.tfirst = tfirst + t0; fa.res_nt = nt; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off; fa.pairs = bpairs + B->first_pair;
+					fa.npairs = B->npairs; fa.mat = d_mat; fa.n = n; fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.cm16 = d_cm16; fa.cm8 = d_cm8;
+					fa.cm_stride = stride; fa.maskLen = prm->maskLen; fa.bias = bias; fa.score_size = prm->score_size; fa.res = d_res; fa.out = d_out; fa.counters = d_cnt;
+					fa.hits = d_hits;
+					{ const char* e = getenv("SSW_GPU_DB_CHAIN_BEST"); fa.chain_best = !(e && e[0] == '0'); }
+					if (ssw_shim_launch_filldb(B->R, &fa, st)) { fail(c, "filldb launch failed: %s", ssw_shim_last_error()); goto done; }
+					int64_t lc = 0;
+					for (int32_t k = 0; k < fa.ntl; ++k)
+						lc += (T->h_off[tl[k0 + k] + 1] - T->h_off[tl[k0 + k]]) * (int64_t)B->P16 * 2 * B->npairs;
+					c->tm.fill_cells += lc;
+					if (b < 64) db_cells[b] += lc;
+				}
+			}
+			for (int sx = 0; sx < DB_STREAMS; ++sx)
+				if (used[sx] && (ssw_shim_event_record(c->tev[sx], c->tstream[sx]) || ssw_shim_stream_wait_event(c->stream, c->tev[sx]))) {
+					fail(c, "stream join failed: %s", ssw_shim_last_error()); goto done;
+				}
 		}
+		ssw_shim_event_record(e1, c->stream);
+		c->tm.fill_launches++;      /* one launch group: all size classes of this chunk of targets */
 		if (ds) {   /* download of this chunk on the second stream; meanwhile hand the previous chunk to the caller */
 			if (ssw_shim_event_record(c->ev_fill[buf], c->stream) || ssw_shim_stream_wait_event(c->stream2, c->ev_fill[buf]) ||
 			    ssw_shim_d2h(ds->h_hits[buf], d_hits, sizeof(struct ssw_hit_rec) * (size_t)nq * (size_t)nt, c->stream2) ||
@@ -929,6 +976,8 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 			const int trace_no_lds = tl_ && tl_[0] == '0';     /* experiment / test: band rows in HBM scratch instead of LDS */
 			const char* tv_ = getenv("SSW_GPU_TRACE_WAVES");
 			const int trace_waves_env = tv_ && (atoi(tv_) == 1 || atoi(tv_) == 4 || atoi(tv_) == 16) ? atoi(tv_) : 0;   /* experiment / test */
+			const char* tb_ = getenv("SSW_GPU_TRACE_BLOCKED");
+			const int trace_unblocked = tb_ && tb_[0] == '0';      /* experiment / test: teams with one cell per thread */
 			/* round 0: every alignment with a small scratch (band <= 16).  Alignments whose band had to grow report what
 			   they needed; later rounds run them in classes of similar need (x4 per class) with 4x headroom. */
 			tpend* pend = (tpend*)malloc(sizeof(tpend) * (size_t)nq);     /* key = band that did not fit, need in 4-KiB units, q = query */
@@ -956,7 +1005,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
 						ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = sstride; ta.soff = 0;
 						ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;     /* CIGAR slots are indexed by query */
-						ta.resume = d_resume; ta.waves = 1; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)ssw_shim_trace_lds_need(16, 1);
+						ta.resume = d_resume; ta.unblocked = trace_unblocked; ta.waves = 1; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)ssw_shim_trace_lds_need(16, 1);
 						if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
 						    (use_wave ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
 						    ssw_shim_d2h(hneed, d_need, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
@@ -967,8 +1016,8 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 								if (hneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
 								nextp[nnext].key = use_wave ? hband[k] : hneed[k]; nextp[nnext].need = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
 							}
-						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round 0: %d alignments, scratch %lld B each, %d pending so far\n",
-						                                     cnt_l, (long long)sstride, nnext);
+						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] %.1f ms: trace round 0: %d alignments, scratch %lld B each, %d pending so far\n",
+						                                     dbg_ms(), cnt_l, (long long)sstride, nnext);
 					}
 				} else {
 					/* every pending alignment gets a multiple of what it last needed (one or two more band doublings).  The
@@ -1026,7 +1075,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 							ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr + grp[gi].base; ta.scratch_stride = 0;
 							ta.soff = d_soff + grp[gi].soff0;
 							ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need + 2 * (int64_t)grp[gi].g0;
-							ta.resume = d_resume; ta.waves = grp[gi].waves; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)grp[gi].lds;
+							ta.resume = d_resume; ta.unblocked = trace_unblocked; ta.waves = grp[gi].waves; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)grp[gi].lds;
 							if (st != c->stream) ssw_shim_stream_wait_event(st, c->ev_fill[0]);
 							if (use_wave ? ssw_shim_launch_trace_wave(&ta, st) : ssw_shim_launch_trace(&ta, st)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
 							if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, LDS %lld B x %d waves per alignment, scratch at %lld\n",
@@ -1046,8 +1095,8 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 									nextp[nnext].key = use_wave ? gband[k] : gneed[k]; nextp[nnext].need = gneed[k]; nextp[nnext].q = lst[grp[gi].g0 + k]; ++nnext;
 								}
 						}
-						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d launches side by side, %lld B of scratch, %d pending so far\n",
-						                                     round, ngrp, (long long)batch_total, nnext);
+						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] %.1f ms: trace round %d: %d launches side by side, %lld B of scratch, %d pending so far\n",
+						                                     dbg_ms(), round, ngrp, (long long)batch_total, nnext);
 						b0 = g0;
 					}
 					free(hoff); free(hall);
@@ -1150,9 +1199,9 @@ int ssw_gpu_search_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs*
 	const int32_t nq = Q->count, nt_all = T->count;
 	int rc = 0;
 	if (nq > 0 && nt_all > 0) {
-		int64_t chunk = targets_per_chunk > 0 ? targets_per_chunk : 512;
-		/* two device + two page-locked host buffers of nq x chunk compact records: keep each below 1 GiB */
-		while (chunk > 16 && (int64_t)nq * chunk * (int64_t)sizeof(ssw_gpu_hit) > ((int64_t)1 << 30)) chunk /= 2;
+		int64_t chunk = targets_per_chunk > 0 ? targets_per_chunk : 2048;
+		/* two device + two page-locked host buffers of nq x chunk compact records: keep each below 2 GiB */
+		while (chunk > 16 && (int64_t)nq * chunk * (int64_t)sizeof(ssw_gpu_hit) > ((int64_t)2 << 30)) chunk /= 2;
 		if (chunk > nt_all) chunk = nt_all;
 		const size_t bytes = sizeof(ssw_gpu_hit) * (size_t)nq * (size_t)chunk;
 		db_stream ds; memset(&ds, 0, sizeof ds);

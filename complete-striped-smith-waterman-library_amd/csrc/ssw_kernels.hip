@@ -415,9 +415,11 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 		{   /* once per 16 steps the lanes of a chain learn the chain's best so far: a lane's own creeping maximum below it is no
 		       candidate for the best cell, so it need not be recorded (>= the chain's best still is: the first column wins ties,
 		       and lanes higher up are ahead in columns) -- records per target drop from ~100 to the handful of true improvements */
-			u32 g = best;
-			g = pk_max(g, xl_row_ror<1>(g)); g = pk_max(g, xl_row_ror<2>(g)); g = pk_max(g, xl_row_ror<4>(g)); g = pk_max(g, xl_row_ror<8>(g));
-			best = pk_max(best, pk_subu(g, 0x00010001u));
+			if (a.chain_best) {
+				u32 g = best;
+				g = pk_max(g, xl_row_ror<1>(g)); g = pk_max(g, xl_row_ror<2>(g)); g = pk_max(g, xl_row_ror<4>(g)); g = pk_max(g, xl_row_ror<8>(g));
+				best = pk_max(best, pk_subu(g, 0x00010001u));
+			}
 		}
 		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
 		const u32 ob16 = out16 + 4u * (u32)((s0 - 16) & 63), ob8 = out8 + 4u * (u32)((s0 - 16) & 63);
@@ -1819,7 +1821,8 @@ SSW_HD u32 trace_ring_size(int band_width, int nthreads) { u32 r = 256; while (r
 SSW_HD int64_t trace_lds_need(int band_width, int nthreads)
 {
 	const int64_t rowbytes = (((int64_t)(band_width * 2 + 3) + 1) * 4 + 15) & ~(int64_t)15;
-	return TRACE_LDS_FIXED + 3 * rowbytes + (int64_t)trace_ring_size(band_width, nthreads);
+	/* teams (several wavefronts per alignment) also keep one (h, F) slot per thread: trace_band_blocked */
+	return TRACE_LDS_FIXED + (nthreads > 64 ? 8192 : 0) + 3 * rowbytes + (int64_t)trace_ring_size(band_width, nthreads);
 }
 
 /* row storage: LDS offsets (L) or the scratch arrays in HBM */
@@ -1984,6 +1987,163 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 	if (lb > tb.best) { tb.best = lb; tb.i = li; tb.j = lj; }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * trace_band_blocked: the same band fill for teams (NW > 1, rows in LDS), TWO workgroup barriers per row instead of two per
+ * 64*NW cells.  Every thread owns CPT consecutive cells of the row: it evaluates E / diagonal / A for them, scans its own
+ * cells serially, the threads' totals are scanned across the team (decay CPT*m per thread: DPP inside a wavefront, wave totals
+ * through LDS -- barrier 1), then every thread finishes its cells (F, H, directions) and writes the row; the direction of F
+ * in a thread's first cell needs h and F of the cell to its left, which the neighbour leaves in an LDS slot (barrier 2).
+ * The rows of H ping-pong between two buffers (no copy), and what the reference forces at a row's start (h_b[edge] = 0,
+ * e_b[edge] = -inf, src/ssw.c:636-639) is applied by whoever writes that index at the end of the row before.  Values,
+ * directions and the row-major strict-> best cell are the scalar walk's: the long rows of wide bands (thousands of cells x 10^4
+ * rows per alignment) were bound by barrier latency, not by arithmetic.
+ * ------------------------------------------------------------------------------------------------ */
+#define TRACE_CPT_MAX 12
+#define TX_SLOT 1536u      /* blocked form: per-thread (h, F) of its last cell: 1024 threads x 8 bytes, placed after the fixed area */
+#define TRACE_LDS_FIXED_BLOCKED (TX_SLOT + 8192u)
+
+template <int NW>
+SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, const int8_t* ref, const int8_t* read, int refLen, int readLen,
+                                int gapO, int gapE, int band_width, int n, int8_t* dir, u32 oring, u32 ring_mask, TraceBest& tb, int tid)
+{
+	constexpr int NT = 64 * NW;
+	const int NEG = -1073741824;
+	const int m = gapO < gapE ? gapO : gapE;
+	const int lane = tid & 63, wv = tid >> 6;
+	const int width = band_width * 2 + 3, width_d = band_width * 2 + 1;
+	const int cpt = (width_d + NT - 1) / NT;          /* cells per thread (<= TRACE_CPT_MAX, checked by the caller) */
+	const int D = cpt * m;                            /* decay of the scan from one thread's last cell to the next one's */
+	for (int j = tid; j < width; j += NT) { lds_st32(lds, oh0 + 4u * (u32)j, 0u); lds_st32(lds, oh1 + 4u * (u32)j, 0u); lds_st32(lds, oeb + 4u * (u32)j, (u32)NEG); }
+	int staged = 0;
+	int lb = tb.best, li = 0, lj = 0;
+	__syncthreads();
+	int rd = read[0];
+	for (int i = 0; i < readLen; ++i) {
+		const int rdn = i + 1 < readLen ? read[i + 1] : 0;
+		const int xi = i - band_width > 0 ? i - band_width : 0;
+		const int xp = i - 1 - band_width > 0 ? i - 1 - band_width : 0;
+		const int sft = xi - xp;
+		const int beg = xi;
+		const int end = i + band_width < refLen - 1 ? i + band_width : refLen - 1;
+		const int ncell = end - beg + 1;
+		const int endn = i + 1 + band_width < refLen - 1 ? i + 1 + band_width : refLen - 1;      /* the next row's forced index */
+		const int edgen = endn + 1 < width - 1 ? endn + 1 : width - 1;
+		const u32 hp = (i & 1) ? oh0 : oh1, hcur = (i & 1) ? oh1 : oh0;      /* previous row's H, this row's H */
+		int8_t* line = dir + (int64_t)width_d * i;
+		if ((i & 63) == 0) {   /* target window: everything the next 64 rows can touch */
+			int64_t hi = (int64_t)i + band_width + 65; if (hi > refLen) hi = refLen;
+			for (int j = staged + tid; j < (int)hi; j += NT) lds_st8(lds, oring + ((u32)j & ring_mask), (u32)(unsigned char)ref[j]);
+			if ((int)hi > staged) staged = (int)hi;
+			__syncthreads();
+		}
+		/* ---- this thread's cells: u0 .. u0 + cnt - 1 */
+		const int u0 = tid * cpt + 1;
+		const int cnt = u0 > ncell ? 0 : (ncell - u0 + 1 < cpt ? ncell - u0 + 1 : cpt);
+		int e[TRACE_CPT_MAX], dia[TRACE_CPT_MAX], sl[TRACE_CPT_MAX];
+		u32 deb = 0;                                   /* bit k: E of cell k was opened (direction 3) */
+		int run = NEG;
+#pragma unroll
+		for (int k = 0; k < TRACE_CPT_MAX; ++k) {
+			e[k] = NEG; dia[k] = NEG; sl[k] = NEG;
+			if (k < cnt) {
+				const int u = u0 + k, up = u + sft, j = beg + u - 1;
+				const int open = i == 0 ? -gapO : (int)lds_ld32(lds, hp + 4u * (u32)up) - gapO;
+				const int ext = i == 0 ? NEG : (int)lds_ld32(lds, oeb + 4u * (u32)up) - gapE;
+				e[k] = open > ext ? open : ext;
+				if (open > ext) deb |= 1u << k;
+				const int sc = lds_ld8s(lds, (u32)((int)lds_ld8s(lds, oring + ((u32)j & ring_mask)) * n + rd));
+				dia[k] = (int)lds_ld32(lds, hp + 4u * (u32)(up - 1)) + sc;
+				int A = e[k] > dia[k] ? e[k] : dia[k]; if (A < 0) A = 0;
+				run = run - m > A ? run - m : A;         /* inclusive max-plus scan inside the thread */
+				sl[k] = run;
+			}
+		}
+		/* ---- scan of the threads' totals: V = S at the thread's last cell (threads without cells carry -inf: nothing follows them) */
+		int V = cnt == cpt ? run : (cnt > 0 ? run - (cpt - cnt) * m : NEG);      /* (a partial last thread: value as if decayed to a full block's end) */
+		{
+			int o;
+			o = (int)xl_row_shr_keep<1>((u32)NEG, (u32)V) - D; V = o > V ? o : V;
+			o = (int)xl_row_shr_keep<2>((u32)NEG, (u32)V) - 2 * D; V = o > V ? o : V;
+			o = (int)xl_row_shr_keep<4>((u32)NEG, (u32)V) - 4 * D; V = o > V ? o : V;
+			o = (int)xl_row_shr_keep<8>((u32)NEG, (u32)V) - 8 * D; V = o > V ? o : V;
+			o = (int)xl_row_bcast15_keep((u32)NEG, (u32)V) - ((lane & 15) + 1) * D; V = o > V ? o : V;
+			o = (int)xl_row_bcast31_keep((u32)NEG, (u32)V) - ((lane & 31) + 1) * D; V = o > V ? o : V;
+		}
+		if (lane == 63) lds_st32(lds, TX_T + 4u * (u32)wv, (u32)V);
+		__syncthreads();                                /* barrier 1: wave totals; every phase-1 read of the previous row is done */
+		int Pw = wv == 0 ? 0 : NEG;                   /* S at the cell before this wavefront's first one; cell 0 of the row holds h_c[0] = 0 */
+		{
+			int t = lane < NW ? (int)lds_ld32(lds, TX_T + 4u * (u32)lane) : NEG, o;
+			if (lane == 0) { const int z = 0 - 64 * D; t = z > t ? z : t; }      /* the row's cell 0 decayed to the end of wavefront 0 */
+			o = (int)xl_row_shr_keep<1>((u32)NEG, (u32)t) - 64 * D; t = o > t ? o : t;
+			o = (int)xl_row_shr_keep<2>((u32)NEG, (u32)t) - 128 * D; t = o > t ? o : t;
+			if (NW > 4) {
+				o = (int)xl_row_shr_keep<4>((u32)NEG, (u32)t) - 256 * D; t = o > t ? o : t;
+				o = (int)xl_row_shr_keep<8>((u32)NEG, (u32)t) - 512 * D; t = o > t ? o : t;
+			}
+			if (wv > 0) Pw = (int)xl_readlane((u32)t, wv - 1);
+		}
+		{ const int sp = Pw - (lane + 1) * D; V = sp > V ? sp : V; }
+		const int P = (int)xl_wave_shr1_keep((u32)Pw, (u32)V);      /* S at the cell before this thread's first one */
+		/* ---- finish the cells */
+		int hl = 0, Fl = NEG;                          /* h and F of the cell to the left (cell 0: h_c[0] = 0, no F); a thread's first cell learns them after barrier 2 */
+		int h_first = 0, F_first = NEG; u32 byte_first = 0;
+		int Sprev = P;
+#pragma unroll
+		for (int k = 0; k < TRACE_CPT_MAX; ++k) {
+			if (k < cnt) {
+				const int u = u0 + k, j = beg + u - 1;
+				const int F = Sprev - gapO;
+				const int sfin = P - (k + 1) * m > sl[k] ? P - (k + 1) * m : sl[k];
+				Sprev = sfin;
+				const int e1 = e[k] > 0 ? e[k] : 0, f1 = F > 0 ? F : 0;
+				const int gap = e1 > f1 ? e1 : f1;
+				const int h = gap > dia[k] ? gap : dia[k];
+				const int de3 = (int)((deb >> k) & 1u);
+				if (k == 0) { h_first = h; F_first = F; byte_first = (u32)de3 | (gap <= dia[k] ? 4u : (e1 > f1 ? (u32)((2 + de3) << 2) : 0x80u)); }     /* 0x80: H's source is F, direction known after barrier 2 */
+				else {
+					const int df5 = (hl - gapO) > (Fl - gapE) ? 1 : 0;
+					const int dh = gap <= dia[k] ? 1 : (e1 > f1 ? 2 + de3 : 4 + df5);
+					line[u - 1] = (int8_t)(de3 | (df5 << 1) | (dh << 2));
+				}
+				/* the row as the next one will read it: its forced index holds 0 / -inf whatever was computed there */
+				lds_st32(lds, oeb + 4u * (u32)u, (u32)(u == edgen ? NEG : e[k]));
+				lds_st32(lds, hcur + 4u * (u32)u, (u32)(u == edgen ? 0 : h));
+				if (h > lb) { lb = h; li = i; lj = j; }
+				hl = h; Fl = F;
+			}
+		}
+		if (cnt > 0) { lds_st32(lds, TX_SLOT + 8u * (u32)tid, (u32)hl); lds_st32(lds, TX_SLOT + 8u * (u32)tid + 4, (u32)Fl); }
+		if (tid == 0 && edgen > ncell) { lds_st32(lds, oeb + 4u * (u32)edgen, (u32)NEG); lds_st32(lds, hcur + 4u * (u32)edgen, 0u); }
+		__syncthreads();                                /* barrier 2: the row is written; neighbours' last cells are in the slots */
+		if (cnt > 0) {
+			int hleft = 0, Fleft = NEG;
+			if (tid > 0) { hleft = (int)lds_ld32(lds, TX_SLOT + 8u * (u32)(tid - 1)); Fleft = (int)lds_ld32(lds, TX_SLOT + 8u * (u32)(tid - 1) + 4); }
+			const int df5 = (hleft - gapO) > (Fleft - gapE) ? 1 : 0;
+			const u32 b = (byte_first & 0x80u) ? ((byte_first & 1u) | ((u32)(4 + df5) << 2)) : byte_first;
+			line[u0 - 1] = (int8_t)(b | ((u32)df5 << 1));
+		}
+		(void)h_first; (void)F_first;
+		rd = rdn;
+	}
+	/* the scalar walk's best cell: highest h above the carried best; among equals the first in row-major order */
+	if (lb <= tb.best) { lb = NEG; li = 0x7fffffff; lj = 0x7fffffff; }
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) {
+		const int oh = wave_bcast(lb, lane ^ d), oi = wave_bcast(li, lane ^ d), oj = wave_bcast(lj, lane ^ d);
+		if (oh > lb || (oh == lb && (oi < li || (oi == li && oj < lj)))) { lb = oh; li = oi; lj = oj; }
+	}
+	__syncthreads();
+	if (lane == 0) { lds_st32(lds, TX_BEST + 12u * (u32)wv, (u32)lb); lds_st32(lds, TX_BEST + 12u * (u32)wv + 4, (u32)li); lds_st32(lds, TX_BEST + 12u * (u32)wv + 8, (u32)lj); }
+	__syncthreads();
+	for (int v = 0; v < NW; ++v) {
+		const int oh = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v), oi = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v + 4), oj = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v + 8);
+		if (oh > lb || (oh == lb && (oi < li || (oi == li && oj < lj)))) { lb = oh; li = oi; lj = oj; }
+	}
+	__syncthreads();
+	if (lb > tb.best) { tb.best = lb; tb.i = li; tb.j = lj; }
+}
+
 /* value of thread 0 in every thread of the team */
 template <int NW> SSW_DEV int team_bcast0(unsigned char* lds, int v, int tid)
 {
@@ -2000,7 +2160,7 @@ template <int NW> SSW_DEV int team_bcast0(unsigned char* lds, int v, int tid)
 template <int NW>
 SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int readLen, int score, int gapO, int gapE,
                        int* band_io, TraceBest& tb, const int8_t* mat, int n, unsigned char* scratch, int64_t cap,
-                       unsigned char* lds, int64_t lds_cap, u32* cig, int cigcap, int64_t* need, int tid)
+                       unsigned char* lds, int64_t lds_cap, u32* cig, int cigcap, int64_t* need, int tid, bool trace_unblocked)
 {
 	const int len = refLen > readLen ? refLen : readLen;
 	int band_width = *band_io, width_d;
@@ -2011,6 +2171,10 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 		const int64_t want = 3 * rowbytes + (int64_t)width_d * readLen + 16;
 		if (want > cap) { *need = want; *band_io = band_width; return -2; }
 		dir = (int8_t*)(scratch + 3 * rowbytes);
+		if (NW > 1 && trace_lds_need(band_width, 64 * NW) <= lds_cap && (width_d + 64 * NW - 1) / (64 * NW) <= TRACE_CPT_MAX && !trace_unblocked) {
+			const u32 oh0 = TRACE_LDS_FIXED_BLOCKED, oh1 = oh0 + (u32)rowbytes, oeb = oh1 + (u32)rowbytes, oring = oeb + (u32)rowbytes;
+			trace_band_blocked<NW>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, trace_ring_size(band_width, 64 * NW) - 1, tb, tid);
+		} else
 		if (trace_lds_need(band_width, 64 * NW) <= lds_cap) {
 			TraceRows<true> R; R.lds = lds; R.ohb = TRACE_LDS_FIXED; R.oeb = TRACE_LDS_FIXED + (u32)rowbytes; R.ohc = TRACE_LDS_FIXED + 2 * (u32)rowbytes;
 			R.hb = R.eb = R.hc = 0;
@@ -2091,7 +2255,7 @@ __global__ void __launch_bounds__(64 * NW) k_trace_wave(ssw_trace_args a)
 		int64_t need = 0;
 		int bio = band;
 		nops = trace_team<NW>(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, &bio, tb, a.mat, a.n, scratch, scap,
-		                      lds, lds_cap, cig, (int)a.cigar_stride, &need, tid);
+		                      lds, lds_cap, cig, (int)a.cigar_stride, &need, tid, a.unblocked != 0);
 		if (nops == -2) {
 			const int64_t need0 = ((int64_t)team_bcast0<NW>(lds, (int)(need >> 32), tid) << 32) | (u32)team_bcast0<NW>(lds, (int)(need & 0xffffffff), tid);
 			if (tid == 0) {

@@ -65,7 +65,7 @@ typedef struct {
 typedef struct {
 	double total_ms;       /* first launch .. results on host */
 	double fill_ms;        /* sum over forward-fill kernel launches */
-	int64_t fill_launches;
+	int64_t fill_launches; /* (database search: launch groups -- all size classes of one chunk of targets, side by side on several streams) */
 	int64_t fill_cells;    /* DP cells actually evaluated by the fill kernel (padding + halo included) */
 	int64_t cells;         /* sum of readLen*refLen over the batch (the GCUPS numerator) */
 	double reduce_ms;      /* score1/score2/end-position reduction */

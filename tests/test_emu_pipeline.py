@@ -330,3 +330,31 @@ def test_wide_alphabets_route_window_passes_by_lds_need(ectx, n):
     reads, ref, mat = wide_alphabet_case(n)
     for flag in (0, 2):
         _run(ectx, reads, [ref], mat, n, 9, 2, flag=flag)
+
+
+def team_traceback_cases(scale):
+    """alignments whose band rows hold many cells per thread of a traceback team (trace_band_blocked): long insertions (band =
+    |ref span - read span| + 1 from the start), deletions that make the band double, an unrelated read, a read ending at the last
+    target base, and a short target that the band covers entirely (the reference's forced index then hits a real cell)"""
+    rng = np.random.default_rng(7)
+    ref = random_ref(5000 * scale, 31, 4)
+    k = scale
+    reads = [np.concatenate([ref[100 * k:700 * k], ref[1900 * k:2500 * k]]),
+             np.concatenate([ref[3000 * k:3400 * k], rng.integers(0, 4, size=700 * k, dtype=np.int8), ref[3400 * k:3800 * k]]),
+             np.concatenate([ref[200 * k:500 * k], ref[900 * k:1200 * k], ref[1700 * k:2000 * k]]),
+             rng.integers(0, 4, size=900 * k, dtype=np.int8),
+             ref[4000 * k:5000 * k].copy()]
+    short = ref[:700 * k].copy()
+    reads2 = [np.concatenate([short[10 * k:200 * k], short[450 * k:690 * k]]),
+              np.concatenate([short[300 * k:400 * k], rng.integers(0, 4, size=300 * k, dtype=np.int8), short[400 * k:650 * k]]), short[5:695 * k].copy()]
+    c = lambda xs: [np.ascontiguousarray(r, dtype=np.int8) for r in xs]
+    return (c(reads), ref), (c(reads2), short)
+
+
+@pytest.mark.parametrize("teams,blocked", [("4", "1"), ("16", "1"), ("4", "0")])
+def test_team_traceback_many_cells_per_thread(ectx, teams, blocked, monkeypatch):
+    monkeypatch.setenv("SSW_GPU_TRACE_WAVE", "1")
+    monkeypatch.setenv("SSW_GPU_TRACE_WAVES", teams)
+    monkeypatch.setenv("SSW_GPU_TRACE_BLOCKED", blocked)
+    for reads, ref in team_traceback_cases(1):
+        _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)

@@ -367,3 +367,14 @@ def test_wide_alphabets_route_window_passes_by_lds_need(gpu_ctx, n):
     reads, ref, mat = wide_alphabet_case(n, seed=10, nreads=60, reflen=5000)
     for flag in (0, 2):
         _run(gpu_ctx, reads, [ref], mat, n, 9, 2, flag=flag)
+
+
+@pytest.mark.parametrize("env", [{}, {"SSW_GPU_TRACE_WAVES": "4"}, {"SSW_GPU_TRACE_BLOCKED": "0"}])
+def test_team_traceback_many_cells_per_thread(gpu_ctx, env, monkeypatch):
+    """wide bands on traceback teams: several cells per thread, two barriers per row (trace_band_blocked) -- 10-kb-scale reads with
+    kilobase insertions / deletions, an unrelated read, band covering the whole target; and the one-cell-per-thread form as control"""
+    from test_emu_pipeline import team_traceback_cases
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for reads, ref in team_traceback_cases(4):
+        _run(gpu_ctx, reads, [ref], dna_matrix(2, 2), 5, flag=2)

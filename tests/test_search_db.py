@@ -39,7 +39,7 @@ def _case(ctx, qs, db, mat, n, gapO, gapE, chunks, check_ref=True):
                 seen.append((tfirst, h.shape[1])); got[:, tfirst:tfirst + h.shape[1]] = h; return 0
             assert ctx.search_db(Q, T, mat, n, gapO, gapE, -1, 2, chunk, on_chunk) == 0
             _same(got, res)
-            step = chunk if chunk > 0 else 512
+            step = chunk if chunk > 0 else 2048
             assert seen == [(t0, min(step, len(db) - t0)) for t0 in range(0, len(db), step)]
         return res
     finally:
