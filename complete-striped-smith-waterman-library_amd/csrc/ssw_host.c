@@ -364,30 +364,28 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 	int32_t* tl_all = (int32_t*)malloc(sizeof(int32_t) * (size_t)tcount);
 	ssw_dres* hres = 0;
 	if (!tk || !tl_all) { free(tk); free(tl_all); return fail(c, "out of host memory%s", ""); }
-	/* queries of 385..640 residues: size classes R' in {28, 32, 36, 40} (k_filldb<R', masked>), paired by length */
-	bucket mid[4]; int nmid = 0;
+	/* queries of 385..640 residues: still one strip of the fused kernel, classes R = ceil(len / 16) = 25..40 like the short ones
+	   (the profile offsets of the target ring are 16-bit: alphabets whose null column would lie beyond 64 KiB keep these queries on
+	   the per-target path) */
+	bucket mid[16]; int nmid = 0;
 	ssw_pair* midpairs = 0; const ssw_pair* d_midpairs = 0;
 	{
 		int32_t nm = 0;
-		for (int32_t q = 0; q < nq; ++q) { const int64_t L = Q->h_off[q + 1] - Q->h_off[q]; if (L > 16 * SSW_RMAX && L <= 640) ++nm; }
+		for (int32_t q = 0; q < nq; ++q) if (qdone[q]) { const int64_t L = Q->h_off[q + 1] - Q->h_off[q]; if (L > 16 * SSW_RMAX && L <= 640) ++nm; }
 		if (nm > 0) {
 			keyed* mk = (keyed*)malloc(sizeof(keyed) * (size_t)nm);
 			midpairs = (ssw_pair*)malloc(sizeof(ssw_pair) * (size_t)nm);
 			if (!mk || !midpairs) { free(mk); free(midpairs); free(tk); free(tl_all); return fail(c, "out of host memory%s", ""); }
 			int32_t k = 0, np = 0;
-			for (int32_t q = 0; q < nq; ++q) { const int64_t L = Q->h_off[q + 1] - Q->h_off[q]; if (L > 16 * SSW_RMAX && L <= 640) { mk[k].key = (int32_t)L; mk[k].q = q; ++k; } }
+			for (int32_t q = 0; q < nq; ++q) if (qdone[q]) { const int64_t L = Q->h_off[q + 1] - Q->h_off[q]; if (L > 16 * SSW_RMAX && L <= 640) { mk[k].key = (int32_t)L; mk[k].q = q; ++k; } }
 			qsort(mk, (size_t)nm, sizeof(keyed), keyed_cmp);
-			for (int cls = 28; cls <= 40; cls += 4) {
+			for (int cls = SSW_RMAX + 1; cls <= 40; ++cls) {
 				bucket b; b.R = cls; b.strips = 1; b.P16 = 16 * cls; b.lanes = 16; b.use_x = 0; b.first_pair = np; b.first_q = 0; b.nq = 0;
-				int32_t i = 0;
-				while (i < nm) {                   /* queries whose ceil(len/16) falls into (cls-4, cls] */
-					const int r = (mk[i].key + 15) / 16;
-					if (r > cls - 4 && r <= cls) {
-						midpairs[np].qa = mk[i].q; midpairs[np].qb = -1; ++b.nq;
-						if (i + 1 < nm && (mk[i + 1].key + 15) / 16 <= cls) { midpairs[np].qb = mk[i + 1].q; ++b.nq; ++i; }
-						++np;
-					}
-					++i;
+				for (int32_t i = 0; i < nm; ++i) {      /* sorted by length: the queries of a class are contiguous; neighbours share a chain */
+					if ((mk[i].key + 15) / 16 != cls) continue;
+					midpairs[np].qa = mk[i].q; midpairs[np].qb = -1; ++b.nq;
+					if (i + 1 < nm && (mk[i + 1].key + 15) / 16 == cls) { midpairs[np].qb = mk[i + 1].q; ++b.nq; ++i; }
+					++np;
 				}
 				b.npairs = np - b.first_pair;
 				if (b.npairs > 0) mid[nmid++] = b;
@@ -561,8 +559,8 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		for (int b = 0; b < nb + nmid && b < 64; ++b) {
 			const bucket* B = b < nb ? &bk[b] : &mid[b - nb];
 			char nm[48];
-			snprintf(nm, sizeof nm, b < nb ? "k_filldb<%d>" : "k_filldb<%d,masked>", B->R);
-			note_fill_kernel(c, db_cells[b], &bestc, nm, b < nb ? 8.5 : 11.0, B->R, 1);
+			snprintf(nm, sizeof nm, "k_filldb<%d>", B->R);
+			note_fill_kernel(c, db_cells[b], &bestc, nm, 8.5, B->R, 1);
 		}
 	}
 	if (ds && prev_t0 >= 0) {     /* the last chunk */
@@ -655,9 +653,15 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 	/* long queries: the wavefront is one chain of 64 lanes; rows per lane bounded so that one profile stays near 24 KiB
 	   of LDS (several waves per CU).  SSW_GPU_XLANES=16 / SSW_GPU_XR=<rows per lane> override (experiments). */
 	int32_t xlanes = 64, xrmax = 4 * (24 / (n + 1) < 1 ? 1 : 24 / (n + 1) > 3 ? 3 : 24 / (n + 1));
+	/* measured on 10-kb DNA reads (profiles/round2_sweep_d_config4_xr*.json): fill 1620 / 1575 / 1586 / 1658 ms at 12 / 10 / 8 / 16
+	   rows per lane (10 and 12 share an LDS footprint, 10 pads fewer rows); the window passes, which carry two target rings and
+	   more registers, are fastest at 8 (245 vs 265 ms) */
+	if (xrmax == 12) xrmax = 10;
+	int32_t xrcap = 8;
 	{
 		const char* e = getenv("SSW_GPU_XLANES"); if (e && atoi(e) == 16) xlanes = 16;
-		e = getenv("SSW_GPU_XR"); if (e && atoi(e) >= 1 && atoi(e) <= 16) xrmax = atoi(e);
+		e = getenv("SSW_GPU_XR"); if (e && atoi(e) >= 1 && atoi(e) <= 16) { xrmax = atoi(e); xrcap = xrmax; }
+		e = getenv("SSW_GPU_XR_WINDOW"); if (e && atoi(e) >= 1 && atoi(e) <= 16) xrcap = atoi(e);
 		/* the target rings hold profile offsets as 16-bit values: residue n (the null column) x ceil(R/4) KiB must stay below 64 KiB */
 		while (xlanes == 64 && xrmax > 4 && (int64_t)n * ((xrmax + 3) / 4) * 1024 > 65535) xrmax -= 4;
 	}
@@ -714,14 +718,15 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 
 	{   /* database search: scores only, several short targets -> fused kernel for the short-query buckets */
 		int any_short = 0, any_long = 0; int64_t maxt = 0;
-		for (int b = 0; b < nb; ++b) { if (bk[b].use_x && bk[b].P16 > 640) any_long = 1; else any_short = 1; }
+		for (int b = 0; b < nb; ++b) { if (bk[b].use_x && (bk[b].P16 > 640 || (int64_t)n * 10 * 256 > 65535)) any_long = 1; else any_short = 1; }
 		for (int32_t ti = 0; ti < tcount; ++ti) { int64_t L = T->h_off[tfirst + ti + 1] - T->h_off[tfirst + ti]; if (L > maxt) maxt = L; }
 		const char* dis = getenv("SSW_GPU_NO_DB");
 		/* (k_filldb takes the column maximum of two rows with a 16-bit float max3, valid below 31744: 640 rows x max(mat) <= 49) */
 		const int db_ok = !literal && prm->flag == 0 && any_short && maxt <= 65536 && maxmat <= 49 && !(dis && dis[0] == '1');
 		if (ds && (!db_ok || any_long)) { rc = SSW_NOT_STREAMABLE; goto done; }
 		if (db_ok && (tcount >= 4 || ds)) {
-			for (int b = 0; b < nb; ++b) if (!bk[b].use_x || bk[b].P16 <= 640) for (int32_t k = 0; k < bk[b].nq; ++k) qdone[order[bk[b].first_q + k]] = 1;
+			const int mid_ok = (int64_t)n * 10 * 256 <= 65535;     /* 40 rows per lane: 10 chunks of 256 bytes per residue; n x that must stay a 16-bit offset */
+			for (int b = 0; b < nb; ++b) if (!bk[b].use_x || (bk[b].P16 <= 640 && mid_ok)) for (int32_t k = 0; k < bk[b].nq; ++k) qdone[order[bk[b].first_q + k]] = 1;
 			for (int32_t q = 0; q < nq; ++q) if (Q->h_off[q + 1] == Q->h_off[q]) qdone[q] = 1;     /* empty queries: empty records, written there */
 			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone, ds)) goto done;
 			d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq);   /* align_db may have regrown the record buffer */
@@ -913,7 +918,9 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 					/* short-query buckets whose four per-chain profiles would not fit the LDS of a workgroup (alphabets near 32
 					   symbols with many rows per lane) take the strip kernel's window mode: one profile per wavefront */
 					const int cap_x = B->use_x || ssw_shim_capture_lds_need(B->R, n) > SSW_LDS_LIMIT;
-					const int32_t capR = B->use_x ? B->R : ((B->P16 + 63) / 64 < xrmax ? (B->P16 + 63) / 64 : xrmax), capL = B->use_x ? B->lanes : xlanes;
+					const int32_t capRmax = xrcap < xrmax ? xrcap : xrmax;
+					const int32_t capR = B->use_x ? (B->lanes == 64 && B->R > capRmax ? capRmax : B->R) : ((B->P16 + 63) / 64 < capRmax ? (B->P16 + 63) / 64 : capRmax),
+					              capL = B->use_x ? B->lanes : xlanes;
 					if (cap_x) {
 						const int32_t hw = halo_for(B->P16, maxmat, prm->gapE);
 						const int64_t wcols = (((int64_t)(hw < refLen ? hw : refLen) + 1) + 31) / 16 * 16;

@@ -153,27 +153,6 @@ SSW_DEV void chain_rows(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f
 	}
 }
 
-/* same, for chains whose 16R rows exceed the padded query: the 16-bit-rule maximum (rows < P8) is a second, masked chain */
-template <int R>
-SSW_DEV void chain_rows_masked(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f, u32& cm, u32& cm8, const u32 (&m8)[R],
-                               u32 gapO2, u32 gapE2)
-{
-#pragma unroll
-	for (int r = 0; r < R; ++r) {
-		const u32 hold = H[r];
-		const u32 s = sc[r >> 2][r & 3];
-		const u32 h0 = pk_max(pk_adds(d, s), E[r]);
-		const u32 h = pk_max(h0, f);
-		const u32 t0 = pk_subu(h0, gapO2);
-		E[r] = pk_max(pk_subu(E[r], gapE2), t0);
-		f = pk_max(pk_subu(f, gapE2), t0);
-		cm = pk_max(cm, h);
-		cm8 = pk_max(cm8, h & m8[r]);
-		H[r] = h;
-		d = hold;
-	}
-}
-
 /* the 16 lanes of a chain write the finished maxima of traversal columns [base, base + 16) (both padding rules) and the
    maximum over the group: a 4-step row_ror butterfly on the packed values (all 16 lanes end up with it, lane 0 stores it) */
 template <int R, bool F16>
@@ -318,7 +297,7 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
  * own column maxima afterwards: score1 / ref_end1 / read_end1 / score2 / ref_end2 come out of ONE launch.
  * grid = npairs * ceil(ntl / 16) workgroups of 256 threads.
  * ================================================================================================ */
-template <int R, bool MASKED>
+template <int R>
 __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 {
 	typedef ChainGeom<R> G;
@@ -333,19 +312,8 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 	const ssw_pair pr = a.pairs[pair];
 	const int lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
 	const int lenb = pr.qb >= 0 ? (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]) : 0;
-	/* MASKED: 16R rows may exceed the padded queries (R is a size class, not ceil(len/16)): dead rows + masked 16-bit maximum */
-	const int p16a = MASKED ? (lena + 15) & ~15 : 0x7fffffff, p16b = MASKED ? (lenb + 15) & ~15 : 0x7fffffff;
 	build_profile<R>(lds, 0, tid, 256, a.mat, a.n, a.qcodes + a.qoff[pr.qa], lena, 0,
-	                 pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0, lenb, p16a, p16b);
-	u32 m8[MASKED ? R : 1];
-	if (MASKED) {
-		const int p8a = (lena + 7) & ~7, p8b = (lenb + 7) & ~7;
-#pragma unroll
-		for (int k = 0; k < (MASKED ? R : 1); ++k) {
-			const int row = l16 * R + k;
-			m8[k] = (row < p8a ? 0xffffu : 0u) | (row < p8b ? 0xffff0000u : 0u);
-		}
-	} else m8[0] = 0;
+	                 pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0, lenb);
 
 	const int slot = tchunk * 16 + grp;
 	const bool active = slot < a.ntl;
@@ -388,9 +356,9 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 	/* The wavefront pays for every record any of its 4 chains x 2 queries sets (unrelated proteins: ~100 per target), so a
 	   record only copies the query's half of the lane's column (R/2 byte permutes instead of 2R compare/select); measured on the config-5 shape the row
 	   search at every record cost 24 % of the kernel. */
-	u32 snap[2][MASKED ? 1 : (R + 1) / 2];
+	u32 snap[2][(R + 1) / 2];
 #pragma unroll
-	for (int k = 0; k < (MASKED ? 1 : (R + 1) / 2); ++k) { snap[0][k] = 0; snap[1][k] = 0; }
+	for (int k = 0; k < (R + 1) / 2; ++k) { snap[0][k] = 0; snap[1][k] = 0; }
 	const u32 lane_prof = (u32)l16 * 16u;
 
 	for (int s0 = 0; s0 < nsteps; s0 += 16) {
@@ -408,7 +376,7 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			const int tc = s0 - 32 + l16;
 			if (tc < ncols) {
 				o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
-				o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (MASKED ? 0 : 15 - G::TAP)) & 63));
+				o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
 			}
 		}
 		wave_lds_fence();
@@ -433,18 +401,17 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			const u32 hin = xl_row_shr1_zero(Hlast);
 			u32 f = xl_row_shr1_zero(Fout);
 			const u32 x = xl_row_ror<1>(cmout);
-			const u32 x8 = MASKED ? xl_row_ror<1>(ck) : xl_row_ror<16 - G::TAP>(ck);   /* MASKED: ck carries the masked chain */
-			u32 cm = x, cm8 = x8;        /* this column's maxima of the rows above (lane 0 starts a new column) */
+			const u32 x8 = xl_row_ror<16 - G::TAP>(ck);
+			u32 cm = x;                  /* this column's maximum of the rows above (lane 0 starts a new column) */
 			if (l16 == 0) {
 				lds_st32(lds, ob16 + 4u * j, x);
 				lds_st32(lds, ob8 + 4u * j, x8);
-				cm = 0; cm8 = 0;
+				cm = 0;
 			}
 			/* best cell: `pre` = the lane's running record and the rows above in this column; only the lane whose OWN rows
 			   beat it -- the lane holding the new record cell, not every lane below -- takes the branch further down */
 			const u32 pre = pk_max(best, cm);
-			if (MASKED) { chain_rows_masked<R>(sc, H, E, hsave, f, cm, cm8, (const u32(&)[R])m8, a.gapO2, a.gapE2); ck = cm8; }
-			else chain_rows<R, true, false, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);   /* the host keeps max(mat) x 640 below 31744 on this path */
+			chain_rows<R, true, false, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);   /* the host keeps max(mat) x 640 below 31744 on this path */
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
 			best = pk_max(best, cm);     /* = max(pre, own rows) */
 			const bool hit = best != pre;   /* (columns outside the target score "dead": H = max(E, F) there, which decays and never sets a record) */
@@ -455,16 +422,11 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 						const int nv = (int)((best >> (16 * h)) & 0xffffu), ov = (int)((pre >> (16 * h)) & 0xffffu);
 						if (nv > ov) {
 							bval[h] = nv; btc[h] = tc;
-							if (MASKED) {     /* size classes of 28..40 rows per lane: no registers to spare, search now */
-								brow[h] = 0x7fffffff;
+							/* keep this query's half of the column (two rows per register); the row is looked up once, after the last column */
 #pragma unroll
-								for (int k = R - 1; k >= 0; --k) if ((int)((H[k] >> (16 * h)) & 0xffffu) == nv) brow[h] = l16 * R + k;
-							} else {          /* keep this query's half of the column (two rows per register); the row is looked up once, after the last column */
-#pragma unroll
-								for (int k = 0; k < R; k += 2) {
-									const u32 lo = H[k], hi = k + 1 < R ? H[k + 1] : 0u;
-									snap[h][k >> 1] = pk_perm(hi, lo, h ? PK_HI2 : PK_LO2);
-								}
+							for (int k = 0; k < R; k += 2) {
+								const u32 lo = H[k], hi = k + 1 < R ? H[k + 1] : 0u;
+								snap[h][k >> 1] = pk_perm(hi, lo, h ? PK_HI2 : PK_LO2);
 							}
 						}
 					}
@@ -477,18 +439,16 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 		const int tc = base + l16;
 		if (tc >= 0 && tc < ncols) {
 			o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
-			o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (MASKED ? 0 : 15 - G::TAP)) & 63));
+			o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
 		}
 	}
 	dev_fence();   /* the chain re-reads its own column maxima below */
-	if (!MASKED) {
 #pragma unroll
-		for (int h = 0; h < 2; ++h) {
-			brow[h] = 0x7fffffff;
-			if (bval[h] > 0) {
+	for (int h = 0; h < 2; ++h) {
+		brow[h] = 0x7fffffff;
+		if (bval[h] > 0) {
 #pragma unroll
-				for (int k = R - 1; k >= 0; --k) if ((int)((snap[h][MASKED ? 0 : k >> 1] >> (16 * (k & 1))) & 0xffffu) == bval[h]) brow[h] = l16 * R + k;
-			}
+			for (int k = R - 1; k >= 0; --k) if ((int)((snap[h][k >> 1] >> (16 * (k & 1))) & 0xffffu) == bval[h]) brow[h] = l16 * R + k;
 		}
 	}
 
@@ -2490,6 +2450,10 @@ extern "C" int ssw_shim_fill_resident_blocks(int R, int n)
 #endif
 }
 
+/* rows per lane of the fused database-search kernel: 1..24 (queries up to 384 residues, shared with k_fill) and 25..40
+   (385..640 residues: still one strip, exact ceil(len / 16) like the short classes) */
+#define FOR_EACH_DBR_LONG(X) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40)
+
 extern "C" int ssw_shim_launch_filldb(int R, const ssw_filldb_args* a, void* stream)
 {
 	ssw_filldb_args args = *a;
@@ -2497,14 +2461,10 @@ extern "C" int ssw_shim_launch_filldb(int R, const ssw_filldb_args* a, void* str
 	if (grid <= 0) return 0;
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
-		SSW_LAUNCH((k_filldb<r, false>), ssw_filldb_args, args, grid, 256, ldsb, stream); } break;
+		SSW_LAUNCH((k_filldb<r>), ssw_filldb_args, args, grid, 256, ldsb, stream); } break;
 		FOR_EACH_R(X)
+		FOR_EACH_DBR_LONG(X)
 #undef X
-	/* size classes for queries of 385..640 residues: rows beyond the padded query are dead, 16-bit maxima masked */
-#define XM(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
-		SSW_LAUNCH((k_filldb<r, true>), ssw_filldb_args, args, grid, 256, ldsb, stream); } break;
-		XM(28) XM(32) XM(36) XM(40)
-#undef XM
 		default: return -2;
 	}
 	return SSW_LAUNCH_OK();
