@@ -48,6 +48,7 @@ struct ssw_gpu_ctx {
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
 	int busy;                           /* a batch call is running on this context (one call at a time per context) */
 	const int32_t* queue_err;           /* device error word of the last work-queue launch, not yet checked */
+	void* hits_d[2]; void* hits_h[2]; size_t hits_cap;     /* streamed database search: two device + two page-locked host buffers, kept between calls */
 };
 
 struct ssw_gpu_seqs {
@@ -124,6 +125,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	if (!c) return;
 	ssw_shim_set_device(c->device);
 	if (c->stream) ssw_shim_stream_sync(c->stream);
+	for (int i = 0; i < 2; ++i) { ssw_shim_free(c->hits_d[i]); ssw_shim_host_free(c->hits_h[i]); }
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
 	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->cigar2); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand); dbuf_free(&c->tresume); dbuf_free(&c->queue); dbuf_free(&c->cands); dbuf_free(&c->sg16); dbuf_free(&c->sg8);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
@@ -775,6 +777,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 			ssw_shim_event_record(e1, c->stream);
 			c->tm.fill_launches++;
 			for (int32_t q = 0; q < nq; ++q) c->tm.fill_cells += (Q->h_off[q + 1] - Q->h_off[q]) * (int64_t)refLen;
+			note_fill_kernel(c, c->tm.fill_cells, &best_fill_cells, "k_literal (lane model of the SSE2 kernels)", 0.0, 0, 1);
 		}
 		if (refLen > 0 && !literal) {
 			const int64_t stride = ((int64_t)refLen + 15) / 16 * 16 + 16;
@@ -787,8 +790,14 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 				int32_t tile, halo, ntiles;
 				if ((int64_t)halo_full * 8 * gran >= refLen) { ntiles = 1; tile = (refLen + 15) / 16 * 16; halo = 0; }
 				else {
-					/* enough chains to fill the device several times over, halo overhead <= 1/8 */
+					/* enough chains PER LAUNCH to fill the device several times over, halo overhead <= 1/8.  A launch covers the pairs
+					   whose column-maximum arrays fit the budget (8 bytes per column and pair): a 5 Mb target leaves 1600 pairs per
+					   launch, which with 16 tiles (one workgroup) per pair would fill little more than half of the device */
+					int64_t launch_pairs = use_x ? B->npairs : (int64_t)(c->cm_budget / (size_t)(8 * stride));
+					if (launch_pairs < 1) launch_pairs = 1;
+					if (launch_pairs > B->npairs) launch_pairs = B->npairs;
 					int64_t want = (4 * 32768 + B->npairs - 1) / B->npairs;
+					if (!use_x && launch_pairs * ((want + 15) / 16) < 6000) want = 16 * ((6000 + launch_pairs - 1) / launch_pairs);   /* >= ~2 rounds of workgroups per launch */
 					int64_t maxt = refLen / ((int64_t)halo_full * 8);
 					if (want > maxt) want = maxt;
 					want = (want + gran - 1) / gran * gran; if (want < gran) want = gran;
@@ -1213,8 +1222,14 @@ int ssw_gpu_search_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs*
 		const size_t bytes = sizeof(ssw_gpu_hit) * (size_t)nq * (size_t)chunk;
 		db_stream ds; memset(&ds, 0, sizeof ds);
 		ds.chunk = (int32_t)chunk; ds.fn = fn; ds.user = user;
-		for (int i = 0; i < 2; ++i) { ds.d_hits[i] = (struct ssw_hit_rec*)ssw_shim_malloc(bytes); ds.h_hits[i] = (ssw_gpu_hit*)ssw_shim_host_alloc(bytes); }
-		if (!ds.d_hits[0] || !ds.d_hits[1] || !ds.h_hits[0] || !ds.h_hits[1]) rc = fail(c, "search_db: buffer allocation failed: %s", ssw_shim_last_error());
+		if (c->hits_cap < bytes) {      /* (page-locking gigabytes takes of the order of a second: the buffers stay with the context) */
+			for (int i = 0; i < 2; ++i) { ssw_shim_free(c->hits_d[i]); ssw_shim_host_free(c->hits_h[i]); c->hits_d[i] = 0; c->hits_h[i] = 0; }
+			c->hits_cap = 0;
+			for (int i = 0; i < 2; ++i) { c->hits_d[i] = ssw_shim_malloc(bytes); c->hits_h[i] = ssw_shim_host_alloc(bytes); }
+			if (c->hits_d[0] && c->hits_d[1] && c->hits_h[0] && c->hits_h[1]) c->hits_cap = bytes;
+		}
+		for (int i = 0; i < 2; ++i) { ds.d_hits[i] = (struct ssw_hit_rec*)c->hits_d[i]; ds.h_hits[i] = (ssw_gpu_hit*)c->hits_h[i]; }
+		if (c->hits_cap < bytes) rc = fail(c, "search_db: buffer allocation failed: %s", ssw_shim_last_error());
 		else rc = align_batch_locked(c, Q, T, 0, nt_all, prm, 0, 0, 0, &ds);
 		if (rc == SSW_NOT_STREAMABLE) {
 			/* generic path (queries above 640 residues, matrices with entries above 49, gapO <= gapE, ...): full records per chunk,
@@ -1237,7 +1252,6 @@ int ssw_gpu_search_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs*
 		}
 		if (rc == 0 && ds.fn_rc) rc = ds.fn_rc;
 		ssw_shim_stream_sync(c->stream); ssw_shim_stream_sync(c->stream2);
-		for (int i = 0; i < 2; ++i) { ssw_shim_free(ds.d_hits[i]); ssw_shim_host_free(ds.h_hits[i]); }
 	}
 	__atomic_store_n(&c->busy, 0, __ATOMIC_RELEASE);
 	return rc;

@@ -2565,6 +2565,13 @@ extern "C" int ssw_shim_chainq_resident(int R, int capture, int n)
 		default: return 0;
 	}
 	if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+	if (per_cu <= 0) {   /* the occupancy query gave nothing (seen on this stack for these kernels): 160 KiB of LDS per CU bound the
+	                        one-wavefront workgroups, the register file (at least two wavefronts per SIMD up to 256 VGPRs) does the rest */
+		const size_t ldsb = (size_t)(n + 1) * ((size_t)((R + 3) / 4) * 1024) + (capture ? 2176 : 1856);
+		per_cu = (int)(SSW_LDS_MAX / ldsb);
+		if (per_cu > 12) per_cu = 12;
+		if (per_cu < 1) per_cu = 1;
+	}
 	cache[R][capture ? 1 : 0][n] = per_cu * cus;
 	return per_cu * cus;
 #endif

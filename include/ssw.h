@@ -72,7 +72,9 @@ typedef struct {
  *              1: 16-bit semantics only; 2: decide per alignment (8-bit rules
  *              unless the score reaches 255 - bias, exactly like the reference's
  *              byte -> word fallback).
- * The returned object is freed with init_destroy().
+ * The returned object is freed with init_destroy().  Like the reference (src/ssw.c:842-843) it BORROWS `read` and
+ * `mat`: both must stay valid until init_destroy().  readLen == 0 is legal (every alignment of it is the empty
+ * record); a negative length or missing arrays return NULL with a message.
  */
 s_profile* ssw_init(const int8_t* read, const int32_t readLen, const int8_t* mat, const int32_t n,
                     const int8_t score_size);
@@ -91,6 +93,10 @@ void init_destroy(s_profile* p);
  * Returns a calloc()ed result (free with align_destroy) or NULL with a message on stderr when
  * the reference would (8-bit overflow without 16-bit semantics enabled; unusable profile) or when
  * the GPU path cannot run (no device, unsupported parameters) -- there is no CPU fallback.
+ * Re-entrant like the reference: every calling thread has its own implicit device context (devices are handed
+ * out round-robin), so concurrent calls -- also on one shared profile -- are legal.  A call is a handful of small kernel
+ * launches (milliseconds): the same target handed in again is not re-uploaded, but throughput needs the batch ABI of
+ * ssw_gpu.h, which aligns whole read sets per call.
  */
 s_align* ssw_align(const s_profile* prof, const int8_t* ref, int32_t refLen, const uint8_t weight_gapO,
                    const uint8_t weight_gapE, const uint8_t flag, const uint16_t filters, const int32_t filterd,
