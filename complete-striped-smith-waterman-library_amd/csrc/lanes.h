@@ -21,6 +21,7 @@ typedef uint32_t u32;
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #ifdef SSW_SIMT_EMU
 #include "simt_emu.h"
@@ -57,6 +58,7 @@ SSW_DEV void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"
 
 /* LDS accessors with byte offsets into the dynamic segment */
 SSW_DEV u32x4 lds_ld128(const unsigned char* lds, u32 off) { return *(const u32x4*)(lds + off); }
+SSW_DEV u32x2 lds_ld64(const unsigned char* lds, u32 off) { return *(const u32x2*)(lds + off); }
 SSW_DEV u32 lds_ld32(const unsigned char* lds, u32 off) { return *(const u32*)(lds + off); }
 SSW_DEV u32 lds_ld16(const unsigned char* lds, u32 off) { return *(const uint16_t*)(lds + off); }
 SSW_DEV void lds_st32(unsigned char* lds, u32 off, u32 v) { *(u32*)(lds + off) = v; }

@@ -303,7 +303,6 @@ int   ssw_shim_stream_wait_event(void* stream, void* ev);   /* later work on `st
 float ssw_shim_event_elapsed_ms(void* start, void* stop);   /* both must have completed */
 
 int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream);
-int ssw_shim_fill_resident_blocks(int R, int n);
 int ssw_shim_launch_filldb(int R, const ssw_filldb_args* a, void* stream);
 int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream);
 int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* stream);

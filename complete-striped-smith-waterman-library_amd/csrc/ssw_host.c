@@ -6,10 +6,14 @@
  * the thin shim declared in ssw_dev.h.  There is no CPU implementation of the alignment in this
  * library: without a device, or for parameters the kernels do not cover, calls fail loudly.
  *
- * Batch pipeline per target (all on one HIP stream):
- *   queries bucketed by R = ceil(readLen/16) and paired  ->  k_fill<R> (column maxima of every tile)
- *   -> k_reduce (score1, ref_end1, score2, ref_end2, 8/16-bit rule)  -> [flag != 0] k_capture<R> twice
- *   (read_end1, then begin position)  -> [CIGAR wanted] k_trace  -> records + CIGAR pool to the host.
+ * Batch pipeline per target (one HIP stream; the database search and the traceback rounds fan out over side streams):
+ *   queries bucketed by chain geometry and paired
+ *     short (<= 384):  k_fill<R> (column maxima + 16-column group maxima of every tile)  ->  k_reduce_seg
+ *     long:            k_chainq<R> (row strips drawn from a work queue, best cell tracked)  ->  k_reduce
+ *     database search (flag 0, several short targets): k_filldb<R>, size classes side by side, records final
+ *   -> [flag != 0] window passes (k_capture<R> / k_chainq<R, window>): read_end1 where not tracked, then the begin position
+ *   -> [CIGAR wanted] k_trace / k_trace_wave rounds with negotiated scratch  -> [SAM] k_mark  -> records + CIGAR pool to the host.
+ * ssw_gpu_search_db streams the database search chunk by chunk; csrc/ssw_pool.c spreads batches over several devices.
  */
 #include <stdlib.h>
 #include <stdio.h>
@@ -815,9 +819,17 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 				if (dbl) chunk = (int64_t)((c->cm_budget / 2) / (size_t)per_pair);
 				if (chunk < 1) chunk = 1;
 				if (chunk > B->npairs) chunk = B->npairs;
-				if (!use_x) {   /* whole rounds of resident workgroups per launch (all workgroups of a launch take the same time) */
-					const int64_t resident = ssw_shim_fill_resident_blocks(B->R, n), bpp = (ntiles + 15) / 16;
-					if (resident > 0 && chunk < B->npairs && chunk * bpp >= resident) chunk = (chunk * bpp / resident) * resident / bpp;
+				if (!use_x && chunk < B->npairs) {
+					/* All workgroups of a launch do the same amount of work, so a launch is as slow as the CU that got one workgroup more
+					   than the others: the launches of a bucket get the same number of pairs (not full chunks and a remainder), and that
+					   number makes the workgroup count a multiple of the CU count (256 on MI355X: the one device this library is built
+					   for).  16 tiles per pair left 1600 workgroups per launch on a 5 Mb target: 6 or 7 per CU, 12 % lost. */
+					const int64_t bpp = (ntiles + 15) / 16, nl = (B->npairs + chunk - 1) / chunk;
+					int64_t even = (B->npairs + nl - 1) / nl;                      /* pairs per launch if all launches are alike */
+					const int64_t unit = 256 / (bpp > 256 ? 256 : bpp) > 0 ? 256 / (bpp > 256 ? 256 : bpp) : 1;      /* pairs that make 256 workgroups */
+					even = (even + unit - 1) / unit * unit;
+					if (even <= chunk) chunk = even;
+					else if (chunk >= unit) chunk = chunk / unit * unit;
 				}
 				uint32_t* d_bnd = 0; int32_t* d_cand = 0;
 				if (use_x) {

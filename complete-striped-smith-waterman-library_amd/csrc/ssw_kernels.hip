@@ -3,14 +3,22 @@
  * C host driver (ssw_host.c) calls.
  *
  * What is computed (reference file:line is mengyao/Complete-Striped-Smith-Waterman-Library src/ssw.c):
- *   k_fill     the DP fill of sw_sse2_byte / sw_sse2_word (197-386 / 412-588): per target column
- *              the maximum H over the (zero-padded) query, for both padding rules at once
- *   k_reduce   the bookkeeping around that fill: best score / first best column (317-340, 523-542)
- *              and the masked second-best scan (368-381 / 570-583), plus ssw_align's choice between
- *              8-bit and 16-bit rules (881-899) and its early exits (900-916)
- *   k_capture  the "where" passes: read_end1 (342-351 / 544-553) and the reverse pass that finds the
- *              begin position (ssw_align 919-935, sw_sse2_* with ref_dir = 1 and `terminate`)
- *   k_trace    banded_sw (590-783) + cigar_alignment_score (785-811) + ssw_align's band retry (941-973)
+ *   k_fill        the DP fill of sw_sse2_byte / sw_sse2_word (197-386 / 412-588) for queries up to 384 residues: per target
+ *                 column the maximum H over the (zero-padded) query, for both padding rules at once, plus the maximum of every
+ *                 group of 16 columns
+ *   k_chainq      the same fill for longer queries, cut into row strips of 64 x R rows that a persistent launch draws from a
+ *                 work queue (k_chainx: the 16-lane form, strips in sequence); its window mode does the "where" passes
+ *   k_filldb      database search: fill + best cell + reduction of one query pair against 16 short targets in one launch
+ *   k_reduce_seg  the bookkeeping around the fill: best score / first best column (317-340, 523-542) and the masked
+ *   / k_reduce    second-best scan (368-381 / 570-583), plus ssw_align's choice between 8-bit and 16-bit rules (881-899) and its
+ *                 early exits (900-916) -- over the group maxima / over the strip kernel's columns
+ *   k_capture     the "where" passes of short queries: read_end1 (342-351 / 544-553) and the reverse pass that finds the
+ *                 begin position (ssw_align 919-935, sw_sse2_* with ref_dir = 1 and `terminate`)
+ *   k_literal     both SSE2 kernels re-enacted lane for lane, for gapO <= gapE (the reference's answer depends on its layout there)
+ *   k_trace /     banded_sw (590-783) + cigar_alignment_score (785-811) + ssw_align's band retry (941-973): one thread, or a
+ *   k_trace_wave  team of 1 / 4 / 16 wavefronts per alignment
+ *   k_mark, k_prep, k_gather   mark_mismatch (1019-1074) on the device, residue translation / reverse complement (main.c:84-116),
+ *                 CIGAR pool compaction
  *
  * How (MI355X-first, not the SSE2 layout): the reference keeps one query in 16/8 SIMD lanes with a
  * striped layout and repairs the vertical (F) dependency with a lazy loop.  Here a DPP row of 16
@@ -895,6 +903,27 @@ template <int R, int GL> struct StripGeom {
 	static constexpr u32 EXTRA = 2 * RINGB + 2 * BND_RING_BYTES + (u32)GL * 12u;   /* capture: one target ring per query half */
 };
 
+/* a boundary record { H, F, column maximum, 16-bit-rule column maximum }: the fourth word only where it is used -- a register of
+   a vector load that nothing reads gets reused by hipcc at once, and overwriting it has to wait for the load to land (a full
+   LDS latency per step in a kernel that runs two wavefronts per SIMD) */
+template <bool ALL4> SSW_DEV u32x4 lds_ld_bnd(const unsigned char* lds, u32 off)
+{
+	if (ALL4) return lds_ld128(lds, off);
+	const u32x2 hf = lds_ld64(lds, off);
+	const u32x4 r = { hf[0], hf[1], lds_ld32(lds, off + 8u), 0u };
+	return r;
+}
+
+/* the packed scores of N <= 4 consecutive rows of a lane (one 16-byte profile chunk; only the rows that exist are loaded) */
+template <int N> SSW_DEV u32x4 lds_ld_rows(const unsigned char* lds, u32 off)
+{
+	if (N >= 3) return lds_ld128(lds, off);
+	u32x4 r = { 0u, 0u, 0u, 0u };
+	if (N == 2) { const u32x2 t = lds_ld64(lds, off); r[0] = t[0]; r[1] = t[1]; }
+	else r[0] = lds_ld32(lds, off);
+	return r;
+}
+
 /* profile of one strip: word = (score of query a's row, score of query b's row) against residue b; rows at or below a
    query's padded length are dead for that half */
 template <int R, int GL>
@@ -1006,7 +1035,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			for (int c = 0; c < C; ++c) sb_n[c] = lds_ld128(lds, pb0 + G::CSTRIDE * c);
 			pb_n = lds_ld16(lds, x.ringb + r0 + 2u) + lane_prof;
 		}
-		rec_n = lds_ld128(lds, x.bin);
+		rec_n = lds_ld_bnd<MASK8>(lds, x.bin);
 		pa_n = lds_ld16(lds, x.ring + r0 + 2u) + lane_prof;
 	}
 
@@ -1051,15 +1080,21 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			}
 			const u32x4 rec = rec_n;       /* what lane 0 receives from the strip above */
 			/* requests for the next steps */
+			/* (the ring entries of step s+2 are requested FIRST: asked for after the score chunks, hipcc gave them a register of the last
+			   chunk's unused rows -- R = 10 uses 10 of 12 -- and had to wait for every load in flight before it could issue them) */
+			const u32 pa_next = lds_ld16(lds, x.ring + rpo + 2u * (j + 2));
+			const u32 pb_next = CAPTURE ? lds_ld16(lds, x.ringb + rpo + 2u * (j + 2)) : 0u;
 #pragma unroll
-			for (int c = 0; c < C; ++c) sc_n[c] = lds_ld128(lds, pa_n + G::CSTRIDE * c);
+			for (int c = 0; c + 1 < C; ++c) sc_n[c] = lds_ld128(lds, pa_n + G::CSTRIDE * c);
+			sc_n[C - 1] = lds_ld_rows<R - 4 * (C - 1)>(lds, pa_n + G::CSTRIDE * (C - 1));      /* the last chunk: only the rows that exist */
 			if (CAPTURE) {
 #pragma unroll
-				for (int c = 0; c < C; ++c) sb_n[c] = lds_ld128(lds, pb_n + G::CSTRIDE * c);
-				pb_n = lds_ld16(lds, x.ringb + rpo + 2u * (j + 2)) + lane_prof;
+				for (int c = 0; c + 1 < C; ++c) sb_n[c] = lds_ld128(lds, pb_n + G::CSTRIDE * c);
+				sb_n[C - 1] = lds_ld_rows<R - 4 * (C - 1)>(lds, pb_n + G::CSTRIDE * (C - 1));
+				pb_n = pb_next + lane_prof;
 			}
-			rec_n = lds_ld128(lds, x.bin + 16u * ((s + 1) & 63));
-			pa_n = lds_ld16(lds, x.ring + rpo + 2u * (j + 2)) + lane_prof;
+			rec_n = lds_ld_bnd<MASK8>(lds, x.bin + 16u * ((s + 1) & 63));
+			pa_n = pa_next + lane_prof;
 			const u32 hin = xl_chain_shr1_keep<GL>(rec[0], st.Hlast);
 			u32 f = xl_chain_shr1_keep<GL>(rec[1], st.Fout);
 			u32 cm = xl_chain_shr1_keep<GL>(rec[2], st.cmout);
@@ -2427,27 +2462,6 @@ extern "C" int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream)
 		default: return -2;
 	}
 	return SSW_LAUNCH_OK();
-}
-
-/* workgroups of k_fill<R> that are resident on the whole device at once (0: unknown) -- lets the host size a launch as a
-   whole number of "rounds" so that no CU idles through a partial last round */
-extern "C" int ssw_shim_fill_resident_blocks(int R, int n)
-{
-#ifdef SSW_SIMT_EMU
-	(void)R; (void)n; return 0;
-#else
-	int per_cu = 0, dev = 0, cus = 0;
-	switch (R) {
-#define X(r) case r: { const size_t ldsb = (size_t)(n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
-		shim_allow_lds(k_fill<r, 0>, ldsb); \
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fill<r, 0>, 256, ldsb) != hipSuccess) per_cu = 0; } break;
-		FOR_EACH_R(X)
-#undef X
-		default: return 0;
-	}
-	if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-	return per_cu * cus;
-#endif
 }
 
 /* rows per lane of the fused database-search kernel: 1..24 (queries up to 384 residues, shared with k_fill) and 25..40

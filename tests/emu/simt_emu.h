@@ -89,6 +89,7 @@ struct emu_tid3 { unsigned x, y, z; };
 
 typedef uint32_t u32;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 SSW_DEV u32 xl_row_shr1_zero(u32 v)
 {
@@ -159,6 +160,7 @@ static inline void emu_lds_check(u32 off, u32 bytes, u32 align, const char* what
 	}
 }
 SSW_DEV u32x4 lds_ld128(const unsigned char* lds, u32 off) { emu_lds_check(off, 16, 16, "ld128"); u32x4 v; memcpy(&v, lds + off, 16); return v; }
+SSW_DEV u32x2 lds_ld64(const unsigned char* lds, u32 off) { emu_lds_check(off, 8, 8, "ld64"); u32x2 v; memcpy(&v, lds + off, 8); return v; }
 SSW_DEV u32 lds_ld32(const unsigned char* lds, u32 off) { emu_lds_check(off, 4, 4, "ld32"); u32 v; memcpy(&v, lds + off, 4); return v; }
 SSW_DEV u32 lds_ld16(const unsigned char* lds, u32 off) { emu_lds_check(off, 2, 2, "ld16"); uint16_t v; memcpy(&v, lds + off, 2); return v; }
 SSW_DEV void lds_st32(unsigned char* lds, u32 off, u32 v) { emu_lds_check(off, 4, 4, "st32"); memcpy(lds + off, &v, 4); }
