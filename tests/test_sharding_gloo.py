@@ -41,3 +41,29 @@ def test_two_rank_bench_over_gloo(emu_lib_path, tmp_path):
             g = z["res"][i, 0]
             assert all(int(g[k]) == d[k] for k in ("score1", "score2", "ref_end1", "read_end1", "ref_end2")), (rank, i)
     assert seen[0] != seen[1]                   # the ranks really worked on different shards
+
+
+def test_two_rank_database_search_over_gloo(emu_lib_path):
+    """config-5 mode under two ranks: every rank streams its own query block against the replicated DB (no collective on the
+    data path), rank 0 prints the one aggregated line"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "5", "--steps", "1", "--warmup", "0",
+           "--reads", "24", "--db-targets", "9", "--db-chunk", "4", "--cpu-sample", "0", "--lib", emu_lib_path]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SSW_BENCH_BACKEND="gloo"), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["alignments_per_step"] == 24 * 9
+    assert out["config"]["baseline_config"] == 5 and "roofline" in out and "roofline_valu" in out
+
+
+def test_pool_mode_of_bench_on_two_pretend_devices(emu_lib_path):
+    """bench.py --pool 2: the in-library per-GPU work queues drive the batch (single process, reads on the host)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--pool", "2", "--steps", "1", "--warmup", "0", "--reads", "12", "--ref-len", "2500",
+           "--read-len", "70", "--cpu-sample", "4", "--lib", emu_lib_path]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SSW_EMU_DEVICES="2"), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["config"]["pool_workers"] == 2 and [s["device"] for s in out["pool_stats"]] == [0, 1]
+    assert sum(s["queries"] for s in out["pool_stats"]) == 12 and out["parity"]["mismatching_alignments"] == 0
