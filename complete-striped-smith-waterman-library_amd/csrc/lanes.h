@@ -50,6 +50,14 @@ SSW_DEV u32 xl_shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 
 SSW_DEV bool wave_any(bool p) { return __any(p) != 0; }
 SSW_DEV bool wave_all(bool p) { return __all(p) != 0; }
 SSW_DEV unsigned long long wave_ballot(bool p) { return __ballot(p); }
+/* `v`, but not before `dep` exists: an opaque data dependency for the instruction scheduler (no instruction is emitted).  Keeps a
+   load that refills registers from being hoisted above the last use of their old contents (which doubles the registers). */
+SSW_DEV u32 after(u32 v, u32 dep) { asm("" : "+v"(v) : "v"(dep)); return v; }
+/* `v` with its origin hidden from the optimiser (no instruction): keeps a bit mask a bit mask (LLVM otherwise turns a mask built from a
+   compare back into per-half selects -- three instructions per word where v_bfi_b32 is one) */
+SSW_DEV u32 opaque(u32 v) { asm("" : "+v"(v)); return v; }
+/* nothing is scheduled across this point (keeps a compare that feeds a LATER scalar branch where it was written) */
+SSW_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 /* LDS hand-off between lanes of ONE wavefront (rings, small reductions): LDS operations of a wave execute in issue order,
    so what is needed is (a) that the compiler does not move LDS accesses across this point -- a wavefront-scope fence turned
    out NOT to stop it from hoisting a lane's loads of other lanes' slots above the stores (seen on gfx950, ROCm 7.2) -- and
@@ -102,6 +110,15 @@ SSW_DEV u32 pk_subu(u32 a, u32 b)   /* v_pk_sub_u16 clamp: unsigned saturating s
 {
 	return __builtin_bit_cast(u32, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
 }
+SSW_DEV u32 pk_minu(u32 a, u32 b)   /* v_pk_min_u16 */
+{
+	return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+SSW_DEV u32 pk_mullo(u32 a, u32 b)  /* v_pk_mul_lo_u16 */
+{
+	return __builtin_bit_cast(u32, __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b));
+}
+SSW_DEV u32 bfi32(u32 mask, u32 ins, u32 base) { return (mask & ins) | (~mask & base); }   /* v_bfi_b32 */
 SSW_DEV u32 pk_max(u32 a, u32 b)    /* v_pk_max_i16 */
 {
 	return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));

@@ -78,6 +78,8 @@ struct ssw_hit_rec {
 	int32_t ref_end1, read_end1, ref_end2;
 };
 
+#define SSW_DB_NCH 16     /* chains (targets) per workgroup of k_filldb; 32 -- twice as many share a profile -- measured 12 % slower */
+
 /*
  * database search (many short targets, scores + end positions only): one workgroup = one query pair against 16
  * targets; the chain also tracks the best cell and reduces its own column maxima, so one launch produces final records.
@@ -104,7 +106,8 @@ typedef struct {
 	struct ssw_out_rec* out; /* optional: final ssw_gpu_result-layout records [query][res_nt], downloaded as they are */
 	int32_t chain_best;      /* 1: lanes learn the chain's best every 16 steps (fewer best-cell records); 0: lane-local records only (experiments) */
 	struct ssw_hit_rec* hits;/* optional (takes precedence): compact 16-byte records [query][res_nt] of the streaming search */
-	int32_t* counters;       /* optional: [0] alignments decided under 16-bit rules, [1] under 8-bit rules */
+	int32_t* counters;       /* optional: [0] alignments decided under 16-bit rules, [1] under 8-bit rules, [2] workgroups repeated in the int16 form */
+	int32_t f16;             /* 1: f16 form first (7.5 instructions per row, exact below 2048); a workgroup whose best cell saturates repeats in int16 */
 } ssw_filldb_args;
 
 /* reduction of the column maxima into score1 / ref_end1 / score2 / ref_end2 */

@@ -53,6 +53,7 @@ struct ssw_gpu_ctx {
 	int busy;                           /* a batch call is running on this context (one call at a time per context) */
 	const int32_t* queue_err;           /* device error word of the last work-queue launch, not yet checked */
 	void* hits_d[2]; void* hits_h[2]; size_t hits_cap;     /* streamed database search: two device + two page-locked host buffers, kept between calls */
+	int db_f16_off;                                        /* > 0: the f16 form of k_filldb kept saturating on this context's data -- that many calls start in the int16 form */
 };
 
 struct ssw_gpu_seqs {
@@ -356,7 +357,12 @@ typedef struct {
 	struct ssw_hit_rec* d_hits[2];
 	ssw_gpu_hit* h_hits[2];
 	int fn_rc;                          /* non-zero: the caller's function asked to stop */
+	size_t cnt_off;                     /* byte offset in h_hits[]: snapshot of the device counters taken after the chunk */
 } db_stream;
+
+#define DB_F16_PAUSE 16                 /* database-search calls that skip the f16 form after one in which > 1/8 of the workgroups repeated */
+#define DB_COUNTERS 4                   /* [0] 16-bit-rule alignments, [1] 8-bit-rule, [2] workgroups of k_filldb that repeated in the int16 form */
+
 
 static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
                     const ssw_gpu_params* prm, ssw_gpu_result* results, const bucket* bk, int nb, const ssw_pair* d_pairs,
@@ -408,8 +414,15 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 	if (ds) tsub = ds->chunk;
 	if (tsub > tcount) tsub = tcount;
 	int32_t* d_tl_all = (int32_t*)ensure(c, &c->tlist, sizeof(int32_t) * (size_t)tcount);     /* every sub-batch has its own slice (uploads stay in flight) */
-	int32_t* d_cnt_s = ds ? (int32_t*)ensure(c, &c->need, 2 * sizeof(int32_t)) : 0;
-	if (!d_tl_all || (ds && (!d_cnt_s || ssw_shim_memset(d_cnt_s, 0, 2 * sizeof(int32_t), c->stream)))) { fail(c, "device allocation failed: %s", ssw_shim_last_error()); goto done; }
+	int32_t* d_cnt_s = ds ? (int32_t*)ensure(c, &c->need, DB_COUNTERS * sizeof(int32_t)) : 0;
+	const int nch = SSW_DB_NCH;
+	/* f16 form first, int16 repeat of the workgroups that saturate (k_filldb): off when those repeats stop being rare */
+	int use_f16 = 1, adaptive = 1;
+	if (c->db_f16_off > 0) { use_f16 = 0; c->db_f16_off--; }      /* recent calls kept saturating: int16 form for a while, then try again */
+	{ const char* e = getenv("SSW_GPU_DB_F16"); if (e && (e[0] == '0' || e[0] == '1')) { use_f16 = e[0] == '1'; adaptive = 0; } }
+	const int f16_first = use_f16;
+	int64_t wgs_f16[2] = { 0, 0 }; int32_t reruns_seen = 0;      /* per result buffer: f16 workgroups launched for the chunk it holds */
+	if (!d_tl_all || (ds && (!d_cnt_s || ssw_shim_memset(d_cnt_s, 0, DB_COUNTERS * sizeof(int32_t), c->stream)))) { fail(c, "device allocation failed: %s", ssw_shim_last_error()); goto done; }
 	int32_t prev_t0 = -1, prev_nt = 0, chunk_i = 0;
 	int64_t db_cells[64]; memset(db_cells, 0, sizeof db_cells);      /* per bucket (nb <= 24 short buckets + 4 size classes) */
 	for (int32_t t0 = 0; t0 < tcount; t0 += (int32_t)tsub, ++chunk_i) {
@@ -431,11 +444,11 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		} else
 		if (direct) {
 			d_out = (struct ssw_out_rec*)ensure(c, &c->res, sizeof(struct ssw_out_rec) * (size_t)nq * (size_t)nt);
-			d_cnt = (int32_t*)ensure(c, &c->need, 2 * sizeof(int32_t));
+			d_cnt = (int32_t*)ensure(c, &c->need, DB_COUNTERS * sizeof(int32_t));
 			if (!d_out || !d_cnt) goto done;
 			/* all-zero bytes are not a valid empty record (begins are -1): empty targets are patched on the host below */
 			if (ssw_shim_memset(d_out, 0, sizeof(struct ssw_out_rec) * (size_t)nq * (size_t)nt, c->stream) ||
-			    ssw_shim_memset(d_cnt, 0, 2 * sizeof(int32_t), c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
+			    ssw_shim_memset(d_cnt, 0, DB_COUNTERS * sizeof(int32_t), c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
 		} else {
 			d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq * (size_t)nt);
 			if (!d_res || ssw_shim_memset(d_res, 0, sizeof(ssw_dres) * (size_t)nq * (size_t)nt, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
@@ -448,6 +461,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		   same work in 23 launches).  Every stream has its own slice of the column-maximum scratch. */
 		void* e0 = next_event(c); void* e1 = next_event(c);
 		ssw_shim_event_record(e0, c->stream);
+		wgs_f16[buf] = 0;
 		if (nz > 0) {
 			int ord[64], nord = 0, used[DB_STREAMS];
 			for (int b = 0; b < nb + nmid && nord < 64; ++b) { const bucket* B = b < nb ? &bk[b] : &mid[b - nb]; if (!B->use_x) ord[nord++] = b; }
@@ -469,9 +483,9 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 				if (w > need) need = w;
 			}
 			if (need > slice) need = slice;
-			for (int i = 0; i < nord; ++i) {     /* ... but never less than one workgroup's 16 targets of the largest class */
+			for (int i = 0; i < nord; ++i) {     /* ... but never less than one workgroup's targets of the largest class */
 				const bucket* B = ord[i] < nb ? &bk[ord[i]] : &mid[ord[i] - nb];
-				if (need < 4 * stride * 16 * (int64_t)B->npairs) need = 4 * stride * 16 * (int64_t)B->npairs;
+				if (need < 4 * stride * nch * (int64_t)B->npairs) need = 4 * stride * nch * (int64_t)B->npairs;
 			}
 			uint32_t* d_cm16_all = (uint32_t*)ensure(c, &c->cm16, (size_t)(need * DB_STREAMS));
 			uint32_t* d_cm8_all = (uint32_t*)ensure(c, &c->cm8, (size_t)(need * DB_STREAMS));
@@ -485,7 +499,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 				void* st = c->tstream[sx];
 				if (!used[sx]) { used[sx] = 1; if (ssw_shim_stream_wait_event(st, c->ev_db)) { fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; } }
 				int64_t per = need / (4 * stride * (int64_t)B->npairs);   /* targets per launch: what one slice holds */
-				per = per / 16 * 16; if (per < 16) per = 16;
+				per = per / nch * nch; if (per < nch) per = nch;
 				if ((int64_t)4 * stride * per * B->npairs > need) { fail(c, "database search: %s", "a size class does not fit the column-maximum budget (SSW_GPU_CM_BUDGET_MB)"); goto done; }
 				uint32_t* d_cm16 = d_cm16_all + (need / 4) * sx;
 				uint32_t* d_cm8 = d_cm8_all + (need / 4) * sx;
@@ -495,7 +509,8 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 					fa.tfirst = tfirst + t0; fa.res_nt = nt; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off; fa.pairs = bpairs + B->first_pair;
 					fa.npairs = B->npairs; fa.mat = d_mat; fa.n = n; fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.cm16 = d_cm16; fa.cm8 = d_cm8;
 					fa.cm_stride = stride; fa.maskLen = prm->maskLen; fa.bias = bias; fa.score_size = prm->score_size; fa.res = d_res; fa.out = d_out; fa.counters = d_cnt;
-					fa.hits = d_hits;
+					fa.hits = d_hits; fa.f16 = use_f16;
+					if (use_f16) wgs_f16[buf] += (int64_t)fa.npairs * ((fa.ntl + nch - 1) / nch);
 					{ const char* e = getenv("SSW_GPU_DB_CHAIN_BEST"); fa.chain_best = !(e && e[0] == '0'); }
 					if (ssw_shim_launch_filldb(B->R, &fa, st)) { fail(c, "filldb launch failed: %s", ssw_shim_last_error()); goto done; }
 					int64_t lc = 0;
@@ -515,9 +530,16 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		if (ds) {   /* download of this chunk on the second stream; meanwhile hand the previous chunk to the caller */
 			if (ssw_shim_event_record(c->ev_fill[buf], c->stream) || ssw_shim_stream_wait_event(c->stream2, c->ev_fill[buf]) ||
 			    ssw_shim_d2h(ds->h_hits[buf], d_hits, sizeof(struct ssw_hit_rec) * (size_t)nq * (size_t)nt, c->stream2) ||
+			    ssw_shim_d2h((char*)ds->h_hits[buf] + ds->cnt_off, d_cnt_s, DB_COUNTERS * sizeof(int32_t), c->stream2) ||
 			    ssw_shim_event_record(c->ev_red[buf], c->stream2)) { fail(c, "result download failed: %s", ssw_shim_last_error()); goto done; }
 			if (prev_t0 >= 0) {
 				if (ssw_shim_event_sync(c->ev_red[buf ^ 1])) { fail(c, "result download failed: %s", ssw_shim_last_error()); goto done; }
+				{   /* the counters are cumulative: what the previous chunk added */
+					const int32_t* snap = (const int32_t*)((const char*)ds->h_hits[buf ^ 1] + ds->cnt_off);
+					const int32_t r = snap[2] - reruns_seen;
+					reruns_seen = snap[2];
+					if (adaptive && use_f16 && wgs_f16[buf ^ 1] > 0 && (int64_t)r * 8 > wgs_f16[buf ^ 1]) { use_f16 = 0; c->db_f16_off = DB_F16_PAUSE; }
+				}
 				ds->fn_rc = ds->fn(ds->user, tfirst + prev_t0, prev_nt, ds->h_hits[buf ^ 1]);
 				if (ds->fn_rc) { ssw_shim_stream_sync(c->stream); ssw_shim_stream_sync(c->stream2); rc = 0; goto done; }
 			}
@@ -525,12 +547,13 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 			continue;
 		}
 		if (direct) {
-			int32_t cnt[2] = { 0, 0 };
+			int32_t cnt[DB_COUNTERS] = { 0, 0, 0, 0 };
 			if (ssw_shim_d2h(results, d_out, sizeof(struct ssw_out_rec) * (size_t)nq * (size_t)nt, c->stream) ||
 			    ssw_shim_d2h(cnt, d_cnt, sizeof cnt, c->stream) || ssw_shim_stream_sync(c->stream)) {
 				fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
 			}
-			c->tm.n_word += cnt[0]; c->tm.n_byte += cnt[1];
+			c->tm.n_word += cnt[0]; c->tm.n_byte += cnt[1]; c->tm.db_repeats += cnt[2];
+			if (adaptive && use_f16 && (int64_t)cnt[2] * 8 > wgs_f16[buf]) c->db_f16_off = DB_F16_PAUSE;
 			int64_t qsum = Q->h_off[nq] - Q->h_off[0];
 			for (int32_t k = 0; k < nt; ++k) {
 				const int64_t L = T->h_off[tfirst + k + 1] - T->h_off[tfirst + k];
@@ -565,17 +588,17 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		for (int b = 0; b < nb + nmid && b < 64; ++b) {
 			const bucket* B = b < nb ? &bk[b] : &mid[b - nb];
 			char nm[48];
-			snprintf(nm, sizeof nm, "k_filldb<%d>", B->R);
-			note_fill_kernel(c, db_cells[b], &bestc, nm, 8.5, B->R, 1);
+			snprintf(nm, sizeof nm, "k_filldb<%d>%s", B->R, f16_first ? " f16 first" : "");
+			note_fill_kernel(c, db_cells[b], &bestc, nm, f16_first ? 7.5 : 8.5, B->R, 1);
 		}
 	}
 	if (ds && prev_t0 >= 0) {     /* the last chunk */
 		const int buf = (chunk_i - 1) & 1;
-		int32_t cnt[2] = { 0, 0 };
+		int32_t cnt[DB_COUNTERS] = { 0, 0, 0, 0 };
 		if (ssw_shim_event_sync(c->ev_red[buf]) || ssw_shim_d2h(cnt, d_cnt_s, sizeof cnt, c->stream) || ssw_shim_stream_sync(c->stream)) {
 			fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
 		}
-		c->tm.n_word += cnt[0]; c->tm.n_byte += cnt[1];
+		c->tm.n_word += cnt[0]; c->tm.n_byte += cnt[1]; c->tm.db_repeats += cnt[2];
 		c->tm.cells += (Q->h_off[nq] - Q->h_off[0]) * (T->h_off[tfirst + tcount] - T->h_off[tfirst]);
 		ds->fn_rc = ds->fn(ds->user, tfirst + prev_t0, prev_nt, ds->h_hits[buf]);
 	}
@@ -728,7 +751,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		for (int32_t ti = 0; ti < tcount; ++ti) { int64_t L = T->h_off[tfirst + ti + 1] - T->h_off[tfirst + ti]; if (L > maxt) maxt = L; }
 		const char* dis = getenv("SSW_GPU_NO_DB");
 		/* (k_filldb takes the column maximum of two rows with a 16-bit float max3, valid below 31744: 640 rows x max(mat) <= 49) */
-		const int db_ok = !literal && prm->flag == 0 && any_short && maxt <= 65536 && maxmat <= 49 && !(dis && dis[0] == '1');
+		const int db_ok = !literal && prm->flag == 0 && any_short && maxt <= 65000 && maxmat <= 49 && !(dis && dis[0] == '1');
 		if (ds && (!db_ok || any_long)) { rc = SSW_NOT_STREAMABLE; goto done; }
 		if (db_ok && (tcount >= 4 || ds)) {
 			const int mid_ok = (int64_t)n * 10 * 256 <= 65535;     /* 40 rows per lane: 10 chunks of 256 bytes per residue; n x that must stay a 16-bit offset */
@@ -1233,11 +1256,11 @@ int ssw_gpu_search_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs*
 		if (chunk > nt_all) chunk = nt_all;
 		const size_t bytes = sizeof(ssw_gpu_hit) * (size_t)nq * (size_t)chunk;
 		db_stream ds; memset(&ds, 0, sizeof ds);
-		ds.chunk = (int32_t)chunk; ds.fn = fn; ds.user = user;
+		ds.chunk = (int32_t)chunk; ds.fn = fn; ds.user = user; ds.cnt_off = bytes;
 		if (c->hits_cap < bytes) {      /* (page-locking gigabytes takes of the order of a second: the buffers stay with the context) */
 			for (int i = 0; i < 2; ++i) { ssw_shim_free(c->hits_d[i]); ssw_shim_host_free(c->hits_h[i]); c->hits_d[i] = 0; c->hits_h[i] = 0; }
 			c->hits_cap = 0;
-			for (int i = 0; i < 2; ++i) { c->hits_d[i] = ssw_shim_malloc(bytes); c->hits_h[i] = ssw_shim_host_alloc(bytes); }
+			for (int i = 0; i < 2; ++i) { c->hits_d[i] = ssw_shim_malloc(bytes); c->hits_h[i] = ssw_shim_host_alloc(bytes + 64); }   /* + the counter snapshot */
 			if (c->hits_d[0] && c->hits_d[1] && c->hits_h[0] && c->hits_h[1]) c->hits_cap = bytes;
 		}
 		for (int i = 0; i < 2; ++i) { ds.d_hits[i] = (struct ssw_hit_rec*)c->hits_d[i]; ds.h_hits[i] = (ssw_gpu_hit*)c->hits_h[i]; }

@@ -8,7 +8,9 @@
  *                 group of 16 columns
  *   k_chainq      the same fill for longer queries, cut into row strips of 64 x R rows that a persistent launch draws from a
  *                 work queue (k_chainx: the 16-lane form, strips in sequence); its window mode does the "where" passes
- *   k_filldb      database search: fill + best cell + reduction of one query pair against 16 short targets in one launch
+ *   k_filldb      database search: fill + best cell + reduction of one query pair against 16 short targets in one launch -- in
+ *                 the f16 form (exact below 2048) with the rare workgroup that saturates repeating in int16, the role ssw_align
+ *                 gives its 16-bit kernel after a saturated 8-bit pass (887-890)
  *   k_reduce_seg  the bookkeeping around the fill: best score / first best column (317-340, 523-542) and the masked
  *   / k_reduce    second-best scan (368-381 / 570-583), plus ssw_align's choice between 8-bit and 16-bit rules (881-899) and its
  *                 early exits (900-916) -- over the group maxima / over the strip kernel's columns
@@ -303,38 +305,143 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
  * k_filldb: database search.  Same chains as k_fill, but the 16 chains of a workgroup take 16 different (short,
  * untiled) targets, each lane also remembers where the running column maximum last grew, and the chain reduces its
  * own column maxima afterwards: score1 / ref_end1 / read_end1 / score2 / ref_end2 come out of ONE launch.
- * grid = npairs * ceil(ntl / 16) workgroups of 256 threads.
+ * grid = npairs * ceil(ntl / NCH) workgroups of NCH chains (16 * NCH threads: the profile of a pair -- 25 residues x R rows x
+ * 64 bytes for proteins -- is what limits the wavefronts per CU, and more chains per workgroup share it).
+ *
+ * F16 form first (a.f16): scores / 2048 in f16 -- `clamp` is the max(0, .) and v_pk_maximum3_f16 folds two maxima, 7.5 instead
+ * of 8.5 instructions per row -- which is exact as long as no cell reaches 2048 and SATURATES there (clamp at 1.0; sums above
+ * round, then clamp).  Every value below 2048 that only depends on values below 2048 is exact, so a pass whose best cells all
+ * stay below 2048 has computed the true matrix; a workgroup that sees a best cell at 2048 writes nothing and repeats its
+ * targets in the int16 form (the role the reference gives its 16-bit kernel after a saturated 8-bit pass, ssw.c:887-890).
  * ================================================================================================ */
+#define DB_OUT_RING 32                                   /* finished column maxima parked per chain (k_fill keeps 64) */
+#define DB_RING_BYTES 192                                /* target ring: 64 entries + 32 mirrored (entries are read two steps ahead) */
+#define DB_CHAIN_BYTES (DB_RING_BYTES + 8 * DB_OUT_RING)
+
+/* the packed scores of N <= 4 consecutive rows of a lane (one 16-byte profile chunk; only the rows that exist are loaded) */
+template <int N> SSW_DEV u32x4 lds_ld_rows(const unsigned char* lds, u32 off)
+{
+	if (N >= 3) return lds_ld128(lds, off);
+	u32x4 r = { 0u, 0u, 0u, 0u };
+	if (N == 2) { const u32x2 t = lds_ld64(lds, off); r[0] = t[0]; r[1] = t[1]; }
+	else r[0] = lds_ld32(lds, off);
+	return r;
+}
+
+/* k_filldb: the R rows of one step (same arithmetic and pairing as chain_rows with TRACK8), with the score chunks of the NEXT step
+   requested as soon as the rows of a chunk are done: one set of score registers instead of two, and every profile read still has
+   a whole step to land.  db_done(r) = the last row that is finished after iteration r of the unrolled loop. */
+template <int R> constexpr int db_done(int r, bool f16)
+{
+	if (r < 0) return -1;
+	if (!f16) return r;
+	const int K8 = ChainGeom<R>::K8, seg0 = r < K8 ? 0 : K8, seg1 = r < K8 ? K8 : R;
+	const bool second = ((r - seg0) & 1) == 1;
+	return !second && r + 1 < seg1 ? r + 1 : r;
+}
+
+template <int R, bool F16>
+SSW_DEV void db_rows(const unsigned char* lds, u32 pa_next, u32x4 (&sc)[(R + 3) / 4], u32 (&H)[R], u32 (&E)[R], u32 d, u32& f, u32& cm, u32& ck,
+                     u32 gO, u32 gE)
+{
+	constexpr int C = (R + 3) / 4, K8 = ChainGeom<R>::K8;
+#pragma unroll
+	for (int r = 0; r < R; ++r) {
+		const int seg0 = r < K8 ? 0 : K8, seg1 = r < K8 ? K8 : R;
+		const bool second = ((r - seg0) & 1) == 1;      /* second row of a pair */
+		const bool pair = !second && r + 1 < seg1;      /* first row of a pair (otherwise a single row left over) */
+		if (r == K8) ck = cm;                           /* rows < A8 end here in lane TAP: the 16-bit-rule maximum */
+		if (F16) {
+			if (pair) {
+				const int r1 = r + 1 < R ? r + 1 : r;
+				const u32 d1 = H[r], hold = H[r1];
+				u32 h0, h1;
+				pkf_cell2(d, sc[r >> 2][r & 3], d1, sc[r1 >> 2][r1 & 3], E[r], E[r1], f, cm, h0, h1, gO, gE);
+				H[r] = h0; H[r1] = h1;
+				d = hold;
+			} else if (!second) {
+				const u32 hold = H[r];
+				u32 h;
+				pkf_cell(d, sc[r >> 2][r & 3], E[r], f, cm, h, gO, gE);
+				H[r] = h;
+				d = hold;
+			}
+		} else {
+			const u32 hold = H[r];
+			const u32 h0 = pk_max(pk_adds(d, sc[r >> 2][r & 3]), E[r]);
+			const u32 h = pk_max(h0, f);
+			const u32 t0 = pk_subu(h0, gO);
+			E[r] = pk_max(pk_subu(E[r], gE), t0);
+			f = pk_max(pk_subu(f, gE), t0);
+			if (second) cm = pk_max3_nonneg(cm, H[r - 1 >= 0 ? r - 1 : 0], h);   /* H[r-1] was just written: this pair's first row */
+			else if (!pair) cm = pk_max(cm, h);
+			H[r] = h;
+			d = hold;
+		}
+#pragma unroll
+		for (int c = 0; c < C; ++c) {
+			const int last = 4 * c + 3 < R - 1 ? 4 * c + 3 : R - 1;      /* the chunk's last row */
+			if (last <= db_done<R>(r, F16) && last > db_done<R>(r - 1, F16)) {
+				const u32 pa = after(pa_next, H[last]);      /* not before the chunk's rows have used the old scores */
+				if (c + 1 < C) sc[c] = lds_ld128(lds, pa + 256u * c);
+				else sc[c] = lds_ld_rows<R - 4 * (C - 1)>(lds, pa + 256u * c);
+			}
+		}
+	}
+}
+
+/* Best-cell tracking of k_filldb.  `now` = the lane's running record after a step, `pre` = before it (with the column's rows above
+   folded in): the lane whose OWN rows raised a half has a new candidate for that query's best cell and keeps the column and that
+   half of its H column.  On unrelated proteins some lane of the wavefront (4 chains x 2 queries) sets one in 60 % of the steps (every
+   new maximum of the rows above and the columns before counts, and ties with the chain's best do), so the record itself is
+   branch-free: a per-half byte mask of the halves that rose, one v_bfi per row for both queries at once -- no compare / select
+   chains, no changes of the execution mask (R / 2 byte permutes per half behind two more branches cost 23 % of the kernel, a
+   look-up of the row at once or stores of the column to scratch more).  The value and the row are read off the kept column
+   after the last step. */
 template <int R>
-__global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
+SSW_DEV void db_record(u32 now, u32 pre, int tc, const u32 (&H)[R], u32 (&snap)[R], u32& btc2)
+{
+	const u32 m = opaque(pk_mullo(pk_minu(pk_subu(now, pre), 0x00010001u), 0xffffffffu));      /* 0xffff in the halves that rose */
+	btc2 = bfi32(m, (u32)tc * 0x00010001u, btc2);
+#pragma unroll
+	for (int r = 0; r < R; ++r) snap[r] = bfi32(m, H[r], snap[r]);
+}
+
+SSW_DEV int pkf_half_to_int(int bits) { return (int)(pkf_to_int2((u32)bits & 0xffffu) & 0xffffu); }
+
+/* returns true when the f16 form saturated (nothing was written: the caller repeats the workgroup in the int16 form) */
+template <int R, int NCH, bool F16, int UNROLL>
+SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 {
 	typedef ChainGeom<R> G;
 	constexpr int C = G::C;
-	SSW_DYN_LDS(lds);
+	constexpr u32 OM = DB_OUT_RING - 1;
 	const int tid = (int)threadIdx.x, l16 = tid & 15, grp = tid >> 4;
-	const int tchunks = (a.ntl + 15) / 16;
+	const int tchunks = (a.ntl + NCH - 1) / NCH;
 	const int pair = (int)blockIdx.x / tchunks, tchunk = (int)blockIdx.x - pair * tchunks;
 	const u32 prof_bytes = (u32)(a.n + 1) * G::PSTRIDE;
-	const u32 ring = prof_bytes + (u32)grp * CHAIN_BYTES, out16 = ring + RING_BYTES, out8 = out16 + 256;
+	const u32 ring = prof_bytes + (u32)grp * DB_CHAIN_BYTES, out16 = ring + DB_RING_BYTES, out8 = out16 + 4u * DB_OUT_RING;
+	const u32 vote = prof_bytes + (u32)NCH * DB_CHAIN_BYTES;      /* one word: some chain of the workgroup saturated */
 	const u32 nulloff = (u32)a.n * G::PSTRIDE;
 	const ssw_pair pr = a.pairs[pair];
 	const int lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
 	const int lenb = pr.qb >= 0 ? (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]) : 0;
-	build_profile<R>(lds, 0, tid, 256, a.mat, a.n, a.qcodes + a.qoff[pr.qa], lena, 0,
-	                 pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0, lenb);
+	build_profile<R, F16>(lds, 0, tid, 16 * NCH, a.mat, a.n, a.qcodes + a.qoff[pr.qa], lena, 0,
+	                      pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0, lenb);
+	if (F16 && tid == 0) lds_st32(lds, vote, 0u);
 
-	const int slot = tchunk * 16 + grp;
+	const int slot = tchunk * NCH + grp;
 	const bool active = slot < a.ntl;
 	const int t = active ? a.tlist[slot] : 0;
 	const int8_t* tg = a.tcodes + a.toff[t];
 	const int ncols = active ? (int)(a.toff[t + 1] - a.toff[t]) : 0;
 	uint32_t* o16 = a.cm16 + ((int64_t)pair * a.ntl + (active ? slot : 0)) * a.cm_stride;
 	uint32_t* o8 = a.cm8 + ((int64_t)pair * a.ntl + (active ? slot : 0)) * a.cm_stride;
-	/* uniform step count of the workgroup: the longest of its 16 targets (lists are sorted by length) */
+	/* uniform step count of the workgroup: the longest of its NCH targets (lists are sorted by length) */
 	int maxcols = 0;
 	{
-		const int last = tchunk * 16 + 15 < a.ntl ? tchunk * 16 + 15 : a.ntl - 1;
-		for (int k = tchunk * 16; k <= last; ++k) { const int tt = a.tlist[k]; const int L = (int)(a.toff[tt + 1] - a.toff[tt]); maxcols = L > maxcols ? L : maxcols; }
+		const int last = tchunk * NCH + NCH - 1 < a.ntl ? tchunk * NCH + NCH - 1 : a.ntl - 1;
+		for (int k = tchunk * NCH; k <= last; ++k) { const int tt = a.tlist[k]; const int L = (int)(a.toff[tt + 1] - a.toff[tt]); maxcols = L > maxcols ? L : maxcols; }
 	}
 	const int nsteps = (maxcols + 16 + 15) & ~15;
 
@@ -355,25 +462,38 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 	}
 	__syncthreads();
 
-	u32 H[R], E[R];
+	u32 H[R], E[R], snap[R];                        /* snap: per query half, the lane's H column at its last record (db_record) */
 #pragma unroll
-	for (int r = 0; r < R; ++r) { H[r] = 0; E[r] = 0; }
+	for (int r = 0; r < R; ++r) { H[r] = 0; E[r] = 0; snap[r] = 0; }
 	u32 Hlast = 0, Fout = 0, cmout = 0, ck = 0, hsave = 0;
 	u32 best = 0;                                   /* packed: highest running column maximum this lane has seen */
-	int bval[2] = { 0, 0 }, btc[2] = { 0x7fffffff, 0x7fffffff }, brow[2] = { 0x7fffffff, 0x7fffffff };   /* the last record this lane set itself */
-	/* The wavefront pays for every record any of its 4 chains x 2 queries sets (unrelated proteins: ~100 per target), so a
-	   record only copies the query's half of the lane's column (R/2 byte permutes instead of 2R compare/select); measured on the config-5 shape the row
-	   search at every record cost 24 % of the kernel. */
-	u32 snap[2][(R + 1) / 2];
-#pragma unroll
-	for (int k = 0; k < (R + 1) / 2; ++k) { snap[0][k] = 0; snap[1][k] = 0; }
+	u32 btc2 = 0xffffffffu;                         /* packed: column of the last record per half (the host keeps targets below 65000 residues here) */
 	const u32 lane_prof = (u32)l16 * 16u;
+	const u32 gO = F16 ? pkf_make(-(int)(a.gapO2 & 0xffffu), -(int)(a.gapO2 & 0xffffu)) : a.gapO2;
+	const u32 gE = F16 ? pkf_make(-(int)(a.gapE2 & 0xffffu), -(int)(a.gapE2 & 0xffffu)) : a.gapE2;
+	/* f16 form: H, the column maxima and `best` are bit patterns of non-negative f16 numbers, whose order is the integer order:
+	   the tracking below compares patterns; the column maxima become integers where they leave the chain */
+
+	/* software pipeline of the LDS reads (three or four wavefronts per SIMD do not hide a ring entry -> address -> scores round
+	   trip per step): the ring entry of step s+2 is requested before the rows of step s run, the score chunks of step s+1 while
+	   they run (db_rows).  Ring entries are staged a chunk ahead and the mirror is 32 entries deep, so reading 17 entries past
+	   a chunk's first one is safe. */
+	u32x4 sc[C];
+	u32 pa_n;
+	{
+		const u32 r0 = ring + 2u * (u32)((0 - l16) & 63);
+		const u32 pa0 = lds_ld16(lds, r0) + lane_prof;
+#pragma unroll
+		for (int c = 0; c + 1 < C; ++c) sc[c] = lds_ld128(lds, pa0 + 256u * c);
+		sc[C - 1] = lds_ld_rows<R - 4 * (C - 1)>(lds, pa0 + 256u * (C - 1));
+		pa_n = lds_ld16(lds, r0 + 2u) + lane_prof;
+	}
 
 	for (int s0 = 0; s0 < nsteps; s0 += 16) {
 		{
 			const int p = (s0 + 16 + l16) & 63;
 			lds_st16(lds, ring + 2u * p, nxt);
-			if (p < 16) lds_st16(lds, ring + 2u * (64 + p), nxt);
+			if (p < 32) lds_st16(lds, ring + 2u * (64 + p), nxt);
 			const int tc = s0 + 32 + l16;
 			int code = tc < ncols ? tg[tc] : a.n;
 			if (code < 0 || code > a.n) code = a.n;
@@ -383,8 +503,9 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 		if (s0 >= 32) {
 			const int tc = s0 - 32 + l16;
 			if (tc < ncols) {
-				o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
-				o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
+				const u32 v16 = lds_ld32(lds, out16 + 4u * ((u32)tc & OM)), v8 = lds_ld32(lds, out8 + 4u * ((u32)(tc - (15 - G::TAP)) & OM));
+				o16[tc] = F16 ? pkf_to_int2(v16) : v16;
+				o8[tc] = F16 ? pkf_to_int2(v8) : v8;
 			}
 		}
 		wave_lds_fence();
@@ -398,14 +519,11 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			}
 		}
 		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
-		const u32 ob16 = out16 + 4u * (u32)((s0 - 16) & 63), ob8 = out8 + 4u * (u32)((s0 - 16) & 63);
-#pragma unroll 4
+		const u32 ob16 = out16 + 4u * ((u32)(s0 - 16) & OM), ob8 = out8 + 4u * ((u32)(s0 - 16) & OM);
+#pragma unroll UNROLL
 		for (int j = 0; j < 16; ++j) {
 			const int tc = s0 + j - l16;
-			const u32 paddr = lds_ld16(lds, rp + 2u * j) + lane_prof;
-			u32x4 sc[C];
-#pragma unroll
-			for (int c = 0; c < C; ++c) sc[c] = lds_ld128(lds, paddr + 256u * c);
+			const u32 pa_next = lds_ld16(lds, rp + 2u * (j + 2));      /* the ring entry of step s + 2 */
 			const u32 hin = xl_row_shr1_zero(Hlast);
 			u32 f = xl_row_shr1_zero(Fout);
 			const u32 x = xl_row_ror<1>(cmout);
@@ -419,46 +537,47 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			/* best cell: `pre` = the lane's running record and the rows above in this column; only the lane whose OWN rows
 			   beat it -- the lane holding the new record cell, not every lane below -- takes the branch further down */
 			const u32 pre = pk_max(best, cm);
-			chain_rows<R, true, false, true>(sc, H, E, hsave, f, cm, ck, a.gapO2, a.gapE2);   /* the host keeps max(mat) x 640 below 31744 on this path */
+			db_rows<R, F16>(lds, pa_n, sc, H, E, hsave, f, cm, ck, gO, gE);   /* int16 form: the host keeps max(mat) x 640 below 31744 on this path */
+			pa_n = pa_next + lane_prof;
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
 			best = pk_max(best, cm);     /* = max(pre, own rows) */
-			const bool hit = best != pre;   /* (columns outside the target score "dead": H = max(E, F) there, which decays and never sets a record) */
-			if (wave_any(hit)) {         /* a scalar branch: hipcc otherwise if-converts half of the row search into every step */
-				if (hit) {
+			/* (columns outside the target score "dead": H = max(E, F) there, which decays and never sets a record) */
+			if (wave_any(best != pre)) db_record<R>(best, pre, tc, H, snap, btc2);   /* a scalar branch: hipcc otherwise if-converts half of the row search into every step */
+		}
+	}
+	/* the lane's last record per half: the value is the largest of the kept column (its own rows had just raised the maximum) */
+	int bval[2], btc[2], brow[2];
+	{
+		u32 mx = 0;
 #pragma unroll
-					for (int h = 0; h < 2; ++h) {
-						const int nv = (int)((best >> (16 * h)) & 0xffffu), ov = (int)((pre >> (16 * h)) & 0xffffu);
-						if (nv > ov) {
-							bval[h] = nv; btc[h] = tc;
-							/* keep this query's half of the column (two rows per register); the row is looked up once, after the last column */
+		for (int r = 0; r < R; ++r) mx = pk_max(mx, snap[r]);
 #pragma unroll
-							for (int k = 0; k < R; k += 2) {
-								const u32 lo = H[k], hi = k + 1 < R ? H[k + 1] : 0u;
-								snap[h][k >> 1] = pk_perm(hi, lo, h ? PK_HI2 : PK_LO2);
-							}
-						}
-					}
-				}
-			}
+		for (int h = 0; h < 2; ++h) {
+			bval[h] = (int)((mx >> (16 * h)) & 0xffffu);
+			btc[h] = bval[h] > 0 ? (int)((btc2 >> (16 * h)) & 0xffffu) : 0x7fffffff;
+			brow[h] = 0x7fffffff;
+#pragma unroll
+			for (int k = R - 1; k >= 0; --k) if (bval[h] > 0 && (int)((snap[k] >> (16 * h)) & 0xffffu) == bval[h]) brow[h] = l16 * R + k;
+		}
+	}
+	if (F16) {   /* a best cell at 2048 (1.0): the form saturated somewhere in this workgroup */
+		if (bval[0] >= 0x3C00 || bval[1] >= 0x3C00) lds_st32(lds, vote, 1u);
+		__syncthreads();
+		if (lds_ld32(lds, vote) != 0u) {
+			if (tid == 0 && a.counters) atomicAdd(a.counters + 2, 1);
+			return true;
 		}
 	}
 	wave_lds_fence();
 	for (int base = nsteps - 32; base < nsteps; base += 16) {
 		const int tc = base + l16;
 		if (tc >= 0 && tc < ncols) {
-			o16[tc] = lds_ld32(lds, out16 + 4u * (tc & 63));
-			o8[tc] = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
+			const u32 v16 = lds_ld32(lds, out16 + 4u * ((u32)tc & OM)), v8 = lds_ld32(lds, out8 + 4u * ((u32)(tc - (15 - G::TAP)) & OM));
+			o16[tc] = F16 ? pkf_to_int2(v16) : v16;
+			o8[tc] = F16 ? pkf_to_int2(v8) : v8;
 		}
 	}
 	dev_fence();   /* the chain re-reads its own column maxima below */
-#pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		brow[h] = 0x7fffffff;
-		if (bval[h] > 0) {
-#pragma unroll
-			for (int k = R - 1; k >= 0; --k) if ((int)((snap[h][k >> 1] >> (16 * (k & 1))) & 0xffffu) == bval[h]) brow[h] = l16 * R + k;
-		}
-	}
 
 	/* ---- per chain, per query: reduce (the role of k_reduce + the locate pass) ---- */
 	const u32 red = ring;   /* the rings are free now: 16 lanes x 16 bytes */
@@ -466,8 +585,7 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 		const int q = h ? pr.qb : pr.qa;
 		if (q < 0) continue;                         /* uniform in the workgroup */
 		const int len = h ? lenb : lena;
-		const int myv = bval[h];
-		lds_st32(lds, red + 16u * l16, (u32)myv);
+		lds_st32(lds, red + 16u * l16, (u32)bval[h]);      /* (f16 form: bit patterns, same order as the scores) */
 		lds_st32(lds, red + 16u * l16 + 4, (u32)btc[h]);
 		lds_st32(lds, red + 16u * l16 + 8, (u32)brow[h]);
 		wave_lds_fence();
@@ -477,6 +595,7 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 			if (v > bv || (v == bv && v > 0 && cc < bc)) { bv = v; bc = cc; br = w; }
 		}
 		wave_lds_fence();
+		if (F16) bv = pkf_half_to_int(bv);
 		const bool padded = (len & 15) >= 1 && (len & 15) <= 8;
 		const int maskLen = a.maskLen >= 0 ? a.maskLen : len / 2;
 		const bool have_byte = a.score_size == 0 || a.score_size == 2, have_word = a.score_size == 1 || a.score_size == 2;
@@ -530,6 +649,24 @@ __global__ void __launch_bounds__(256) k_filldb(ssw_filldb_args a)
 		}
 		wave_lds_fence();
 	}
+	return false;
+}
+
+/* F16FIRST: the f16 form, then -- rarely -- the repeat in the int16 form, which is compiled with the step loop rolled up so that
+   the kernel's register count is the f16 form's (the wavefronts per SIMD of the common case); otherwise the int16 form alone */
+#ifndef DB_UNROLL_F16
+#define DB_UNROLL_F16 2
+#endif
+#ifndef DB_UNROLL_REPEAT
+#define DB_UNROLL_REPEAT 1
+#endif
+template <int R, int NCH, bool F16FIRST>
+__global__ void __launch_bounds__(16 * NCH) k_filldb(ssw_filldb_args a)
+{
+	SSW_DYN_LDS(lds);
+	if (F16FIRST) {
+		if (filldb_pass<R, NCH, true, DB_UNROLL_F16>(a, lds)) filldb_pass<R, NCH, false, DB_UNROLL_REPEAT>(a, lds);
+	} else filldb_pass<R, NCH, false, 4>(a, lds);
 }
 
 /* ================================================================================================
@@ -914,16 +1051,6 @@ template <bool ALL4> SSW_DEV u32x4 lds_ld_bnd(const unsigned char* lds, u32 off)
 	return r;
 }
 
-/* the packed scores of N <= 4 consecutive rows of a lane (one 16-byte profile chunk; only the rows that exist are loaded) */
-template <int N> SSW_DEV u32x4 lds_ld_rows(const unsigned char* lds, u32 off)
-{
-	if (N >= 3) return lds_ld128(lds, off);
-	u32x4 r = { 0u, 0u, 0u, 0u };
-	if (N == 2) { const u32x2 t = lds_ld64(lds, off); r[0] = t[0]; r[1] = t[1]; }
-	else r[0] = lds_ld32(lds, off);
-	return r;
-}
-
 /* profile of one strip: word = (score of query a's row, score of query b's row) against residue b; rows at or below a
    query's padded length are dead for that half */
 template <int R, int GL>
@@ -979,6 +1106,26 @@ template <int PS> SSW_DEV u32 strip_code_off(const StripCtx& x, int h, int tc, b
 	return (u32)code * (u32)PS;
 }
 
+/* fill mode, best-cell tracking: `now` = the lane's running record after a step, `pre` = before it (this column's rows above folded
+   in).  Only the lane whose OWN rows beat that -- the lane holding the new record cell, not every lane below it -- records: value,
+   column, smallest row.  (Columns outside the target only decay; the test on tc keeps the hand-written contract explicit.  The
+   branch-free form of k_filldb's db_record, one v_bfi per row, measured 13 ms slower on config 4's fill.) */
+template <int R>
+SSW_DEV void strip_record(u32 now, u32 pre, int tc, const StripCtx& x, const u32 (&H)[R], int (&sv)[2], int (&stc)[2], int (&srow)[2])
+{
+	if (now != pre && x.mine && tc >= 0 && tc < x.ncols) {
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int nv = (int)((now >> (16 * h)) & 0xffffu), ov = (int)((pre >> (16 * h)) & 0xffffu);
+			if (nv > ov) {
+				sv[h] = nv; stc[h] = tc; srow[h] = 0x7fffffff;
+#pragma unroll
+				for (int k = R - 1; k >= 0; --k) if ((int)((H[k] >> (16 * h)) & 0xffffu) == nv) srow[h] = x.row0 + x.l16 * R + k;
+			}
+		}
+	}
+}
+
 template <int R, bool CAPTURE, bool MASK8, int GL, bool CM3 = false>
 SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st, const u32 (&m8)[R])
 {
@@ -1018,6 +1165,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	const u32 lane_prof = x.prof + (u32)l16 * 16u;
 	u32 sbest = 0; int sv[2] = { 0, 0 }, stc[2] = { 0x7fffffff, 0x7fffffff }, srow[2] = { 0x7fffffff, 0x7fffffff };   /* this strip's tracking */
 	if (CAPTURE) sbest = pk_subu(pk_make(st.best[0], st.best[1]), 0x00010001u);
+	unsigned long long pend = 0ull; u32 prep = 0;   /* fill: lanes whose rows set a record in the step before, and that step's `pre` */
 	wave_lds_fence();
 	/* software pipeline of the LDS reads (two waves per SIMD do not hide their latency): the scores and the boundary record
 	   of step s+1 and the ring entry of step s+2 are requested before step s computes.  Ring entries are staged a chunk ahead
@@ -1101,6 +1249,11 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			u32 cm8 = MASK8 ? xl_chain_shr1_keep<GL>(rec[3], st.cm8out) : 0u;
 			u32 d = st.hsave;
 			u32 lm = 0;   /* capture: this lane's own maximum in this column */
+			/* fill: the record of the step BEFORE.  The scalar branch on "some lane set a record" is taken a step late, before the rows of
+			   the next column run: the compare that feeds it is a whole step old by then, while at the end of its own step the scalar
+			   unit would wait for the vector compare every time (config 4's fill: 1602 -> 1546 ms).  H still holds that column.
+			   (k_filldb, where the branch is taken in most steps, got slower with the same change.) */
+			if (!CAPTURE && pend != 0ull) strip_record<R>(sbest, prep, tc - 1, x, st.H, sv, stc, srow);
 			const u32 pre = pk_max(sbest, cm);   /* fill: the lane's running record and this column's rows above */
 #pragma unroll
 			for (int r = 0; r < R; ++r) {
@@ -1125,17 +1278,8 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 				   record and this column's maximum of the rows above).  Only the lane whose OWN rows beat that -- the lane
 				   holding the new record cell, not every lane below it -- takes the branch. */
 				sbest = pk_max(sbest, cm);      /* = max(pre, own rows); pre was taken before the rows */
-				if (sbest != pre && x.mine && tc >= 0 && tc < x.ncols) {
-#pragma unroll
-					for (int h = 0; h < 2; ++h) {
-						const int nv = (int)((sbest >> (16 * h)) & 0xffffu), ov = (int)((pre >> (16 * h)) & 0xffffu);
-						if (nv > ov) {
-							sv[h] = nv; stc[h] = tc; srow[h] = 0x7fffffff;
-#pragma unroll
-							for (int k = R - 1; k >= 0; --k) if ((int)((st.H[k] >> (16 * h)) & 0xffffu) == nv) srow[h] = x.row0 + l16 * R + k;
-						}
-					}
-				}
+				pend = wave_ballot(sbest != pre); prep = pre;
+				sched_fence();
 			}
 			st.hsave = hin; st.Hlast = st.H[R - 1]; st.Fout = f; st.cmout = cm; st.cm8out = MASK8 ? cm8 : cm;
 			if (l16 == GL - 1) {
@@ -1158,6 +1302,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			}
 		}
 	}
+	if (!CAPTURE && pend != 0ull) strip_record<R>(sbest, prep, x.nsteps - 1 - l16, x, st.H, sv, stc, srow);
 	wave_lds_fence();
 	for (int base = x.nsteps - GL - 16; base < x.nsteps - GL + 16; base += 16) {
 		const int tc = base + l16;
@@ -1454,6 +1599,18 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 		for (int h = 0; h < 2; ++h) {
 			st.best[h] = CAPTURE ? cv[h] : 0; st.btc[h] = CAPTURE ? cc[h] : 0x7fffffff; st.brow[h] = CAPTURE ? cr[h] : 0;
 			st.tv[h] = 0; st.ttc[h] = 0x7fffffff; st.trow[h] = 0x7fffffff;
+		}
+		if (CAPTURE) {
+			/* A window pass only asks WHERE the known score1 is reached: cells below it need no record.  The lanes start from
+			   score1 - 1 (no column, no row) wherever a window that does not hold score1 is not accepted anyway -- the forward
+			   locate pass (status 3) and the capped first try of the reverse pass (rerun with the exact halo) -- so along a true
+			   alignment, where a new best comes with every column, they stop recording.  The uncapped reverse pass keeps every
+			   record: there a smaller best is an answer (flag 2 of the reference, ssw.c:932-935). */
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const int floorv = ch[h].active && (!a.reverse || ch[h].capped) ? ch[h].r.score1 - 1 : 0;
+				if (floorv > st.best[h]) { st.best[h] = floorv; st.btc[h] = 0x7fffffff; st.brow[h] = 0; }
+			}
 		}
 		build_profile_strip<R, GL>(lds, x.prof, l16, GL, a.mat, a.n, qa, lena, rev, rowsa, qb, lenb, rev, rowsb, x.row0);
 		u32 m8[R];
@@ -2471,11 +2628,13 @@ extern "C" int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream)
 extern "C" int ssw_shim_launch_filldb(int R, const ssw_filldb_args* a, void* stream)
 {
 	ssw_filldb_args args = *a;
-	const int64_t grid = (int64_t)args.npairs * ((args.ntl + 15) / 16);
+	const int nch = SSW_DB_NCH;
+	const int64_t grid = (int64_t)args.npairs * ((args.ntl + nch - 1) / nch);
 	if (grid <= 0) return 0;
 	switch (R) {
-#define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
-		SSW_LAUNCH((k_filldb<r>), ssw_filldb_args, args, grid, 256, ldsb, stream); } break;
+#define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + (size_t)nch * DB_CHAIN_BYTES + 16; \
+		if (args.f16) SSW_LAUNCH((k_filldb<r, SSW_DB_NCH, true>), ssw_filldb_args, args, grid, 16 * SSW_DB_NCH, ldsb, stream); \
+		else SSW_LAUNCH((k_filldb<r, SSW_DB_NCH, false>), ssw_filldb_args, args, grid, 16 * SSW_DB_NCH, ldsb, stream); } break;
 		FOR_EACH_R(X)
 		FOR_EACH_DBR_LONG(X)
 #undef X

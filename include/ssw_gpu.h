@@ -78,6 +78,7 @@ typedef struct {
 	double fill_ops_per_row; /* packed 16-bit VALU instructions per (row, column) of a query pair in that kernel: 7.5 / 8.5 / 9 */
 	int32_t fill_rows_per_lane;
 	int32_t fill_strips;
+	int64_t db_repeats;    /* database search: workgroups whose f16 form saturated (a score >= 2048) and that repeated in the int16 form */
 } ssw_gpu_timing;
 
 int ssw_gpu_device_count(void);

@@ -78,3 +78,57 @@ def test_streamed_search_equals_batch_gpu(gpu_ctx):
     assert not bad, "\n".join(bad)
     for f in ("score1", "score2", "ref_end1", "read_end1", "ref_end2"):
         assert (r2[f] == res[f][sub][:, :40]).all()
+
+
+# ---- the f16 form of the fused kernel saturates at 2048: workgroups that see it repeat in the int16 form ----
+def _f16_limit_case():
+    """n = 5 alphabet, A-A scores 7, C-C 1, G-G 5, every mismatch -4: the self-alignment of A^292 C^k scores 2044 + k --
+    2047 (exact in f16), 2048 (the saturation value itself) and 2049-2051 (beyond it), next to unrelated short sequences
+    and longer homologs far above the limit; several sequences per size class so that chains of one workgroup disagree."""
+    mat = np.full((5, 5), -4, dtype=np.int8)
+    mat[0, 0] = 7; mat[1, 1] = 1; mat[2, 2] = 5; mat[3, 3] = 2
+    mat[4, :] = 0; mat[:, 4] = 0
+    rng = np.random.default_rng(77)
+    seqs = [np.array([0] * 292 + [1] * k, dtype=np.int8) for k in (0, 2, 3, 4, 5, 7)]
+    seqs.append(np.array([0] * 300 + [2] * 100, dtype=np.int8))          # 2600: far above, another size class
+    seqs.append(np.array([0] * 120 + [1] * 30, dtype=np.int8))           # 870: stays f16
+    seqs += [rng.integers(0, 4, size=int(L), dtype=np.int8) for L in (295, 299, 150, 301, 64)]
+    return seqs, np.ascontiguousarray(mat.reshape(-1))
+
+
+def _f16_limit_check(ctx, monkeypatch):
+    seqs, mat = _f16_limit_case()
+    for _ in range(1):
+        monkeypatch.setenv("SSW_GPU_DB_F16", "1")          # f16 form first in every call (most workgroups of this case repeat: the library would pause it)
+        res = _case(ctx, seqs, seqs, mat, 5, 3, 1, chunks=(4, 0))
+        s = np.array([[int(res["score1"][i, j]) for j in range(6)] for i in range(6)])
+        assert s[2, 2] == 2047 and s[3, 3] == 2048 and s[4, 4] == 2049 and s[5, 5] == 2051 and s[0, 5] == 2044
+        assert int(res["score1"][6, 6]) == 2600
+        tm = ctx.timing()
+        assert "f16 first" in tm["fill_kernel"] and tm["db_repeats"] > 0, tm
+        monkeypatch.setenv("SSW_GPU_DB_F16", "0")          # the int16 form alone gives the same records
+        res2 = _case(ctx, seqs, seqs, mat, 5, 3, 1, chunks=(0,), check_ref=False)
+        assert ctx.timing()["db_repeats"] == 0
+        monkeypatch.delenv("SSW_GPU_DB_F16")
+        for f in ("score1", "score2", "ref_end1", "read_end1", "ref_end2"):
+            assert (res2[f] == res[f]).all(), f
+    # left to itself the library notices the repeats and pauses the f16 form on this context
+    own = ssw_amd.Context(0, ctx.lib)          # (a context of its own: the pause would outlive this test on the shared one)
+    Q = own.upload(seqs); T = own.upload(seqs)
+    try:
+        own.align_batch(Q, T, mat, 5, 3, 1, 0, 0, 0, -1, 2)
+        first = own.timing()
+        own.align_batch(Q, T, mat, 5, 3, 1, 0, 0, 0, -1, 2)
+        second = own.timing()
+    finally:
+        Q.free(); T.free(); own.close()
+    assert first["db_repeats"] > 0 and second["db_repeats"] == 0 and "f16" not in second["fill_kernel"], (first, second)
+
+
+def test_f16_form_limit_and_int16_repeat_emulated(ectx, monkeypatch):
+    _f16_limit_check(ectx, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_f16_form_limit_and_int16_repeat_gpu(gpu_ctx, monkeypatch):
+    _f16_limit_check(gpu_ctx, monkeypatch)
