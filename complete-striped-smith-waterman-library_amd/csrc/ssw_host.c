@@ -682,10 +682,10 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 	/* long queries: the wavefront is one chain of 64 lanes; rows per lane bounded so that one profile stays near 24 KiB
 	   of LDS (several waves per CU).  SSW_GPU_XLANES=16 / SSW_GPU_XR=<rows per lane> override (experiments). */
 	int32_t xlanes = 64, xrmax = 4 * (24 / (n + 1) < 1 ? 1 : 24 / (n + 1) > 3 ? 3 : 24 / (n + 1));
-	/* measured on 10-kb DNA reads (profiles/round2_sweep_d_config4_xr*.json): fill 1620 / 1575 / 1586 / 1658 ms at 12 / 10 / 8 / 16
-	   rows per lane (10 and 12 share an LDS footprint, 10 pads fewer rows); the window passes, which carry two target rings and
-	   more registers, are fastest at 8 (245 vs 265 ms) */
-	if (xrmax == 12) xrmax = 10;
+	/* measured on 10-kb DNA reads: fill 1462 / 1514 / 1550 / 1604 / 1568 ms at 12 / 11 / 10 / 9 / 8 rows per lane (9..12 share an LDS
+	   footprint -- three 16-byte profile chunks per lane and residue --, and the more rows a step has, the less its fixed part
+	   weighs; before the record branch was deferred by a step 10 was ahead of 12, profiles/round2_sweep_d_config4_xr*.json vs
+	   round2_sweep_o_config4_xr*.json); the window passes, which carry two target rings and more registers, are fastest at 8 */
 	int32_t xrcap = 8;
 	{
 		const char* e = getenv("SSW_GPU_XLANES"); if (e && atoi(e) == 16) xlanes = 16;

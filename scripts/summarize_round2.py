@@ -51,7 +51,7 @@ with open(os.path.join(out_dir, "round2_pmc.csv"), "w") as f:
                            "where kernel_name like '%k_%' group by kernel_name, counter_name order by kernel_name, counter_name"):
             f.write("%s,\"%s\",%s,%d,%.6g,%.6g,%.0f\n" % (name, r[0], r[1], r[2], r[3], r[4], r[5]))
             cfg = int(name[3])
-            if dominant[cfg] in r[0] and "true" not in r[0].split("<")[-1][:12] and r[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+            if dominant[cfg] in r[0] and not ("k_chainq" in r[0] and ", true," in r[0]) and r[1] in ("FETCH_SIZE", "WRITE_SIZE"):   # (window passes of the strip kernel excluded)
                 sums.setdefault(cfg, {}).setdefault(r[1], 0.0)
                 sums[cfg][r[1]] += r[3]
 for cfg, v in sums.items():
