@@ -2,6 +2,8 @@
 score1 / score2 / ref_end1 / read_end1 / ref_end2 of a plain ssw_gpu_align_batch over the same queries and targets --
 which the parity tests pin to the reference -- whatever the chunk size, also when the fused kernel does not cover the
 batch (a query above 640 residues -> generic path), and must stop when the caller's function says so."""
+import os
+
 import numpy as np
 import pytest
 
@@ -132,3 +134,40 @@ def test_f16_form_limit_and_int16_repeat_emulated(ectx, monkeypatch):
 @pytest.mark.gpu
 def test_f16_form_limit_and_int16_repeat_gpu(gpu_ctx, monkeypatch):
     _f16_limit_check(gpu_ctx, monkeypatch)
+
+
+def _streamed_pause_check(ctx_factory):
+    """a database searched against itself, streamed in small chunks: the self-hits above 2048 make most workgroups of the first
+    chunks repeat in the int16 form, the library then starts the following chunks in the int16 form -- same records either way"""
+    seqs, mat = _f16_limit_case()
+    seqs = (seqs[:5] + seqs[8:9]) * 2        # 12 entries, long self-hits in every chunk of 3
+    own = ctx_factory()
+    Q = own.upload(seqs); T = own.upload(seqs)
+    try:
+        hits = own.search_db(Q, T, mat, 5, 3, 1, -1, 2, 3)
+        tm = own.timing()
+        res, _ = own.align_batch(Q, T, mat, 5, 3, 1, 0, 0, 0, -1, 2)
+    finally:
+        Q.free(); T.free(); own.close()
+    _same(hits, res)
+    assert "f16 first" in tm["fill_kernel"] and tm["db_repeats"] > 0      # it started with the f16 form and noticed
+    forced = ctx_factory()                  # the same with the f16 form forced in every chunk: more repeats
+    os.environ["SSW_GPU_DB_F16"] = "1"
+    try:
+        Q = forced.upload(seqs); T = forced.upload(seqs)
+        hits2 = forced.search_db(Q, T, mat, 5, 3, 1, -1, 2, 3)
+        tm2 = forced.timing()
+        Q.free(); T.free()
+    finally:
+        del os.environ["SSW_GPU_DB_F16"]; forced.close()
+    _same(hits2, res)
+    assert tm["db_repeats"] < tm2["db_repeats"], (tm, tm2)
+
+
+def test_streamed_search_pauses_f16_form_emulated(emu_lib_path):
+    _streamed_pause_check(lambda: ssw_amd.Context(0, ssw_amd.load(emu_lib_path)))
+
+
+@pytest.mark.gpu
+def test_streamed_search_pauses_f16_form_gpu(gpu_ctx):
+    _streamed_pause_check(lambda: ssw_amd.Context(0, gpu_ctx.lib))
