@@ -100,20 +100,19 @@ def _f16_limit_case():
 
 def _f16_limit_check(ctx, monkeypatch):
     seqs, mat = _f16_limit_case()
-    for _ in range(1):
-        monkeypatch.setenv("SSW_GPU_DB_F16", "1")          # f16 form first in every call (most workgroups of this case repeat: the library would pause it)
-        res = _case(ctx, seqs, seqs, mat, 5, 3, 1, chunks=(4, 0))
-        s = np.array([[int(res["score1"][i, j]) for j in range(6)] for i in range(6)])
-        assert s[2, 2] == 2047 and s[3, 3] == 2048 and s[4, 4] == 2049 and s[5, 5] == 2051 and s[0, 5] == 2044
-        assert int(res["score1"][6, 6]) == 2600
-        tm = ctx.timing()
-        assert "f16 first" in tm["fill_kernel"] and tm["db_repeats"] > 0, tm
-        monkeypatch.setenv("SSW_GPU_DB_F16", "0")          # the int16 form alone gives the same records
-        res2 = _case(ctx, seqs, seqs, mat, 5, 3, 1, chunks=(0,), check_ref=False)
-        assert ctx.timing()["db_repeats"] == 0
-        monkeypatch.delenv("SSW_GPU_DB_F16")
-        for f in ("score1", "score2", "ref_end1", "read_end1", "ref_end2"):
-            assert (res2[f] == res[f]).all(), f
+    monkeypatch.setenv("SSW_GPU_DB_F16", "1")          # f16 form first in every call (most workgroups of this case repeat: the library would pause it)
+    res = _case(ctx, seqs, seqs, mat, 5, 3, 1, chunks=(4, 0))
+    s = np.array([[int(res["score1"][i, j]) for j in range(6)] for i in range(6)])
+    assert s[2, 2] == 2047 and s[3, 3] == 2048 and s[4, 4] == 2049 and s[5, 5] == 2051 and s[0, 5] == 2044
+    assert int(res["score1"][6, 6]) == 2600
+    tm = ctx.timing()
+    assert "f16 first" in tm["fill_kernel"] and tm["db_repeats"] > 0, tm
+    monkeypatch.setenv("SSW_GPU_DB_F16", "0")          # the int16 form alone gives the same records
+    res2 = _case(ctx, seqs, seqs, mat, 5, 3, 1, chunks=(0,), check_ref=False)
+    assert ctx.timing()["db_repeats"] == 0
+    monkeypatch.delenv("SSW_GPU_DB_F16")
+    for f in ("score1", "score2", "ref_end1", "read_end1", "ref_end2"):
+        assert (res2[f] == res[f]).all(), f
     # left to itself the library notices the repeats and pauses the f16 form on this context
     own = ssw_amd.Context(0, ctx.lib)          # (a context of its own: the pause would outlive this test on the shared one)
     Q = own.upload(seqs); T = own.upload(seqs)
