@@ -50,6 +50,8 @@ SSW_DEV u32 xl_shfl(u32 v, int src_lane) { return (u32)__shfl((int)v, src_lane, 
 SSW_DEV bool wave_any(bool p) { return __any(p) != 0; }
 SSW_DEV bool wave_all(bool p) { return __all(p) != 0; }
 SSW_DEV unsigned long long wave_ballot(bool p) { return __ballot(p); }
+/* register budget of a kernel as wavefronts per SIMD (512 / n registers per lane); the emulator build ignores it */
+#define SSW_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 /* `v`, but not before `dep` exists: an opaque data dependency for the instruction scheduler (no instruction is emitted).  Keeps a
    load that refills registers from being hoisted above the last use of their old contents (which doubles the registers). */
 SSW_DEV u32 after(u32 v, u32 dep) { asm("" : "+v"(v) : "v"(dep)); return v; }

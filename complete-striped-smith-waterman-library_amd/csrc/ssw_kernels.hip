@@ -173,7 +173,7 @@ SSW_DEV void fill_flush16(unsigned char* lds, u32 out16, u32 out8, int base, int
 	const int tc = base + l16;
 	u32 i16 = 0, i8 = 0;
 	if (tc >= store_from && tc < ncols) {
-		const u32 v16 = lds_ld32(lds, out16 + 4u * (tc & 63)), v8 = lds_ld32(lds, out8 + 4u * ((tc - (15 - G::TAP)) & 63));
+		const u32 v16 = lds_ld32(lds, out16 + 4u * ((tc + 15) & 63)), v8 = lds_ld32(lds, out8 + 4u * ((tc + G::TAP) & 63));
 		i16 = F16 ? pkf_to_int2(v16) : v16;
 		i8 = F16 ? pkf_to_int2(v8) : v8;
 		o16[tc] = i16;
@@ -193,8 +193,10 @@ SSW_DEV void fill_flush16(unsigned char* lds, u32 out16, u32 out8, int base, int
  * k_fill: forward fill, column maxima only.  grid = npairs * bpp workgroups of 256 threads.
  * ================================================================================================ */
 /* FORM 0: int16, 9 instructions per row; 1: f16 (scores < 2048), 7.5; 2: int16 with the two-row column maximum (scores < 31744), 8.5 */
+/* (up to 10 rows per lane the kernel is held to 72 registers -- seven wavefronts per SIMD; hipcc otherwise takes 74, i.e. 80, and
+   the one spill this costs is a pointer reloaded once per 16 steps) */
 template <int R, int FORM>
-__global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
+__global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fill(ssw_fill_args a)
 {
 	constexpr bool F16 = FORM == 1;
 	typedef ChainGeom<R> G;
@@ -274,8 +276,10 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 		if (s0 >= 32) fill_flush16<R, F16>(lds, out16, out8, s0 - 32, l16, store_from, ncols, o16, o8, g16, g8);   /* columns [s0-32, s0-16) are complete in the out rings */
 		wave_lds_fence();
 		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
-		/* lane 0 parks finished maxima: column s-16 (all rows) and column s-1-TAP (rows < A8, stored in the slot of s-16) */
-		const u32 ob16 = out16 + 4u * (u32)((s0 - 16) & 63), ob8 = out8 + 4u * (u32)((s0 - 16) & 63);
+		/* the lanes that FINISH a maximum park it themselves, in the slot of the step: lane 15 the column's (all rows; its column is
+		   s - 15), lane TAP the one of the rows < A8 (its column is s - TAP) -- nothing travels back to lane 0, whose column starts
+		   from the zero the row_shr move fills in */
+		const u32 ob16 = out16 + 4u * (u32)(s0 & 63), ob8 = out8 + 4u * (u32)(s0 & 63);
 #pragma unroll
 		for (int j = 0; j < 16; ++j) {
 			const u32 paddr = lds_ld16(lds, rp + 2u * j) + lane_prof;
@@ -284,16 +288,15 @@ __global__ void __launch_bounds__(256) k_fill(ssw_fill_args a)
 			for (int c = 0; c < C; ++c) sc[c] = lds_ld128(lds, paddr + 256u * c);
 			const u32 hin = xl_row_shr1_zero(Hlast);
 			u32 f = xl_row_shr1_zero(Fout);
-			const u32 x = xl_row_ror<1>(cmout);
-			const u32 x8 = xl_row_ror<16 - G::TAP>(ck);
-			u32 cm = x;
-			if (l16 == 0) {
-				lds_st32(lds, ob16 + 4u * j, x);
-				lds_st32(lds, ob8 + 4u * j, x8);
-				cm = 0;
-			}
+			u32 cm = xl_row_shr1_zero(cmout);      /* this column's maximum of the rows above */
 			chain_rows<R, true, F16, FORM == 2>(sc, H, E, hsave, f, cm, ck, gO, gE);
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
+			if (G::TAP == 15) {
+				if (l16 == 15) { lds_st32(lds, ob16 + 4u * j, cm); lds_st32(lds, ob8 + 4u * j, ck); }
+			} else {
+				if (l16 == 15) lds_st32(lds, ob16 + 4u * j, cm);
+				if (l16 == G::TAP) lds_st32(lds, ob8 + 4u * j, ck);
+			}
 		}
 	}
 	wave_lds_fence();
@@ -503,7 +506,7 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 		if (s0 >= 32) {
 			const int tc = s0 - 32 + l16;
 			if (tc < ncols) {
-				const u32 v16 = lds_ld32(lds, out16 + 4u * ((u32)tc & OM)), v8 = lds_ld32(lds, out8 + 4u * ((u32)(tc - (15 - G::TAP)) & OM));
+				const u32 v16 = lds_ld32(lds, out16 + 4u * ((u32)(tc + 15) & OM)), v8 = lds_ld32(lds, out8 + 4u * ((u32)(tc + G::TAP) & OM));
 				o16[tc] = F16 ? pkf_to_int2(v16) : v16;
 				o8[tc] = F16 ? pkf_to_int2(v8) : v8;
 			}
@@ -519,21 +522,14 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 			}
 		}
 		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
-		const u32 ob16 = out16 + 4u * ((u32)(s0 - 16) & OM), ob8 = out8 + 4u * ((u32)(s0 - 16) & OM);
+		const u32 ob16 = out16 + 4u * ((u32)s0 & OM), ob8 = out8 + 4u * ((u32)s0 & OM);      /* lanes 15 / TAP park what they finish (k_fill) */
 #pragma unroll UNROLL
 		for (int j = 0; j < 16; ++j) {
 			const int tc = s0 + j - l16;
 			const u32 pa_next = lds_ld16(lds, rp + 2u * (j + 2));      /* the ring entry of step s + 2 */
 			const u32 hin = xl_row_shr1_zero(Hlast);
 			u32 f = xl_row_shr1_zero(Fout);
-			const u32 x = xl_row_ror<1>(cmout);
-			const u32 x8 = xl_row_ror<16 - G::TAP>(ck);
-			u32 cm = x;                  /* this column's maximum of the rows above (lane 0 starts a new column) */
-			if (l16 == 0) {
-				lds_st32(lds, ob16 + 4u * j, x);
-				lds_st32(lds, ob8 + 4u * j, x8);
-				cm = 0;
-			}
+			u32 cm = xl_row_shr1_zero(cmout);      /* this column's maximum of the rows above (lane 0 starts a new column with 0) */
 			/* best cell: `pre` = the lane's running record and the rows above in this column; only the lane whose OWN rows
 			   beat it -- the lane holding the new record cell, not every lane below -- takes the branch further down */
 			const u32 pre = pk_max(best, cm);
@@ -541,6 +537,12 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 			pa_n = pa_next + lane_prof;
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
 			best = pk_max(best, cm);     /* = max(pre, own rows) */
+			if (G::TAP == 15) {
+				if (l16 == 15) { lds_st32(lds, ob16 + 4u * j, cm); lds_st32(lds, ob8 + 4u * j, ck); }
+			} else {
+				if (l16 == 15) lds_st32(lds, ob16 + 4u * j, cm);
+				if (l16 == G::TAP) lds_st32(lds, ob8 + 4u * j, ck);
+			}
 			/* (columns outside the target score "dead": H = max(E, F) there, which decays and never sets a record) */
 			if (wave_any(best != pre)) db_record<R>(best, pre, tc, H, snap, btc2);   /* a scalar branch: hipcc otherwise if-converts half of the row search into every step */
 		}
@@ -572,7 +574,7 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 	for (int base = nsteps - 32; base < nsteps; base += 16) {
 		const int tc = base + l16;
 		if (tc >= 0 && tc < ncols) {
-			const u32 v16 = lds_ld32(lds, out16 + 4u * ((u32)tc & OM)), v8 = lds_ld32(lds, out8 + 4u * ((u32)(tc - (15 - G::TAP)) & OM));
+			const u32 v16 = lds_ld32(lds, out16 + 4u * ((u32)(tc + 15) & OM)), v8 = lds_ld32(lds, out8 + 4u * ((u32)(tc + G::TAP) & OM));
 			o16[tc] = F16 ? pkf_to_int2(v16) : v16;
 			o8[tc] = F16 ? pkf_to_int2(v8) : v8;
 		}

@@ -1,6 +1,6 @@
 # round 2, final evidence on the final kernel source (after the k_filldb / strip-kernel work of calls K-O): GPU suite, the PMC /
 # kernel-trace passes, bench lines of configs 2-5 at their stated sizes + the side lines (flag 2, in-library work queues, two
-# ranks on the one device, the lane-model kernel), SQ counters of config 4 at full size, two more strip geometries
+# ranks on the one device, the lane-model kernel), SQ counters of config 4 at full size
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -15,7 +15,6 @@ timeout 200 python bench.py --config 2 --flag 2 --steps 1 --cpu-sample 0 > gpuru
 timeout 200 python bench.py --pool 2 --steps 1 --cpu-sample 0 > gpurun_out/final3_pool2.log 2>&1; echo "pool rc=$?"
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --config 3 --steps 1 --warmup 1 --cpu-sample 0 > gpurun_out/final3_config3_2ranks_one_gpu.log 2>&1; echo "2 ranks rc=$?"
 timeout 200 python bench.py --reads 2000 --gap-open 1 --gap-extend 1 --steps 1 --warmup 1 --cpu-sample 200 > gpurun_out/final3_literal.log 2>&1; echo "literal rc=$?"
-for xr in 14 16; do SSW_GPU_XR=$xr timeout 150 python bench.py --config 4 --steps 2 --warmup 1 --cpu-sample 0 > gpurun_out/final3_config4_xr$xr.log 2>&1; done
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/final3_*.log")):

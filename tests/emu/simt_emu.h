@@ -140,6 +140,7 @@ SSW_DEV bool wave_any(bool p)
 }
 SSW_DEV bool wave_all(bool p) { return !wave_any(!p); }
 SSW_DEV void sched_fence() {}
+#define SSW_WAVES_PER_EU(lo, hi)
 SSW_DEV u32 after(u32 v, u32 dep) { (void)dep; return v; }
 SSW_DEV u32 opaque(u32 v) { return v; }
 SSW_DEV unsigned long long wave_ballot(bool p)
