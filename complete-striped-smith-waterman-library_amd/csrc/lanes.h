@@ -142,8 +142,9 @@ SSW_DEV u32 pk_perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, 
 #define PK_HI2 0x07060302u
 /* packed 2 x f16 arithmetic on scores scaled by 1/2048 (k/2048 is exact in f16 for every integer |k| <= 2048, and so are sums
    and differences of such values): `clamp` (result -> [0, 1]) is the max(0, .) of local alignment for free, and gfx950's
-   v_pk_maximum3_f16 takes three inputs -- together one instruction less per DP cell than the int16 form.  Only used when
-   no score can reach 2048 (see k_fill). */
+   v_pk_maximum3_f16 takes three inputs -- together one instruction less per DP cell than the int16 form.  Used where
+   no score can reach 2048 (k_fill: the host checks the bucket), or where reaching it is detected and repaired (k_filldb: the form
+   saturates at 2048, a workgroup that sees a best cell there repeats in the int16 form). */
 #ifdef SSW_SIMT_EMU
 /* emulation through exact integer tables (every value that occurs is k/2048): f16 bits -> k and k -> f16 bits */
 struct emu_f16_tables {
