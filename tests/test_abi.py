@@ -68,3 +68,20 @@ def test_no_device_fails_loudly(product_lib_path):
         pytest.skip("a device is present")
     with pytest.raises(RuntimeError, match="no HIP device"):
         ssw_amd.Context(0, lib)
+
+
+def test_ctypes_mirrors_match_the_c_header(tmp_path):
+    """the Python binding's structures (ssw_amd.py) have the sizes the C compiler gives include/ssw_gpu.h's"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "complete-striped-smith-waterman-library_amd"))
+    import ssw_amd
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "ssw_gpu.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu\\n", sizeof(ssw_gpu_timing), sizeof(ssw_gpu_result), sizeof(ssw_gpu_hit), sizeof(ssw_gpu_params)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    t, r, h, p = (int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
+    assert C.sizeof(ssw_amd.Timing) == t
+    assert ssw_amd.HIT_DTYPE.itemsize == h
+    assert ssw_amd.RESULT_DTYPE.itemsize == r and C.sizeof(ssw_amd.Result) == r
+    assert C.sizeof(ssw_amd.Params) == p
