@@ -424,7 +424,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 	int64_t wgs_f16[2] = { 0, 0 }; int32_t reruns_seen = 0;      /* per result buffer: f16 workgroups launched for the chunk it holds */
 	if (!d_tl_all || (ds && (!d_cnt_s || ssw_shim_memset(d_cnt_s, 0, DB_COUNTERS * sizeof(int32_t), c->stream)))) { fail(c, "device allocation failed: %s", ssw_shim_last_error()); goto done; }
 	int32_t prev_t0 = -1, prev_nt = 0, chunk_i = 0;
-	int64_t db_cells[64]; memset(db_cells, 0, sizeof db_cells);      /* per bucket (nb <= 24 short buckets + 4 size classes) */
+	int64_t db_cells[64]; memset(db_cells, 0, sizeof db_cells);      /* per bucket (nb <= 24 short buckets + up to 16 classes of 385..640 residues) */
 	for (int32_t t0 = 0; t0 < tcount; t0 += (int32_t)tsub, ++chunk_i) {
 		const int32_t nt = tcount - t0 < tsub ? tcount - t0 : (int32_t)tsub;
 		int32_t* const tl = tl_all + t0;
