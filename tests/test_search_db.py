@@ -170,3 +170,42 @@ def test_streamed_search_pauses_f16_form_emulated(emu_lib_path):
 @pytest.mark.gpu
 def test_streamed_search_pauses_f16_form_gpu(gpu_ctx):
     _streamed_pause_check(lambda: ssw_amd.Context(0, gpu_ctx.lib))
+
+
+# ---- random scoring systems through the fused kernel (f16 form first): matrices up to its limit of 49, large gap penalties, all
+#      three score_size modes, short mask lengths -- against the reference, pair by pair
+def _random_db_sweep(ctx, seeds, nq, nt, maxlen):
+    for seed in seeds:
+        rng = np.random.default_rng(1000 + seed)
+        n = int(rng.choice([4, 5, 12, 24]))
+        hi = int(rng.choice([2, 5, 15, 49]))
+        mat = rng.integers(-min(hi, 20), hi + 1, size=(n, n)).astype(np.int8)
+        mat = np.maximum(mat, mat.T)                       # symmetric like real matrices (not required, just typical)
+        for k in range(n): mat[k, k] = max(1, int(rng.integers(1, hi + 1)))
+        gapE = int(rng.integers(1, 6)); gapO = gapE + int(rng.integers(1, 12))
+        ss = int(rng.choice([0, 1, 2])); maskLen = int(rng.choice([-1, 15, 8, 40]))
+        base = rng.integers(0, n, size=maxlen, dtype=np.int8)
+        def seq():
+            L = int(rng.integers(1, maxlen + 1))
+            if rng.random() < 0.5:                         # related to the base sequence: high scores, long diagonals
+                o = int(rng.integers(0, maxlen - L + 1)); s = base[o:o + L].copy()
+                flip = rng.random(L) < 0.1; s[flip] = rng.integers(0, n, size=int(flip.sum()), dtype=np.int8)
+                return np.ascontiguousarray(s)
+            return rng.integers(0, n, size=L, dtype=np.int8)
+        qs = [seq() for _ in range(nq)]; db = [seq() for _ in range(nt)]
+        Q = ctx.upload(qs); T = ctx.upload(db)
+        try:
+            res, cig = ctx.align_batch(Q, T, np.ascontiguousarray(mat.reshape(-1)), n, gapO, gapE, 0, 0, 0, maskLen, ss)
+        finally:
+            Q.free(); T.free()
+        bad = compare_batch(res, cig, qs, db, np.ascontiguousarray(mat.reshape(-1)), n, gapO, gapE, 0, 0, 0, maskLen, ss)
+        assert not bad, "seed %d (n %d, max %d, gaps %d/%d, score_size %d, maskLen %d):\n%s" % (seed, n, hi, gapO, gapE, ss, maskLen, "\n".join(bad[:8]))
+
+
+def test_random_scoring_systems_database_path_emulated(ectx):
+    _random_db_sweep(ectx, range(24), nq=6, nt=8, maxlen=150)
+
+
+@pytest.mark.gpu
+def test_random_scoring_systems_database_path_gpu(gpu_ctx):
+    _random_db_sweep(gpu_ctx, range(200), nq=24, nt=40, maxlen=420)
