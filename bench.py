@@ -14,7 +14,12 @@ reduction, read_end1 / begin position, traceback where the flag asks for it, res
 rank works on its own block against a replicated target / DB: no collective on the data path, weak scaling.  GCUPS counts
 readLen x refLen of the forward matrix only.
 
+`python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself (torch.distributed.run on 127.0.0.1, one
+process per GPU -- what the driver's command line does); under a launcher the ranks are used as they are.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields:
+  also            (default run of the metric's config on one GPU) BASELINE configs 3, 4 and 5 run for a few steps each AFTER the
+                  timed region: rate, roofline fraction of their fill kernel, parity against tests/golden/full
   roofline        HBM view of the dominant fill kernel: algorithmic bytes per launch / mean launch time (HIP events on the
                   library's stream), `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes of THIS kernel
                   source (profiles/round2_traffic.json; null when the source changed since)
@@ -108,8 +113,12 @@ def parse_args(argv=None):
     ap.add_argument("--pool", type=int, default=0,
                     help="> 0: drive the batch through the library's per-GPU work queues (ssw_gpu_pool) with this many workers "
                          "spread over the visible devices, reads on the host (single process)")
+    ap.add_argument("--also", default=None,
+                    help="comma-separated other BASELINE configs run for 2 steps each AFTER the timed region and attached to the line as "
+                         "`also` (default: 3,4,5 when the metric's config runs as stated on one GPU; 'none' to skip)")
     ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)   # tests point this at the emulated library
     a = ap.parse_args(argv)
+    a.quiet = False
     a.custom = any(getattr(a, k) is not None for k in ("read_len", "ref_len", "sub", "indel")) or (a.match, a.mismatch, a.gap_open, a.gap_extend) != (2, 2, 3, 1)
     if a.steps is None:
         a.steps = {2: 2, 3: 2, 4: 1, 5: 1}[a.config]
@@ -285,7 +294,7 @@ def bench_dna(args, world, rank, local_rank, dist):
                                             "`frac` counts every evaluated cell (padding rows, halo columns), `frac_on_real_cells` only readLen x refLen",
                                     "fill_gcups_padded": round(acc["fill_cells"] / (acc["fill_ms"] * 1e-3) / 1e9, 1) if acc["fill_ms"] > 0 else 0.0}
             # PCIe-inclusive rate: one more step with the reads uploaded (and freed) inside it
-            if world == 1:
+            if world == 1 and not args.quiet:
                 t1 = time.perf_counter()
                 Q2 = upload_reads()
                 step(Q2)
@@ -355,8 +364,10 @@ def bench_dna(args, world, rank, local_rank, dist):
                 out["cpu_baseline"] = {"value": round(ns * rlen * p["ref_len"] / secs / 1e9, 3), "unit": "GCUPS", "cores": 1,
                                        "kind": "port", "sample": "%d reads, scalar lane-model oracle (oracle/_ref not shipped)" % ns}
                 out.setdefault("parity", {"sample": ns, "mismatching_alignments": mism})
-        print(json.dumps(out))
-        sys.stdout.flush()
+        if not args.quiet:
+            attach_also(args, out, world)
+            print(json.dumps(out))
+            sys.stdout.flush()
     dump = os.environ.get("SSW_BENCH_DUMP")
     if dump:   # tests: keep every rank's shard and results for an independent check
         np.savez(os.path.join(dump, "rank%d.npz" % rank), reads=reads, ref=ref, res=res)
@@ -515,8 +526,9 @@ def bench_db(args, world, rank, local_rank, dist):
                 par.setdefault("mismatching_alignments", par["cpu_sample"]["mismatching_alignments"])
             if par:
                 out["parity"] = par
-        print(json.dumps(out))
-        sys.stdout.flush()
+        if not args.quiet:
+            print(json.dumps(out))
+            sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -524,13 +536,63 @@ def bench_db(args, world, rank, local_rank, dist):
     return out, state.get("kept")
 
 
+def attach_also(args, out, world):
+    """The driver-run line is BASELINE config 2; the other configs (3: 5 Mb target, 4: long reads with traceback, 5: protein database
+    search) run for a few steps each AFTER the timed region -- `value` / `ms_per_step` above are not touched -- and their rate,
+    roofline fraction and parity against the committed full-size fixtures go into `also`."""
+    which = args.also
+    if which is None:
+        which = "3,4,5" if (args.config == 2 and world == 1 and not args.custom and args.pool == 0 and args.lib is None and
+                            all(getattr(args, k) is None for k in ("reads", "flag", "mask_len"))) else "none"
+    if which in ("none", ""):
+        return
+    also = {}
+    t0 = time.perf_counter()
+    for c in [int(x) for x in which.split(",")]:
+        sub = parse_args(["--config", str(c), "--steps", "1" if c == 5 else "2", "--warmup", "0" if c == 5 else "1", "--cpu-sample", "0"] +
+                         (["--lib", args.lib] if args.lib else []))
+        if args.lib:        # (tests on the emulator: small shapes)
+            sub = parse_args(["--config", str(c), "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--lib", args.lib] +
+                             (["--reads", "24", "--db-targets", "9", "--db-chunk", "4"] if c == 5 else
+                              ["--reads", "4", "--ref-len", "3000", "--read-len", "700" if c == 4 else "90"]))
+        sub.quiet = True
+        try:
+            o, _ = bench_db(sub, 1, 0, 0, None) if c == 5 else bench_dna(sub, 1, 0, 0, None)
+            also["config%d" % c] = {"value": o["value"], "unit": "GCUPS", "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
+                                    "workload": o["config"]["workload"], "dtype": o["dtype"],
+                                    "fill_kernel": o.get("roofline", {}).get("kernel"),
+                                    "roofline_valu_frac": o.get("roofline_valu", {}).get("frac"),
+                                    "roofline_valu_frac_on_real_cells": o.get("roofline_valu", {}).get("frac_on_real_cells"),
+                                    "roofline_hbm_frac": o.get("roofline", {}).get("frac"),
+                                    "phases_ms_per_step": o.get("phases_ms_per_step"), "parity": o.get("parity")}
+        except Exception as e:      # the metric's line must survive a failure here
+            also["config%d" % c] = {"error": "%s: %s" % (type(e).__name__, e)}
+    also["seconds"] = round(time.perf_counter() - t0, 1)
+    also["note"] = "run after the timed region of the metric's config, same process and device; parity = the GPU results of these runs against tests/golden/full"
+    out["also"] = also
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU under
+    torch.distributed.run on 127.0.0.1, exactly what the driver's command line does) and pass rank 0's line through.  With fewer
+    visible devices than ranks, rank r uses device r mod devices (the ranks then share GPUs: a plumbing check, not a scaling number)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
 def main(argv=None):
     args = parse_args(argv)
     world, rank, local_rank, dist = init_dist()
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus),
-              file=sys.stderr)
-        sys.exit(2)
+    if args.gpus != world and world == 1 and args.gpus > 1 and args.pool == 0:
+        self_launch(args, argv)
     if args.config == 5:
         return bench_db(args, world, rank, local_rank, dist)
     return bench_dna(args, world, rank, local_rank, dist)

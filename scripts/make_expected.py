@@ -4,8 +4,8 @@ unmodified reference -- oracle/_ref/libssw_ref.so, built from /root/reference/sr
 seeded workloads of tests/workloads.py, and committed as compressed fixtures under tests/golden/full/.
 
   config2_block0.npz  all 100 000 reads of BASELINE config 2, flag 2 (scores, ends, begins, CIGAR length + FNV-1a of the CIGAR)
-  config3_block0.npz  first 10 000 reads of read block 0 of config 3 (5 Mb target), flag 2
-  config4_block0.npz  first 1 500 reads of config 4 (10 kb reads, 100 kb target, maskLen 5000), flag 2
+  config3_block0.npz  all 20 000 reads of read block 0 of config 3 (5 Mb target), flag 2
+  config4_block0.npz  first 5 000 reads of config 4 (10 kb reads, 100 kb target, maskLen 5000), flag 2
   config5_block0.npz  first 2 048 queries of query block 0 against all 10 000 DB entries (2.05e7 alignments): one 64-bit
                       checksum per query over its 10 000 x (score1 score2 ref_end1 read_end1 ref_end2), full records of
                       the first 16 queries
@@ -93,9 +93,9 @@ def main():
         if cfg == 2:
             run_dna(R, 2, 100_000, threads)
         elif cfg == 3:
-            run_dna(R, 3, 10_000, threads)
+            run_dna(R, 3, 20_000, threads)
         elif cfg == 4:
-            run_dna(R, 4, 1_500, threads)
+            run_dna(R, 4, 5_000, threads)
         elif cfg == 5:
             run_protein(R, 2048, threads)
         elif cfg == 50:

@@ -67,3 +67,32 @@ def test_pool_mode_of_bench_on_two_pretend_devices(emu_lib_path):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["config"]["pool_workers"] == 2 and [s["device"] for s in out["pool_stats"]] == [0, 1]
     assert sum(s["queries"] for s in out["pool_stats"]) == 12 and out["parity"]["mismatching_alignments"] == 0
+
+
+def test_gpus_flag_without_a_launcher_starts_the_ranks_itself(emu_lib_path):
+    """`python bench.py --gpus 2` as a plain command (no torch.distributed.run around it): bench.py launches the two ranks itself and
+    rank 0's single line comes through with n_gpus 2"""
+    env = dict(os.environ, SSW_BENCH_BACKEND="gloo", SSW_EMU_DEVICES="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--reads", "4", "--ref-len", "2000",
+           "--read-len", "60", "--cpu-sample", "0", "--lib", emu_lib_path]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["reads_per_gpu"] == 4 and "also" not in out
+
+
+def test_also_block_carries_the_other_configs(emu_lib_path):
+    """the metric's line with configs 3, 4 and 5 attached (`also`): here on the emulator with toy shapes, on the GPU at the stated sizes"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "3", "--ref-len", "2000", "--read-len", "60",
+           "--cpu-sample", "0", "--also", "3,4,5", "--lib", emu_lib_path]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and set(out["also"]) >= {"config3", "config4", "config5"}
+    for c in ("config3", "config4", "config5"):
+        assert "error" not in out["also"][c], out["also"][c]
+        assert out["also"][c]["ms_per_step"] > 0 and out["also"][c]["fill_kernel"]
