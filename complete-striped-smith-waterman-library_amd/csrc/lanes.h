@@ -269,6 +269,37 @@ SSW_DEV u32 pk_max3_nonneg(u32 a, u32 b, u32 c)
 	                                                             __builtin_bit_cast(f16x2, c)));
 }
 #endif
+/* ---- column frame: every stored value carries + phi(column), phi growing by gapE per column.  Then E needs no
+   decrement, every add / subtract of the recurrence is a PLAIN 32-bit add on the packed pair (no carry can cross the halves: all
+   live values are non-negative 15-bit numbers) -- v_add_u32 issues in 2 cycles where every VOP3P takes 4 -- and the maxima are
+   v_pk_maximum3_f16 on the bit patterns (non-negative int16 below 0x7C00 are positive finite binary16 numbers in the same order).
+   The one operand that may be "negative" is diag + score of a dead row / null column: pattern 0x8000 + value, a negative finite
+   binary16 number, which loses against the other two.  The emulation takes the halves as signed 16-bit integers (same outcome:
+   at most the first operand has bit 15 set). */
+#ifdef SSW_SIMT_EMU
+SSW_DEV u32 pk_max3_fr(u32 a, u32 b, u32 c)
+{
+	for (int h = 0; h < 32; h += 16) {   /* no infinity / NaN pattern in any operand; only the first may be "negative" */
+		const u32 x = (a >> h) & 0xffffu, y = (b >> h) & 0xffffu, z = (c >> h) & 0xffffu;
+		if ((x & 0x7c00u) == 0x7c00u || y >= 0x7c00u || z >= 0x7c00u) emu::fail("pk_max3_fr: operand outside the range of the frame form");
+	}
+	const int al = (short)(a & 0xffffu), ah = (short)(a >> 16);
+	int lo = al > (int)(b & 0xffffu) ? al : (int)(b & 0xffffu), hi = ah > (int)(b >> 16) ? ah : (int)(b >> 16);
+	lo = (int)(c & 0xffffu) > lo ? (int)(c & 0xffffu) : lo; hi = (int)(c >> 16) > hi ? (int)(c >> 16) : hi;
+	return (u32)lo | ((u32)hi << 16);
+}
+#else
+SSW_DEV u32 pk_max3_fr(u32 a, u32 b, u32 c) { return pk_max3_nonneg(a, b, c); }
+#endif
+/* packed profile entry of the frame form: each half is a small signed score (live row) or FR_DEAD (+32768 as an unsigned addend:
+   diag + 0x8000 has bit 15 set and never carries).  A negative low half borrows from the high half here and gives the carry back
+   at run time (diag + score >= 0 for every live row), so the packed sum is exact in both halves. */
+#define FR_DEAD 32768
+SSW_DEV u32 fr_pack(int lo, int hi) { return (u32)lo + ((u32)hi << 16); }
+SSW_DEV u32 umax32(u32 a, u32 b) { return a > b ? a : b; }
+/* phi of the column that lane `lane` of a GL-lane chain works on at step `step`: base + ((step mod K) + GL - lane) * gapE (all
+   registers drop by K * gapE when step reaches a multiple of K) */
+SSW_DEV int fr_phi(int step, int lane, int GL, int base, int kmask, int gapE) { return base + ((step & kmask) + GL - lane) * gapE; }
 SSW_DEV u32 pk_dup(int v) { return ((u32)v & 0xffffu) * 0x10001u; }
 SSW_DEV u32 pk_make(int lo, int hi) { return ((u32)lo & 0xffffu) | ((u32)hi << 16); }
 

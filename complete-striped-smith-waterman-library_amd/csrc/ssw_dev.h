@@ -61,7 +61,9 @@ typedef struct {
 	uint32_t* sg8;           /* ... and of cm8 (k_reduce_seg scans these instead of the columns) */
 	int64_t seg_stride;
 	int32_t f16;             /* form of the recurrence: 1: no score can reach 2048 -> f16 (scores / 2048, exact), 7.5 instructions per row;
-	                            2: no score can reach 31744 -> int16 with a two-row column maximum, 8.5; 0: plain int16, 9 */
+	                            2: no score can reach 31744 -> int16 with a two-row column maximum, 8.5; 0: plain int16, 9;
+	                            3: column frame (ssw_frame_params says when), 6.5 of which 3 are 2-cycle 32-bit adds */
+	int32_t fr_base, fr_kmask;   /* form 3: phi(column) = fr_base + ((step & fr_kmask) + lanes - lane) * gapE */
 } ssw_fill_args;
 
 /* byte-for-byte the layout of ssw_gpu_result (include/ssw_gpu.h); checked by a static assertion in ssw_host.c */

@@ -232,6 +232,22 @@ int ssw_gpu_last_timing(const ssw_gpu_ctx* c, ssw_gpu_timing* out) { if (!c || !
 
 /* ------------------------------------------------------------------------------------------------ */
 
+/* Column-frame form (lanes.h): stored values are true value + phi(column).  For gap penalties gapO > gapE and a bucket
+   whose true scores stay <= top, picks the renormalisation period K (a power of two >= 64, K * gapE <= ~4096) and the base offset
+   so that every live operand is a non-negative number below 0x7C00; returns 0 when the bucket does not fit (plain int16 form then).
+   lanes = lanes per chain (16 or 64). */
+static int ssw_frame_params(int64_t top, int gapO, int gapE, int minmat, int lanes, int32_t* base, int32_t* kmask)
+{
+	if (gapO <= gapE || gapE < 1) return 0;
+	int K = 1024;
+	{ const char* e = getenv("SSW_GPU_FRAME_K"); if (e && atoi(e) >= 16) { K = 16; while (K * 2 <= atoi(e) && K < 1024) K <<= 1; } }   /* tests: renormalise often */
+	while (K > 64 && (int64_t)K * gapE > 4096) K >>= 1;
+	const int b = (minmat < 0 ? -minmat : 0) + gapO + 2 * gapE + 8;     /* diag + score' >= 0, F - gapE >= 0, t >= 0 */
+	if (top + b + (int64_t)(K + lanes + 2) * gapE >= 31744) return 0;
+	*base = b; *kmask = K - 1;
+	return 1;
+}
+
 static int32_t halo_for(int32_t P, int32_t maxmat, int32_t gapE)
 {
 	if (gapE <= 0) return 0x3fffffff;
@@ -645,6 +661,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 
 	int32_t bias = 0, maxmat = 0;
 	for (int32_t i = 0; i < n * n; ++i) { if (prm->mat[i] < bias) bias = prm->mat[i]; if (prm->mat[i] > maxmat) maxmat = prm->mat[i]; }
+	const int32_t minmat = bias;      /* <= 0 */
 	bias = (prm->score_size == 0 || prm->score_size == 2) ? -bias : 0;
 
 	/* bucket the queries by chain geometry, pair neighbours inside a bucket.  Empty queries take no part: the reference gives
@@ -742,8 +759,10 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 
 	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
 	double fill_ms = 0, reduce_ms = 0, locate_ms = 0, trace_ms = 0;
-	int fill_f16 = 1;
+	int fill_f16 = 1, fill_form = -1;
 	{ const char* e = getenv("SSW_GPU_FILL_F16"); if (e && e[0] == '0') fill_f16 = 0; }     /* experiment / test: int16 form everywhere */
+	{ const char* e = getenv("SSW_GPU_FILL_FORM"); if (e && e[0] >= '0' && e[0] <= '3') fill_form = e[0] - '0'; }   /* tests: cap the form of k_fill (0 int16, 1 f16, 2 int16 + max3, 3 / unset: column frame where it fits) */
+	if (!fill_f16) fill_form = 0;
 
 	{   /* database search: scores only, several short targets -> fused kernel for the short-query buckets */
 		int any_short = 0, any_long = 0; int64_t maxt = 0;
@@ -893,6 +912,10 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 					{
 						const int64_t top = (int64_t)16 * B->R * (maxmat > 0 ? maxmat : 0);     /* no cell of the bucket scores more */
 						fa.f16 = !fill_f16 ? 0 : top <= 2047 ? 1 : top < 31744 ? 2 : 0;
+						fa.fr_base = 0; fa.fr_kmask = 0;
+						if (fill_form != 0 && fill_form != 1 && fill_form != 2 &&
+						    ssw_frame_params(top, prm->gapO, prm->gapE, minmat, 16, &fa.fr_base, &fa.fr_kmask)) fa.f16 = 3;
+						else if (fill_form >= 0 && fill_form < fa.f16) fa.f16 = fill_form == 1 && top > 2047 ? fa.f16 : fill_form;
 					}
 					/* strip kernel: two-row column maximum when no score of the bucket can reach 31744 */
 					const int xform = fill_f16 && (int64_t)B->P16 * (maxmat > 0 ? maxmat : 0) < 31744 ? 2 : 0;
@@ -928,10 +951,10 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 						const int64_t lc = cols * (int64_t)(B->lanes * B->R * B->strips) * 2 * np;
 						c->tm.fill_cells += lc;
 						char nm[48];
-						if (!use_x) snprintf(nm, sizeof nm, "k_fill<%d,%s>", B->R, fa.f16 == 1 ? "f16" : fa.f16 == 2 ? "int16+max3" : "int16");
+						if (!use_x) snprintf(nm, sizeof nm, "k_fill<%d,%s>", B->R, fa.f16 == 3 ? "frame" : fa.f16 == 1 ? "f16" : fa.f16 == 2 ? "int16+max3" : "int16");
 						else if (B->lanes == 64) snprintf(nm, sizeof nm, "k_chainq<%d,%s> x %d strips", B->R, xform == 2 ? "int16+max3" : "int16", B->strips);
 						else snprintf(nm, sizeof nm, "k_chainx<%d,16 lanes> x %d strips", B->R, B->strips);
-						note_fill_kernel(c, lc, &best_fill_cells, nm, !use_x ? (fa.f16 == 1 ? 7.5 : fa.f16 == 2 ? 8.5 : 9.0) : (B->lanes == 64 && xform == 2 ? 8.5 : 9.0), B->R, B->strips);
+						note_fill_kernel(c, lc, &best_fill_cells, nm, !use_x ? (fa.f16 == 3 ? 6.5 : fa.f16 == 1 ? 7.5 : fa.f16 == 2 ? 8.5 : 9.0) : (B->lanes == 64 && xform == 2 ? 8.5 : 9.0), B->R, B->strips);
 					}
 					ssw_reduce_args ra;
 					ra.cm16 = d_cm16; ra.cm8 = d_cm8; ra.cm_stride = stride; ra.refLen = refLen; ra.pairs = fa.pairs; ra.npairs = np;

@@ -57,12 +57,14 @@ template <int R> struct ChainGeom {
 };
 
 /* build one packed profile: rows of query A in the low halves, query B in the high halves */
-template <int R, bool F16 = false>
+/* PM: 0 packed int16, 1 f16 (scores / 2048), 2 column frame (score + gapE per live row, FR_DEAD for dead rows: lanes.h) */
+template <int R, int PM = 0>
 SSW_DEV void build_profile(unsigned char* lds, u32 base, int first, int nthreads,
                            const int8_t* mat, int n,
                            const int8_t* qa, int lena, int reva,
-                           const int8_t* qb, int lenb, int p16a = 0x7fffffff, int p16b = 0x7fffffff)
+                           const int8_t* qb, int lenb, int p16a = 0x7fffffff, int p16b = 0x7fffffff, int gapE = 0)
 {
+	constexpr bool F16 = PM == 1;
 	constexpr int C = ChainGeom<R>::C;
 	const int total = (n + 1) * C * 64;
 	for (int w = first; w < total; w += nthreads) {
@@ -70,13 +72,14 @@ SSW_DEV void build_profile(unsigned char* lds, u32 base, int first, int nthreads
 		const int c = rem >> 6, l = (rem & 63) >> 2, k = rem & 3;
 		const int r = c * 4 + k, row = l * R + r;
 		u32 v;
-		if (b == n) v = F16 ? PKF_DEAD2 : DEAD2;
+		if (b == n) v = F16 ? PKF_DEAD2 : PM == 2 ? fr_pack(FR_DEAD, FR_DEAD) : DEAD2;
 		else if (r >= R) v = 0;
 		else {
 			int lo = row < p16a ? 0 : -32768, hi = row < p16b ? 0 : -32768;   /* rows below a padded query are dead */
 			if (row < lena) lo = mat[b * n + (reva ? qa[lena - 1 - row] : qa[row])];
 			if (qb && row < lenb) hi = mat[b * n + qb[row]];
-			v = F16 ? pkf_make(lo < -2048 ? -2048 : lo, hi < -2048 ? -2048 : hi) : pk_make(lo, hi);
+			if (PM == 2) v = fr_pack(lo == -32768 ? FR_DEAD : lo + gapE, hi == -32768 ? FR_DEAD : hi + gapE);
+			else v = F16 ? pkf_make(lo < -2048 ? -2048 : lo, hi < -2048 ? -2048 : hi) : pk_make(lo, hi);
 		}
 		lds_st32(lds, base + (u32)w * 4u, v);
 	}
@@ -125,11 +128,42 @@ SSW_DEV void chain_rows_cm3(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32& d, u
 	}
 }
 
-template <int R, bool TRACK8, bool F16 = false, bool CM3 = false>
+/* column-frame form of rows [R0, R1) (lanes.h): 3 plain 32-bit adds + 3.5 packed maxima per row.  c1 = gapO - gapE (packed),
+   fl = phi(column + 1): the floor that keeps E at "0" or above.
+     h = max3(d + s', E, F)        t = h - c1        E' = max3(E, t, fl)        F' = max(F, t) - gapE        cm = max3(cm, h_r, h_r+1) */
+template <int R, int R0, int R1>
+SSW_DEV void chain_rows_fr(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32& d, u32& f, u32& cm, u32 c1, u32 gapE2, u32 fl)
+{
+#pragma unroll
+	for (int r = R0; r < R1; ++r) {
+		const u32 hold = H[r];
+		const u32 h = pk_max3_fr(d + sc[r >> 2][r & 3], E[r], f);
+		const u32 t = h - c1;
+		E[r] = pk_max3_fr(E[r], t, fl);
+		f = pk_max(f, t) - gapE2;
+		if (((r - R0) & 1) == 1) cm = pk_max3_fr(cm, H[r - 1 >= 0 ? r - 1 : 0], h);      /* H[r-1] was just written: this pair's first row */
+		else if (r == R1 - 1) cm = pk_max(cm, h);                                         /* odd row left over */
+		H[r] = h;
+		d = hold;
+	}
+}
+
+/* FORM 0: int16, 9 instructions per row; 1: f16 (scores < 2048), 7.5; 2: int16 with the two-row column maximum (scores < 31744), 8.5;
+   3: column frame (scores + frame offsets < 31744), 6.5 of which 3 are 2-cycle adds (gapO2 then carries gapO - gapE) */
+template <int R, bool TRACK8, int FORM = 0>
 SSW_DEV void chain_rows(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f, u32& cm, u32& ck,
-                        u32 gapO2, u32 gapE2)
+                        u32 gapO2, u32 gapE2, u32 fl = 0)
 {
 	constexpr int K8 = ChainGeom<R>::K8;
+	constexpr bool F16 = FORM == 1, CM3 = FORM == 2;
+	if (FORM == 3) {
+		if (TRACK8) {
+			chain_rows_fr<R, 0, K8>(sc, H, E, d, f, cm, gapO2, gapE2, fl);
+			ck = cm;
+			chain_rows_fr<R, K8, R>(sc, H, E, d, f, cm, gapO2, gapE2, fl);
+		} else chain_rows_fr<R, 0, R>(sc, H, E, d, f, cm, gapO2, gapE2, fl);
+		return;
+	}
 	if (CM3 && !F16) {
 		if (TRACK8) {
 			chain_rows_cm3<R, 0, K8>(sc, H, E, d, f, cm, gapO2, gapE2);
@@ -165,17 +199,23 @@ SSW_DEV void chain_rows(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f
 
 /* the 16 lanes of a chain write the finished maxima of traversal columns [base, base + 16) (both padding rules) and the
    maximum over the group: a 4-step row_ror butterfly on the packed values (all 16 lanes end up with it, lane 0 stores it) */
-template <int R, bool F16>
+template <int R, int FORM>
 SSW_DEV void fill_flush16(unsigned char* lds, u32 out16, u32 out8, int base, int l16, int store_from, int ncols,
-                          uint32_t* o16, uint32_t* o8, uint32_t* g16, uint32_t* g8)
+                          uint32_t* o16, uint32_t* o8, uint32_t* g16, uint32_t* g8, int fr_base = 0, int fr_kmask = 0, int gapE = 0)
 {
 	typedef ChainGeom<R> G;
+	constexpr bool F16 = FORM == 1;
 	const int tc = base + l16;
 	u32 i16 = 0, i8 = 0;
 	if (tc >= store_from && tc < ncols) {
 		const u32 v16 = lds_ld32(lds, out16 + 4u * ((tc + 15) & 63)), v8 = lds_ld32(lds, out8 + 4u * ((tc + G::TAP) & 63));
+		if (FORM == 3) {   /* parked in the frame of the step that finished them: column tc at step tc + 15 (lane 15) / tc + TAP (lane TAP) */
+			i16 = v16 - pk_dup(fr_phi(tc + 15, 15, 16, fr_base, fr_kmask, gapE));
+			i8 = v8 - pk_dup(fr_phi(tc + G::TAP, G::TAP, 16, fr_base, fr_kmask, gapE));
+		} else {
 		i16 = F16 ? pkf_to_int2(v16) : v16;
 		i8 = F16 ? pkf_to_int2(v8) : v8;
+		}
 		o16[tc] = i16;
 		o8[tc] = i8;
 	}
@@ -198,12 +238,13 @@ SSW_DEV void fill_flush16(unsigned char* lds, u32 out16, u32 out8, int base, int
 template <int R, int FORM>
 __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fill(ssw_fill_args a)
 {
-	constexpr bool F16 = FORM == 1;
+	constexpr bool F16 = FORM == 1, FR = FORM == 3;
 	typedef ChainGeom<R> G;
 	constexpr int C = G::C;
 	SSW_DYN_LDS(lds);
 	const int tid = (int)threadIdx.x, l16 = tid & 15, grp = tid >> 4;
 	const int pair = (int)blockIdx.x / a.bpp, tchunk = (int)blockIdx.x - pair * a.bpp;
+	const int gapEi = (int)(a.gapE2 & 0xffffu);
 	const u32 prof_bytes = (u32)(a.n + 1) * G::PSTRIDE;
 	const u32 ring = prof_bytes + (u32)grp * CHAIN_BYTES, out16 = ring + RING_BYTES, out8 = out16 + 256;
 	const u32 nulloff = (u32)a.n * G::PSTRIDE;
@@ -214,7 +255,7 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
 		const int lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
 		const int8_t* qb = pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0;
 		const int lenb = pr.qb >= 0 ? (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]) : 0;
-		build_profile<R, F16>(lds, 0, tid, 256, a.mat, a.n, qa, lena, 0, qb, lenb);
+		build_profile<R, FR ? 2 : F16 ? 1 : 0>(lds, 0, tid, 256, a.mat, a.n, qa, lena, 0, qb, lenb, 0x7fffffff, 0x7fffffff, gapEi);
 	}
 
 	/* this chain's tile */
@@ -253,16 +294,25 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
 	}
 	__syncthreads();
 
+	/* frame form: the all-zero state of the column before the lane's first one is phi of that column; `fl` runs one column ahead */
+	const u32 zero0 = FR ? pk_dup(fr_phi(0, l16, 16, a.fr_base, a.fr_kmask, gapEi) - gapEi) : 0u;
+	u32 fl = zero0 + a.gapE2;
 	u32 H[R], E[R];
 #pragma unroll
-	for (int r = 0; r < R; ++r) { H[r] = 0; E[r] = 0; }
-	u32 Hlast = 0, Fout = 0, cmout = 0, ck = 0, hsave = 0;
+	for (int r = 0; r < R; ++r) { H[r] = zero0; E[r] = FR ? fl : 0u; }
+	u32 Hlast = zero0, Fout = zero0, cmout = zero0, ck = 0, hsave = zero0;
 	const u32 lane_prof = (u32)l16 * 16u;
-	/* f16 form: the penalties enter as negative scaled constants */
-	const u32 gO = F16 ? pkf_make(-(int)(a.gapO2 & 0xffffu), -(int)(a.gapO2 & 0xffffu)) : a.gapO2;
+	/* f16 form: the penalties enter as negative scaled constants; frame form: gapO - gapE */
+	const u32 gO = F16 ? pkf_make(-(int)(a.gapO2 & 0xffffu), -(int)(a.gapO2 & 0xffffu)) : FR ? a.gapO2 - a.gapE2 : a.gapO2;
 	const u32 gE = F16 ? pkf_make(-(int)(a.gapE2 & 0xffffu), -(int)(a.gapE2 & 0xffffu)) : a.gapE2;
 
 	for (int s0 = 0; s0 < nsteps; s0 += 16) {
+		if (FR && s0 > 0 && (s0 & a.fr_kmask) == 0) {   /* renormalisation: every frame value drops by K x gapE */
+			const u32 k = (u32)(a.fr_kmask + 1) * a.gapE2;
+#pragma unroll
+			for (int r = 0; r < R; ++r) { H[r] -= k; E[r] -= k; }
+			Hlast -= k; Fout -= k; cmout -= k; hsave -= k; fl -= k;
+		}
 		{   /* stage target columns [s0+16, s0+32), prefetch [s0+32, s0+48) */
 			const int p = (s0 + 16 + l16) & 63;
 			lds_st16(lds, ring + 2u * p, nxt);
@@ -273,7 +323,7 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
 			nxt = (u32)code * G::PSTRIDE;
 		}
 		wave_lds_fence();   /* lane 0's ring writes of the previous 16 steps are visible to the chain */
-		if (s0 >= 32) fill_flush16<R, F16>(lds, out16, out8, s0 - 32, l16, store_from, ncols, o16, o8, g16, g8);   /* columns [s0-32, s0-16) are complete in the out rings */
+		if (s0 >= 32) fill_flush16<R, FORM>(lds, out16, out8, s0 - 32, l16, store_from, ncols, o16, o8, g16, g8, a.fr_base, a.fr_kmask, gapEi);   /* columns [s0-32, s0-16) are complete in the out rings */
 		wave_lds_fence();
 		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
 		/* the lanes that FINISH a maximum park it themselves, in the slot of the step: lane 15 the column's (all rows; its column is
@@ -286,10 +336,11 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
 			u32x4 sc[C];
 #pragma unroll
 			for (int c = 0; c < C; ++c) sc[c] = lds_ld128(lds, paddr + 256u * c);
-			const u32 hin = xl_row_shr1_zero(Hlast);
+			u32 hin = xl_row_shr1_zero(Hlast);
+			if (FR) { hin = umax32(hin, fl); fl += gE; }      /* lane 0: the zero that row_shr fills in becomes phi(column) -- a plain u32 max is exact here, both halves of every H are >= phi */
 			u32 f = xl_row_shr1_zero(Fout);
 			u32 cm = xl_row_shr1_zero(cmout);      /* this column's maximum of the rows above */
-			chain_rows<R, true, F16, FORM == 2>(sc, H, E, hsave, f, cm, ck, gO, gE);
+			chain_rows<R, true, FORM>(sc, H, E, hsave, f, cm, ck, gO, gE, fl);
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
 			if (G::TAP == 15) {
 				if (l16 == 15) { lds_st32(lds, ob16 + 4u * j, cm); lds_st32(lds, ob8 + 4u * j, ck); }
@@ -301,7 +352,7 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
 	}
 	wave_lds_fence();
 	for (int base = nsteps - 32; base < nsteps; base += 16)
-		if (base >= 0) fill_flush16<R, F16>(lds, out16, out8, base, l16, store_from, ncols, o16, o8, g16, g8);
+		if (base >= 0) fill_flush16<R, FORM>(lds, out16, out8, base, l16, store_from, ncols, o16, o8, g16, g8, a.fr_base, a.fr_kmask, gapEi);
 }
 
 /* ================================================================================================
@@ -2613,7 +2664,8 @@ extern "C" int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream)
 	if (grid <= 0) return 0;
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
-		if (args.f16 == 1) SSW_LAUNCH((k_fill<r, 1>), ssw_fill_args, args, grid, 256, ldsb, stream); \
+		if (args.f16 == 3) SSW_LAUNCH((k_fill<r, 3>), ssw_fill_args, args, grid, 256, ldsb, stream); \
+		else if (args.f16 == 1) SSW_LAUNCH((k_fill<r, 1>), ssw_fill_args, args, grid, 256, ldsb, stream); \
 		else if (args.f16 == 2) SSW_LAUNCH((k_fill<r, 2>), ssw_fill_args, args, grid, 256, ldsb, stream); \
 		else SSW_LAUNCH((k_fill<r, 0>), ssw_fill_args, args, grid, 256, ldsb, stream); } break;
 		FOR_EACH_R(X)
