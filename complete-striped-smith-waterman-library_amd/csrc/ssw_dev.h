@@ -109,7 +109,8 @@ typedef struct {
 	int32_t chain_best;      /* 1: lanes learn the chain's best every 16 steps (fewer best-cell records); 0: lane-local records only (experiments) */
 	struct ssw_hit_rec* hits;/* optional (takes precedence): compact 16-byte records [query][res_nt] of the streaming search */
 	int32_t* counters;       /* optional: [0] alignments decided under 16-bit rules, [1] under 8-bit rules, [2] workgroups repeated in the int16 form */
-	int32_t f16;             /* 1: f16 form first (7.5 instructions per row, exact below 2048); a workgroup whose best cell saturates repeats in int16 */
+	int32_t f16;             /* 1: column-frame form of the recurrence (fr_base / fr_kmask as in ssw_fill_args), 0: plain int16 with the two-row maximum */
+	int32_t fr_base, fr_kmask;
 } ssw_filldb_args;
 
 /* reduction of the column maxima into score1 / ref_end1 / score2 / ref_end2 */
@@ -191,7 +192,9 @@ typedef struct {
 	int32_t* queue;          /* [0] ticket counter, [1 + job * strips + strip] completion flags, [1 + items] error word (a wait
 	                            that timed out); zeroed before the launch */
 	int32_t* cand_strip;     /* [job * strips + strip][half][4]: best cell of the job up to and including that strip */
-	int32_t form;            /* fill mode: 2 = no score of the bucket reaches 31744 (two-row column maximum), 0 = plain */
+	int32_t form;            /* fill mode: 3 = column frame (fr_base / fr_kmask as in ssw_fill_args), 2 = no score of the bucket reaches 31744
+	                            (two-row column maximum), 0 = plain */
+	int32_t fr_base, fr_kmask;
 	int32_t whole_jobs;      /* 1: a ticket is a whole job (its strips in sequence on one wavefront); 0: a ticket is one strip */
 } ssw_chainx_args;
 

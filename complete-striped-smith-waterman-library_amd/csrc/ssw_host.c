@@ -53,7 +53,6 @@ struct ssw_gpu_ctx {
 	int busy;                           /* a batch call is running on this context (one call at a time per context) */
 	const int32_t* queue_err;           /* device error word of the last work-queue launch, not yet checked */
 	void* hits_d[2]; void* hits_h[2]; size_t hits_cap;     /* streamed database search: two device + two page-locked host buffers, kept between calls */
-	int db_f16_off;                                        /* > 0: the f16 form of k_filldb kept saturating on this context's data -- that many calls start in the int16 form */
 };
 
 struct ssw_gpu_seqs {
@@ -376,7 +375,6 @@ typedef struct {
 	size_t cnt_off;                     /* byte offset in h_hits[]: snapshot of the device counters taken after the chunk */
 } db_stream;
 
-#define DB_F16_PAUSE 16                 /* database-search calls that skip the f16 form after one in which > 1/8 of the workgroups repeated */
 #define DB_COUNTERS 4                   /* [0] 16-bit-rule alignments, [1] 8-bit-rule, [2] workgroups of k_filldb that repeated in the int16 form */
 
 
@@ -432,12 +430,13 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 	int32_t* d_tl_all = (int32_t*)ensure(c, &c->tlist, sizeof(int32_t) * (size_t)tcount);     /* every sub-batch has its own slice (uploads stay in flight) */
 	int32_t* d_cnt_s = ds ? (int32_t*)ensure(c, &c->need, DB_COUNTERS * sizeof(int32_t)) : 0;
 	const int nch = SSW_DB_NCH;
-	/* f16 form first, int16 repeat of the workgroups that saturate (k_filldb): off when those repeats stop being rare */
-	int use_f16 = 1, adaptive = 1;
-	if (c->db_f16_off > 0) { use_f16 = 0; c->db_f16_off--; }      /* recent calls kept saturating: int16 form for a while, then try again */
-	{ const char* e = getenv("SSW_GPU_DB_F16"); if (e && (e[0] == '0' || e[0] == '1')) { use_f16 = e[0] == '1'; adaptive = 0; } }
-	const int f16_first = use_f16;
-	int64_t wgs_f16[2] = { 0, 0 }; int32_t reruns_seen = 0;      /* per result buffer: f16 workgroups launched for the chunk it holds */
+	/* column-frame form of the recurrence wherever a size class's scores leave room for the frame offsets below 31744 (always, for the
+	   matrices and lengths this path admits with sane gap penalties); SSW_GPU_DB_FORM=0 (tests) keeps the plain int16 form */
+	int use_fr = 1;
+	{ const char* e = getenv("SSW_GPU_DB_FORM"); if (e && e[0] == '0') use_fr = 0; }
+	int32_t db_minmat = 0, db_maxmat = 0;
+	for (int32_t i = 0; i < n * n; ++i) { if (prm->mat[i] < db_minmat) db_minmat = prm->mat[i]; if (prm->mat[i] > db_maxmat) db_maxmat = prm->mat[i]; }
+	int db_form[64]; memset(db_form, 0, sizeof db_form);
 	if (!d_tl_all || (ds && (!d_cnt_s || ssw_shim_memset(d_cnt_s, 0, DB_COUNTERS * sizeof(int32_t), c->stream)))) { fail(c, "device allocation failed: %s", ssw_shim_last_error()); goto done; }
 	int32_t prev_t0 = -1, prev_nt = 0, chunk_i = 0;
 	int64_t db_cells[64]; memset(db_cells, 0, sizeof db_cells);      /* per bucket (nb <= 24 short buckets + up to 16 classes of 385..640 residues) */
@@ -477,7 +476,6 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		   same work in 23 launches).  Every stream has its own slice of the column-maximum scratch. */
 		void* e0 = next_event(c); void* e1 = next_event(c);
 		ssw_shim_event_record(e0, c->stream);
-		wgs_f16[buf] = 0;
 		if (nz > 0) {
 			int ord[64], nord = 0, used[DB_STREAMS];
 			for (int b = 0; b < nb + nmid && nord < 64; ++b) { const bucket* B = b < nb ? &bk[b] : &mid[b - nb]; if (!B->use_x) ord[nord++] = b; }
@@ -499,10 +497,8 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 				if (w > need) need = w;
 			}
 			if (need > slice) need = slice;
-			for (int i = 0; i < nord; ++i) {     /* ... but never less than one workgroup's targets of the largest class */
-				const bucket* B = ord[i] < nb ? &bk[ord[i]] : &mid[ord[i] - nb];
-				if (need < 4 * stride * nch * (int64_t)B->npairs) need = 4 * stride * nch * (int64_t)B->npairs;
-			}
+			if (need < 4 * stride * nch) need = 4 * stride * nch;     /* ... but never less than one workgroup (one pair x its 16 targets); a class
+			                                                             whose pairs do not fit a slice is cut into launches of fewer pairs */
 			uint32_t* d_cm16_all = (uint32_t*)ensure(c, &c->cm16, (size_t)(need * DB_STREAMS));
 			uint32_t* d_cm8_all = (uint32_t*)ensure(c, &c->cm8, (size_t)(need * DB_STREAMS));
 			if (!d_cm16_all || !d_cm8_all) goto done;
@@ -514,24 +510,32 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 				const ssw_pair* bpairs = b < nb ? d_pairs : d_midpairs;
 				void* st = c->tstream[sx];
 				if (!used[sx]) { used[sx] = 1; if (ssw_shim_stream_wait_event(st, c->ev_db)) { fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; } }
-				int64_t per = need / (4 * stride * (int64_t)B->npairs);   /* targets per launch: what one slice holds */
+				/* pairs per launch: all of the class when one workgroup row of them fits the slice, else what fits (the scratch of a launch
+				   is 8 bytes x stride x pairs x targets); targets per launch: what the slice then holds, in workgroups of 16 */
+				int64_t ppl = B->npairs;
+				if (4 * stride * nch * ppl > need) ppl = need / (4 * stride * nch);
+				if (ppl < 1) ppl = 1;
+				int64_t per = need / (4 * stride * ppl);
 				per = per / nch * nch; if (per < nch) per = nch;
-				if ((int64_t)4 * stride * per * B->npairs > need) { fail(c, "database search: %s", "a size class does not fit the column-maximum budget (SSW_GPU_CM_BUDGET_MB)"); goto done; }
+				if ((int64_t)4 * stride * per * ppl > need) { fail(c, "database search: %s", "a size class does not fit the column-maximum budget (SSW_GPU_CM_BUDGET_MB)"); goto done; }
 				uint32_t* d_cm16 = d_cm16_all + (need / 4) * sx;
 				uint32_t* d_cm8 = d_cm8_all + (need / 4) * sx;
+				int32_t fr_base = 0, fr_kmask = 0;
+				const int fr = use_fr && ssw_frame_params((int64_t)B->P16 * db_maxmat, prm->gapO, prm->gapE, db_minmat, 16, &fr_base, &fr_kmask);
+				if (b < 64) db_form[b] = fr;
+				for (int32_t p0 = 0; p0 < B->npairs; p0 += (int32_t)ppl)
 				for (int32_t k0 = 0; k0 < nz; k0 += (int32_t)per) {
 					ssw_filldb_args fa;
 					fa.tcodes = T->d_codes; fa.toff = T->d_off; fa.tlist = d_tl + k0; fa.ntl = nz - k0 < per ? nz - k0 : (int32_t)per;
-					fa.tfirst = tfirst + t0; fa.res_nt = nt; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off; fa.pairs = bpairs + B->first_pair;
-					fa.npairs = B->npairs; fa.mat = d_mat; fa.n = n; fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.cm16 = d_cm16; fa.cm8 = d_cm8;
+					fa.tfirst = tfirst + t0; fa.res_nt = nt; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off; fa.pairs = bpairs + B->first_pair + p0;
+					fa.npairs = B->npairs - p0 < ppl ? B->npairs - p0 : (int32_t)ppl; fa.mat = d_mat; fa.n = n; fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.cm16 = d_cm16; fa.cm8 = d_cm8;
 					fa.cm_stride = stride; fa.maskLen = prm->maskLen; fa.bias = bias; fa.score_size = prm->score_size; fa.res = d_res; fa.out = d_out; fa.counters = d_cnt;
-					fa.hits = d_hits; fa.f16 = use_f16;
-					if (use_f16) wgs_f16[buf] += (int64_t)fa.npairs * ((fa.ntl + nch - 1) / nch);
+					fa.hits = d_hits; fa.f16 = fr; fa.fr_base = fr_base; fa.fr_kmask = fr_kmask;
 					{ const char* e = getenv("SSW_GPU_DB_CHAIN_BEST"); fa.chain_best = !(e && e[0] == '0'); }
 					if (ssw_shim_launch_filldb(B->R, &fa, st)) { fail(c, "filldb launch failed: %s", ssw_shim_last_error()); goto done; }
 					int64_t lc = 0;
 					for (int32_t k = 0; k < fa.ntl; ++k)
-						lc += (T->h_off[tl[k0 + k] + 1] - T->h_off[tl[k0 + k]]) * (int64_t)B->P16 * 2 * B->npairs;
+						lc += (T->h_off[tl[k0 + k] + 1] - T->h_off[tl[k0 + k]]) * (int64_t)B->P16 * 2 * fa.npairs;
 					c->tm.fill_cells += lc;
 					if (b < 64) db_cells[b] += lc;
 				}
@@ -550,12 +554,6 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 			    ssw_shim_event_record(c->ev_red[buf], c->stream2)) { fail(c, "result download failed: %s", ssw_shim_last_error()); goto done; }
 			if (prev_t0 >= 0) {
 				if (ssw_shim_event_sync(c->ev_red[buf ^ 1])) { fail(c, "result download failed: %s", ssw_shim_last_error()); goto done; }
-				{   /* the counters are cumulative: what the previous chunk added */
-					const int32_t* snap = (const int32_t*)((const char*)ds->h_hits[buf ^ 1] + ds->cnt_off);
-					const int32_t r = snap[2] - reruns_seen;
-					reruns_seen = snap[2];
-					if (adaptive && use_f16 && wgs_f16[buf ^ 1] > 0 && (int64_t)r * 8 > wgs_f16[buf ^ 1]) { use_f16 = 0; c->db_f16_off = DB_F16_PAUSE; }
-				}
 				ds->fn_rc = ds->fn(ds->user, tfirst + prev_t0, prev_nt, ds->h_hits[buf ^ 1]);
 				if (ds->fn_rc) { ssw_shim_stream_sync(c->stream); ssw_shim_stream_sync(c->stream2); rc = 0; goto done; }
 			}
@@ -569,7 +567,6 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 				fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
 			}
 			c->tm.n_word += cnt[0]; c->tm.n_byte += cnt[1]; c->tm.db_repeats += cnt[2];
-			if (adaptive && use_f16 && (int64_t)cnt[2] * 8 > wgs_f16[buf]) c->db_f16_off = DB_F16_PAUSE;
 			int64_t qsum = Q->h_off[nq] - Q->h_off[0];
 			for (int32_t k = 0; k < nt; ++k) {
 				const int64_t L = T->h_off[tfirst + k + 1] - T->h_off[tfirst + k];
@@ -604,8 +601,8 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		for (int b = 0; b < nb + nmid && b < 64; ++b) {
 			const bucket* B = b < nb ? &bk[b] : &mid[b - nb];
 			char nm[48];
-			snprintf(nm, sizeof nm, "k_filldb<%d>%s", B->R, f16_first ? " f16 first" : "");
-			note_fill_kernel(c, db_cells[b], &bestc, nm, f16_first ? 7.5 : 8.5, B->R, 1);
+			snprintf(nm, sizeof nm, "k_filldb<%d,%s>", B->R, db_form[b] ? "frame" : "int16+max3");
+			note_fill_kernel(c, db_cells[b], &bestc, nm, db_form[b] ? 6.5 : 8.5, B->R, 1);
 		}
 	}
 	if (ds && prev_t0 >= 0) {     /* the last chunk */
@@ -918,7 +915,10 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 						else if (fill_form >= 0 && fill_form < fa.f16) fa.f16 = fill_form == 1 && top > 2047 ? fa.f16 : fill_form;
 					}
 					/* strip kernel: two-row column maximum when no score of the bucket can reach 31744 */
-					const int xform = fill_f16 && (int64_t)B->P16 * (maxmat > 0 ? maxmat : 0) < 31744 ? 2 : 0;
+					int xform = fill_f16 && (int64_t)B->P16 * (maxmat > 0 ? maxmat : 0) < 31744 ? 2 : 0;
+					int32_t xfr_base = 0, xfr_kmask = 0;
+					if (xform == 2 && (fill_form < 0 || fill_form == 3) && B->lanes == 64 &&
+					    ssw_frame_params((int64_t)B->P16 * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, minmat, 64, &xfr_base, &xfr_kmask)) xform = 3;
 					void* e0 = next_event(c); void* e1 = next_event(c);
 					ssw_shim_event_record(e0, c->stream);
 					if (use_x) {
@@ -930,7 +930,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 						if (B->lanes == 64) {     /* strips of all jobs behind one work queue (k_chainq) */
 							const int qgrid = chainq_grid(B->R, 0, n);
 							if (chainq_prepare(c, &xa, B->strips, (int64_t)np * ntiles, qgrid)) goto done;
-							xa.form = xform;
+							xa.form = xform; xa.fr_base = xfr_base; xa.fr_kmask = xfr_kmask;
 							if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] chainq fill: R %d, %d jobs x %d strips, %d wavefronts, %s tickets, form %d\n",
 							                                     B->R, np * ntiles, B->strips, qgrid, xa.whole_jobs ? "job" : "strip", xa.form);
 							if (ssw_shim_launch_chainq(B->R, 0, &xa, qgrid, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
@@ -952,9 +952,9 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 						c->tm.fill_cells += lc;
 						char nm[48];
 						if (!use_x) snprintf(nm, sizeof nm, "k_fill<%d,%s>", B->R, fa.f16 == 3 ? "frame" : fa.f16 == 1 ? "f16" : fa.f16 == 2 ? "int16+max3" : "int16");
-						else if (B->lanes == 64) snprintf(nm, sizeof nm, "k_chainq<%d,%s> x %d strips", B->R, xform == 2 ? "int16+max3" : "int16", B->strips);
+						else if (B->lanes == 64) snprintf(nm, sizeof nm, "k_chainq<%d,%s> x %d strips", B->R, xform == 3 ? "frame" : xform == 2 ? "int16+max3" : "int16", B->strips);
 						else snprintf(nm, sizeof nm, "k_chainx<%d,16 lanes> x %d strips", B->R, B->strips);
-						note_fill_kernel(c, lc, &best_fill_cells, nm, !use_x ? (fa.f16 == 3 ? 6.5 : fa.f16 == 1 ? 7.5 : fa.f16 == 2 ? 8.5 : 9.0) : (B->lanes == 64 && xform == 2 ? 8.5 : 9.0), B->R, B->strips);
+						note_fill_kernel(c, lc, &best_fill_cells, nm, !use_x ? (fa.f16 == 3 ? 6.5 : fa.f16 == 1 ? 7.5 : fa.f16 == 2 ? 8.5 : 9.0) : (B->lanes == 64 && xform == 3 ? 6.5 : B->lanes == 64 && xform == 2 ? 8.5 : 9.0), B->R, B->strips);
 					}
 					ssw_reduce_args ra;
 					ra.cm16 = d_cm16; ra.cm8 = d_cm8; ra.cm_stride = stride; ra.refLen = refLen; ra.pairs = fa.pairs; ra.npairs = np;

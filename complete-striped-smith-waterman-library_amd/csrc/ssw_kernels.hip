@@ -385,18 +385,12 @@ template <int N> SSW_DEV u32x4 lds_ld_rows(const unsigned char* lds, u32 off)
 /* k_filldb: the R rows of one step (same arithmetic and pairing as chain_rows with TRACK8), with the score chunks of the NEXT step
    requested as soon as the rows of a chunk are done: one set of score registers instead of two, and every profile read still has
    a whole step to land.  db_done(r) = the last row that is finished after iteration r of the unrolled loop. */
-template <int R> constexpr int db_done(int r, bool f16)
-{
-	if (r < 0) return -1;
-	if (!f16) return r;
-	const int K8 = ChainGeom<R>::K8, seg0 = r < K8 ? 0 : K8, seg1 = r < K8 ? K8 : R;
-	const bool second = ((r - seg0) & 1) == 1;
-	return !second && r + 1 < seg1 ? r + 1 : r;
-}
+template <int R> constexpr int db_done(int r) { return r < 0 ? -1 : r; }
 
-template <int R, bool F16>
+/* FR: column-frame form (chain_rows_fr; gO then carries gapO - gapE and fl = phi one column ahead), else plain int16 with the two-row maximum */
+template <int R, bool FR>
 SSW_DEV void db_rows(const unsigned char* lds, u32 pa_next, u32x4 (&sc)[(R + 3) / 4], u32 (&H)[R], u32 (&E)[R], u32 d, u32& f, u32& cm, u32& ck,
-                     u32 gO, u32 gE)
+                     u32 gO, u32 gE, u32 fl)
 {
 	constexpr int C = (R + 3) / 4, K8 = ChainGeom<R>::K8;
 #pragma unroll
@@ -405,28 +399,21 @@ SSW_DEV void db_rows(const unsigned char* lds, u32 pa_next, u32x4 (&sc)[(R + 3) 
 		const bool second = ((r - seg0) & 1) == 1;      /* second row of a pair */
 		const bool pair = !second && r + 1 < seg1;      /* first row of a pair (otherwise a single row left over) */
 		if (r == K8) ck = cm;                           /* rows < A8 end here in lane TAP: the 16-bit-rule maximum */
-		if (F16) {
-			if (pair) {
-				const int r1 = r + 1 < R ? r + 1 : r;
-				const u32 d1 = H[r], hold = H[r1];
-				u32 h0, h1;
-				pkf_cell2(d, sc[r >> 2][r & 3], d1, sc[r1 >> 2][r1 & 3], E[r], E[r1], f, cm, h0, h1, gO, gE);
-				H[r] = h0; H[r1] = h1;
-				d = hold;
-			} else if (!second) {
-				const u32 hold = H[r];
-				u32 h;
-				pkf_cell(d, sc[r >> 2][r & 3], E[r], f, cm, h, gO, gE);
-				H[r] = h;
-				d = hold;
-			}
-		} else {
+		{
 			const u32 hold = H[r];
-			const u32 h0 = pk_max(pk_adds(d, sc[r >> 2][r & 3]), E[r]);
-			const u32 h = pk_max(h0, f);
-			const u32 t0 = pk_subu(h0, gO);
-			E[r] = pk_max(pk_subu(E[r], gE), t0);
-			f = pk_max(pk_subu(f, gE), t0);
+			u32 h;
+			if (FR) {
+				h = pk_max3_fr(d + sc[r >> 2][r & 3], E[r], f);
+				const u32 t = h - gO;
+				E[r] = pk_max3_fr(E[r], t, fl);
+				f = pk_max(f, t) - gE;
+			} else {
+				const u32 h0 = pk_max(pk_adds(d, sc[r >> 2][r & 3]), E[r]);
+				h = pk_max(h0, f);
+				const u32 t0 = pk_subu(h0, gO);
+				E[r] = pk_max(pk_subu(E[r], gE), t0);
+				f = pk_max(pk_subu(f, gE), t0);
+			}
 			if (second) cm = pk_max3_nonneg(cm, H[r - 1 >= 0 ? r - 1 : 0], h);   /* H[r-1] was just written: this pair's first row */
 			else if (!pair) cm = pk_max(cm, h);
 			H[r] = h;
@@ -435,7 +422,7 @@ SSW_DEV void db_rows(const unsigned char* lds, u32 pa_next, u32x4 (&sc)[(R + 3) 
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			const int last = 4 * c + 3 < R - 1 ? 4 * c + 3 : R - 1;      /* the chunk's last row */
-			if (last <= db_done<R>(r, F16) && last > db_done<R>(r - 1, F16)) {
+			if (last <= db_done<R>(r) && last > db_done<R>(r - 1)) {
 				const u32 pa = after(pa_next, H[last]);      /* not before the chunk's rows have used the old scores */
 				if (c + 1 < C) sc[c] = lds_ld128(lds, pa + 256u * c);
 				else sc[c] = lds_ld_rows<R - 4 * (C - 1)>(lds, pa + 256u * c);
@@ -461,11 +448,8 @@ SSW_DEV void db_record(u32 now, u32 pre, int tc, const u32 (&H)[R], u32 (&snap)[
 	for (int r = 0; r < R; ++r) snap[r] = bfi32(m, H[r], snap[r]);
 }
 
-SSW_DEV int pkf_half_to_int(int bits) { return (int)(pkf_to_int2((u32)bits & 0xffffu) & 0xffffu); }
-
-/* returns true when the f16 form saturated (nothing was written: the caller repeats the workgroup in the int16 form) */
-template <int R, int NCH, bool F16, int UNROLL>
-SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
+template <int R, int NCH, bool FR, int UNROLL>
+SSW_DEV void filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 {
 	typedef ChainGeom<R> G;
 	constexpr int C = G::C;
@@ -475,14 +459,13 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 	const int pair = (int)blockIdx.x / tchunks, tchunk = (int)blockIdx.x - pair * tchunks;
 	const u32 prof_bytes = (u32)(a.n + 1) * G::PSTRIDE;
 	const u32 ring = prof_bytes + (u32)grp * DB_CHAIN_BYTES, out16 = ring + DB_RING_BYTES, out8 = out16 + 4u * DB_OUT_RING;
-	const u32 vote = prof_bytes + (u32)NCH * DB_CHAIN_BYTES;      /* one word: some chain of the workgroup saturated */
 	const u32 nulloff = (u32)a.n * G::PSTRIDE;
 	const ssw_pair pr = a.pairs[pair];
 	const int lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
 	const int lenb = pr.qb >= 0 ? (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]) : 0;
-	build_profile<R, F16>(lds, 0, tid, 16 * NCH, a.mat, a.n, a.qcodes + a.qoff[pr.qa], lena, 0,
-	                      pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0, lenb);
-	if (F16 && tid == 0) lds_st32(lds, vote, 0u);
+	const int gapEi = (int)(a.gapE2 & 0xffffu);
+	build_profile<R, FR ? 2 : 0>(lds, 0, tid, 16 * NCH, a.mat, a.n, a.qcodes + a.qoff[pr.qa], lena, 0,
+	                             pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0, lenb, 0x7fffffff, 0x7fffffff, gapEi);
 
 	const int slot = tchunk * NCH + grp;
 	const bool active = slot < a.ntl;
@@ -516,17 +499,20 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 	}
 	__syncthreads();
 
+	/* frame form: the all-zero state of the column before the lane's first one is phi of that column; `fl` runs one column ahead.  H, the
+	   column maxima and `best` carry the phi of the lane's current column (`best` is moved along with it); the column maxima and the
+	   best cell become true values where they leave the chain */
+	const u32 zero0 = FR ? pk_dup(fr_phi(0, l16, 16, a.fr_base, a.fr_kmask, gapEi) - gapEi) : 0u;
+	u32 fl = zero0 + a.gapE2;
 	u32 H[R], E[R], snap[R];                        /* snap: per query half, the lane's H column at its last record (db_record) */
 #pragma unroll
-	for (int r = 0; r < R; ++r) { H[r] = 0; E[r] = 0; snap[r] = 0; }
-	u32 Hlast = 0, Fout = 0, cmout = 0, ck = 0, hsave = 0;
-	u32 best = 0;                                   /* packed: highest running column maximum this lane has seen */
+	for (int r = 0; r < R; ++r) { H[r] = zero0; E[r] = FR ? fl : 0u; snap[r] = 0; }
+	u32 Hlast = zero0, Fout = zero0, cmout = zero0, ck = 0, hsave = zero0;
+	u32 best = zero0;                               /* packed: highest running column maximum this lane has seen */
 	u32 btc2 = 0xffffffffu;                         /* packed: column of the last record per half (the host keeps targets below 65000 residues here) */
 	const u32 lane_prof = (u32)l16 * 16u;
-	const u32 gO = F16 ? pkf_make(-(int)(a.gapO2 & 0xffffu), -(int)(a.gapO2 & 0xffffu)) : a.gapO2;
-	const u32 gE = F16 ? pkf_make(-(int)(a.gapE2 & 0xffffu), -(int)(a.gapE2 & 0xffffu)) : a.gapE2;
-	/* f16 form: H, the column maxima and `best` are bit patterns of non-negative f16 numbers, whose order is the integer order:
-	   the tracking below compares patterns; the column maxima become integers where they leave the chain */
+	const u32 gO = FR ? a.gapO2 - a.gapE2 : a.gapO2;
+	const u32 gE = a.gapE2;
 
 	/* software pipeline of the LDS reads (three or four wavefronts per SIMD do not hide a ring entry -> address -> scores round
 	   trip per step): the ring entry of step s+2 is requested before the rows of step s run, the score chunks of step s+1 while
@@ -544,6 +530,12 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 	}
 
 	for (int s0 = 0; s0 < nsteps; s0 += 16) {
+		if (FR && s0 > 0 && (s0 & a.fr_kmask) == 0) {   /* renormalisation: every frame value drops by K x gapE (snap keeps the frame of its record) */
+			const u32 k = (u32)(a.fr_kmask + 1) * a.gapE2;
+#pragma unroll
+			for (int r = 0; r < R; ++r) { H[r] -= k; E[r] -= k; }
+			Hlast -= k; Fout -= k; cmout -= k; hsave -= k; fl -= k; best -= k;
+		}
 		{
 			const int p = (s0 + 16 + l16) & 63;
 			lds_st16(lds, ring + 2u * p, nxt);
@@ -558,8 +550,8 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 			const int tc = s0 - 32 + l16;
 			if (tc < ncols) {
 				const u32 v16 = lds_ld32(lds, out16 + 4u * ((u32)(tc + 15) & OM)), v8 = lds_ld32(lds, out8 + 4u * ((u32)(tc + G::TAP) & OM));
-				o16[tc] = F16 ? pkf_to_int2(v16) : v16;
-				o8[tc] = F16 ? pkf_to_int2(v8) : v8;
+				o16[tc] = FR ? v16 - pk_dup(fr_phi(tc + 15, 15, 16, a.fr_base, a.fr_kmask, gapEi)) : v16;
+				o8[tc] = FR ? v8 - pk_dup(fr_phi(tc + G::TAP, G::TAP, 16, a.fr_base, a.fr_kmask, gapEi)) : v8;
 			}
 		}
 		wave_lds_fence();
@@ -567,9 +559,10 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 		       candidate for the best cell, so it need not be recorded (>= the chain's best still is: the first column wins ties,
 		       and lanes higher up are ahead in columns) -- records per target drop from ~100 to the handful of true improvements */
 			if (a.chain_best) {
-				u32 g = best;
+				const u32 ph = FR ? fl - a.gapE2 : 0u;      /* the lanes stand in different columns: compare true values (best >= phi of the lane's column) */
+				u32 g = best - ph;
 				g = pk_max(g, xl_row_ror<1>(g)); g = pk_max(g, xl_row_ror<2>(g)); g = pk_max(g, xl_row_ror<4>(g)); g = pk_max(g, xl_row_ror<8>(g));
-				best = pk_max(best, pk_subu(g, 0x00010001u));
+				best = pk_max(best, pk_subu(g, 0x00010001u) + ph);
 			}
 		}
 		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
@@ -578,13 +571,14 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 		for (int j = 0; j < 16; ++j) {
 			const int tc = s0 + j - l16;
 			const u32 pa_next = lds_ld16(lds, rp + 2u * (j + 2));      /* the ring entry of step s + 2 */
-			const u32 hin = xl_row_shr1_zero(Hlast);
+			u32 hin = xl_row_shr1_zero(Hlast);
+			if (FR) { hin = umax32(hin, fl); fl += gE; best += gE; }      /* lane 0: the zero row_shr fills in becomes phi(column); the record follows the lane's frame */
 			u32 f = xl_row_shr1_zero(Fout);
 			u32 cm = xl_row_shr1_zero(cmout);      /* this column's maximum of the rows above (lane 0 starts a new column with 0) */
 			/* best cell: `pre` = the lane's running record and the rows above in this column; only the lane whose OWN rows
 			   beat it -- the lane holding the new record cell, not every lane below -- takes the branch further down */
 			const u32 pre = pk_max(best, cm);
-			db_rows<R, F16>(lds, pa_n, sc, H, E, hsave, f, cm, ck, gO, gE);   /* int16 form: the host keeps max(mat) x 640 below 31744 on this path */
+			db_rows<R, FR>(lds, pa_n, sc, H, E, hsave, f, cm, ck, gO, gE, fl);   /* int16 form: the host keeps max(mat) x 640 below 31744 on this path */
 			pa_n = pa_next + lane_prof;
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
 			best = pk_max(best, cm);     /* = max(pre, own rows) */
@@ -611,14 +605,7 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 			brow[h] = 0x7fffffff;
 #pragma unroll
 			for (int k = R - 1; k >= 0; --k) if (bval[h] > 0 && (int)((snap[k] >> (16 * h)) & 0xffffu) == bval[h]) brow[h] = l16 * R + k;
-		}
-	}
-	if (F16) {   /* a best cell at 2048 (1.0): the form saturated somewhere in this workgroup */
-		if (bval[0] >= 0x3C00 || bval[1] >= 0x3C00) lds_st32(lds, vote, 1u);
-		__syncthreads();
-		if (lds_ld32(lds, vote) != 0u) {
-			if (tid == 0 && a.counters) atomicAdd(a.counters + 2, 1);
-			return true;
+			if (FR && bval[h] > 0) bval[h] -= fr_phi(btc[h] + l16, l16, 16, a.fr_base, a.fr_kmask, gapEi);      /* the kept column is in the frame of its step */
 		}
 	}
 	wave_lds_fence();
@@ -626,8 +613,8 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 		const int tc = base + l16;
 		if (tc >= 0 && tc < ncols) {
 			const u32 v16 = lds_ld32(lds, out16 + 4u * ((u32)(tc + 15) & OM)), v8 = lds_ld32(lds, out8 + 4u * ((u32)(tc + G::TAP) & OM));
-			o16[tc] = F16 ? pkf_to_int2(v16) : v16;
-			o8[tc] = F16 ? pkf_to_int2(v8) : v8;
+			o16[tc] = FR ? v16 - pk_dup(fr_phi(tc + 15, 15, 16, a.fr_base, a.fr_kmask, gapEi)) : v16;
+			o8[tc] = FR ? v8 - pk_dup(fr_phi(tc + G::TAP, G::TAP, 16, a.fr_base, a.fr_kmask, gapEi)) : v8;
 		}
 	}
 	dev_fence();   /* the chain re-reads its own column maxima below */
@@ -638,7 +625,7 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 		const int q = h ? pr.qb : pr.qa;
 		if (q < 0) continue;                         /* uniform in the workgroup */
 		const int len = h ? lenb : lena;
-		lds_st32(lds, red + 16u * l16, (u32)bval[h]);      /* (f16 form: bit patterns, same order as the scores) */
+		lds_st32(lds, red + 16u * l16, (u32)bval[h]);
 		lds_st32(lds, red + 16u * l16 + 4, (u32)btc[h]);
 		lds_st32(lds, red + 16u * l16 + 8, (u32)brow[h]);
 		wave_lds_fence();
@@ -648,7 +635,6 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 			if (v > bv || (v == bv && v > 0 && cc < bc)) { bv = v; bc = cc; br = w; }
 		}
 		wave_lds_fence();
-		if (F16) bv = pkf_half_to_int(bv);
 		const bool padded = (len & 15) >= 1 && (len & 15) <= 8;
 		const int maskLen = a.maskLen >= 0 ? a.maskLen : len / 2;
 		const bool have_byte = a.score_size == 0 || a.score_size == 2, have_word = a.score_size == 1 || a.score_size == 2;
@@ -702,24 +688,18 @@ SSW_DEV bool filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 		}
 		wave_lds_fence();
 	}
-	return false;
 }
 
-/* F16FIRST: the f16 form, then -- rarely -- the repeat in the int16 form, which is compiled with the step loop rolled up so that
-   the kernel's register count is the f16 form's (the wavefronts per SIMD of the common case); otherwise the int16 form alone */
-#ifndef DB_UNROLL_F16
-#define DB_UNROLL_F16 2
+/* FR: the column-frame form (whenever the bucket's scores and the frame offsets stay below 31744: the host decides), else plain int16 */
+#ifndef DB_UNROLL
+#define DB_UNROLL 2
 #endif
-#ifndef DB_UNROLL_REPEAT
-#define DB_UNROLL_REPEAT 1
-#endif
-template <int R, int NCH, bool F16FIRST>
+template <int R, int NCH, bool FR>
 __global__ void __launch_bounds__(16 * NCH) k_filldb(ssw_filldb_args a)
 {
 	SSW_DYN_LDS(lds);
-	if (F16FIRST) {
-		if (filldb_pass<R, NCH, true, DB_UNROLL_F16>(a, lds)) filldb_pass<R, NCH, false, DB_UNROLL_REPEAT>(a, lds);
-	} else filldb_pass<R, NCH, false, 4>(a, lds);
+	if (FR) filldb_pass<R, NCH, true, DB_UNROLL>(a, lds);
+	else filldb_pass<R, NCH, false, 4>(a, lds);
 }
 
 /* ================================================================================================
@@ -1106,9 +1086,9 @@ template <bool ALL4> SSW_DEV u32x4 lds_ld_bnd(const unsigned char* lds, u32 off)
 
 /* profile of one strip: word = (score of query a's row, score of query b's row) against residue b; rows at or below a
    query's padded length are dead for that half */
-template <int R, int GL>
+template <int R, int GL, bool FR = false>
 SSW_DEV void build_profile_strip(unsigned char* lds, u32 base, int first, int nthreads, const int8_t* mat, int n,
-                                 const int8_t* qa, int lena, int reva, int rowsa, const int8_t* qb, int lenb, int revb, int rowsb, int row0)
+                                 const int8_t* qa, int lena, int reva, int rowsa, const int8_t* qb, int lenb, int revb, int rowsb, int row0, int gapE = 0)
 {
 	constexpr int C = StripGeom<R, GL>::C;
 	const int total = (n + 1) * C * GL * 4;
@@ -1118,12 +1098,12 @@ SSW_DEV void build_profile_strip(unsigned char* lds, u32 base, int first, int nt
 		const int r = c * 4 + k, row = row0 + l * R + r;
 		u32 v;
 		if (r >= R) v = 0;
-		else if (b == n) v = DEAD2;                            /* null residue */
+		else if (b == n) v = FR ? fr_pack(FR_DEAD, FR_DEAD) : DEAD2;                            /* null residue */
 		else {
 			int lo = -32768, hi = -32768;                      /* rows below the padded query */
 			if (row < rowsa) lo = row < lena ? mat[b * n + (reva ? qa[lena - 1 - row] : qa[row])] : 0;
 			if (row < rowsb) hi = qb && row < lenb ? mat[b * n + (revb ? qb[lenb - 1 - row] : qb[row])] : 0;
-			v = pk_make(lo, hi);
+			v = FR ? fr_pack(lo == -32768 ? FR_DEAD : lo + gapE, hi == -32768 ? FR_DEAD : hi + gapE) : pk_make(lo, hi);
 		}
 		lds_st32(lds, base + (u32)w * 4u, v);
 	}
@@ -1149,6 +1129,7 @@ struct StripCtx {
 	u32 gapO2, gapE2;
 	int n;
 	u32 bmask;         /* boundary-out ring: entries - 1 (63, or 31 in the LDS-trimmed queue kernel) */
+	int fr_base, fr_kmask, gapEi;   /* column-frame form of the fill (run_strip<..., FR>) */
 };
 
 template <int PS> SSW_DEV u32 strip_code_off(const StripCtx& x, int h, int tc, bool capture)
@@ -1164,14 +1145,14 @@ template <int PS> SSW_DEV u32 strip_code_off(const StripCtx& x, int h, int tc, b
    column, smallest row.  (Columns outside the target only decay; the test on tc keeps the hand-written contract explicit.  The
    branch-free form of k_filldb's db_record, one v_bfi per row, measured 13 ms slower on config 4's fill.) */
 template <int R>
-SSW_DEV void strip_record(u32 now, u32 pre, int tc, const StripCtx& x, const u32 (&H)[R], int (&sv)[2], int (&stc)[2], int (&srow)[2])
+SSW_DEV void strip_record(u32 now, u32 pre, int tc, const StripCtx& x, const u32 (&H)[R], int (&sv)[2], int (&stc)[2], int (&srow)[2], int phi = 0)
 {
 	if (now != pre && x.mine && tc >= 0 && tc < x.ncols) {
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
 			const int nv = (int)((now >> (16 * h)) & 0xffffu), ov = (int)((pre >> (16 * h)) & 0xffffu);
 			if (nv > ov) {
-				sv[h] = nv; stc[h] = tc; srow[h] = 0x7fffffff;
+				sv[h] = nv - phi; stc[h] = tc; srow[h] = 0x7fffffff;      /* (frame form: now / pre / H carry + phi of that column) */
 #pragma unroll
 				for (int k = R - 1; k >= 0; --k) if ((int)((H[k] >> (16 * h)) & 0xffffu) == nv) srow[h] = x.row0 + x.l16 * R + k;
 			}
@@ -1179,13 +1160,25 @@ SSW_DEV void strip_record(u32 now, u32 pre, int tc, const StripCtx& x, const u32
 	}
 }
 
-template <int R, bool CAPTURE, bool MASK8, int GL, bool CM3 = false>
+/* FR (fill mode only): column-frame form of the recurrence (chain_rows_fr).  Boundary records travel between strips as TRUE values:
+   the staging lanes add phi of the column when a record enters the boundary-in ring (lane 0 meets column tc at step tc) and
+   subtract the parking lane's when it leaves the boundary-out ring (lane GL-1 finishes column tc at step tc + GL - 1). */
+template <int R, bool CAPTURE, bool MASK8, int GL, bool CM3 = false, bool FR = false>
 SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st, const u32 (&m8)[R])
 {
 	typedef StripGeom<R, GL> G;
 	constexpr int C = G::C, RB = G::RB;
 	const int l16 = x.l16;             /* lane within the chain (0..GL-1) */
 	const bool stg = l16 < 16;         /* the 16 lanes that stage the rings and flush the boundary records */
+	const u32 fr_c1 = x.gapO2 - x.gapE2;
+	auto bnd_in = [&](u32x4 rec, int tc) -> u32x4 {      /* a record of the strip above (true values) in the frame lane 0 has at column tc */
+		if (FR) { const u32 p = pk_dup(fr_phi(tc, 0, GL, x.fr_base, x.fr_kmask, x.gapEi)); rec[0] += p; rec[1] += p; rec[2] += p; rec[3] += p; }
+		return rec;
+	};
+	auto bnd_out = [&](u32x4 rec, int tc) -> u32x4 {     /* what lane GL-1 parked for column tc, as true values */
+		if (FR) { const u32 p = pk_dup(fr_phi(tc + GL - 1, GL - 1, GL, x.fr_base, x.fr_kmask, x.gapEi)); rec[0] -= p; rec[1] -= p; rec[2] -= p; rec[3] -= p; }
+		return rec;
+	};
 	/* rings: target columns -GL..-1 null, 0..15 now, 16..31 in flight; boundary-in likewise */
 	lds_st16(lds, x.ring + 2u * (RB - GL + l16), x.nulloff);
 	if (CAPTURE) lds_st16(lds, x.ringb + 2u * (RB - GL + l16), x.nulloff);
@@ -1207,16 +1200,20 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	if (stg) {
 		u32x4 rec = zero4;
 		if (take && l16 < x.ncols) rec = *(const u32x4*)(x.bnd + 4 * (int64_t)l16);
-		lds_st128(lds, x.bin + 16u * l16, rec);
+		lds_st128(lds, x.bin + 16u * l16, bnd_in(rec, l16));
 		lds_st128(lds, x.bin + 16u * (48 + l16), zero4);
 	}
 	u32x4 nb = zero4;
 	if (take && 16 + l16 < x.ncols) nb = *(const u32x4*)(x.bnd + 4 * (int64_t)(16 + l16));
+	nb = bnd_in(nb, 16 + l16);
+	/* frame form: the all-zero state of the column before the lane's first one; `fl` = phi one column ahead */
+	const u32 zero0 = FR ? pk_dup(fr_phi(0, l16, GL, x.fr_base, x.fr_kmask, x.gapEi) - x.gapEi) : 0u;
+	u32 fl = zero0 + x.gapE2;
 #pragma unroll
-	for (int r = 0; r < R; ++r) { st.H[r] = 0; st.E[r] = 0; }
-	st.Hlast = 0; st.Fout = 0; st.cmout = 0; st.cm8out = 0; st.hsave = 0;
+	for (int r = 0; r < R; ++r) { st.H[r] = zero0; st.E[r] = FR ? fl : 0u; }
+	st.Hlast = zero0; st.Fout = zero0; st.cmout = zero0; st.cm8out = zero0; st.hsave = zero0;
 	const u32 lane_prof = x.prof + (u32)l16 * 16u;
-	u32 sbest = 0; int sv[2] = { 0, 0 }, stc[2] = { 0x7fffffff, 0x7fffffff }, srow[2] = { 0x7fffffff, 0x7fffffff };   /* this strip's tracking */
+	u32 sbest = zero0; int sv[2] = { 0, 0 }, stc[2] = { 0x7fffffff, 0x7fffffff }, srow[2] = { 0x7fffffff, 0x7fffffff };   /* this strip's tracking */
 	if (CAPTURE) sbest = pk_subu(pk_make(st.best[0], st.best[1]), 0x00010001u);
 	unsigned long long pend = 0ull; u32 prep = 0;   /* fill: lanes whose rows set a record in the step before, and that step's `pre` */
 	wave_lds_fence();
@@ -1241,6 +1238,12 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	}
 
 	for (int s0 = 0; s0 < x.nsteps; s0 += 16) {
+		if (FR && s0 > 0 && (s0 & x.fr_kmask) == 0) {   /* renormalisation: every frame value drops by K x gapE */
+			const u32 k = (u32)(x.fr_kmask + 1) * x.gapE2;
+#pragma unroll
+			for (int r = 0; r < R; ++r) { st.H[r] -= k; st.E[r] -= k; }
+			st.Hlast -= k; st.Fout -= k; st.cmout -= k; st.cm8out -= k; st.hsave -= k; fl -= k; sbest -= k; prep -= k;
+		}
 		if (stg) {   /* stage [s0+16, s0+32), prefetch [s0+32, s0+48) */
 			const int p = (s0 + 16 + l16) & (RB - 1);
 			lds_st16(lds, x.ring + 2u * p, nxt);
@@ -1255,12 +1258,13 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			if (CAPTURE) nxtb = strip_code_off<G::PSTRIDE>(x, 1, tc, true);
 			nb = zero4;
 			if (take && tc < x.ncols) nb = *(const u32x4*)(x.bnd + 4 * (int64_t)tc);
+			nb = bnd_in(nb, tc);
 		}
 		wave_lds_fence();
 		if (s0 >= GL + 16 && stg) {   /* boundary-out records of columns [s0-GL-16, s0-GL) are complete */
 			const int tc = s0 - GL - 16 + l16;
 			if (x.mine && tc < x.ncols) {
-				const u32x4 rec = lds_ld128(lds, x.bout + 16u * ((u32)tc & x.bmask));
+				const u32x4 rec = bnd_out(lds_ld128(lds, x.bout + 16u * ((u32)tc & x.bmask)), tc);
 				if (!x.last) *(u32x4*)(x.bnd + 4 * (int64_t)tc) = rec;
 				else if (!CAPTURE && tc >= x.store_from) { x.o16[tc] = rec[2]; x.o8[tc] = rec[3]; }
 			}
@@ -1306,17 +1310,26 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			   the next column run: the compare that feeds it is a whole step old by then, while at the end of its own step the scalar
 			   unit would wait for the vector compare every time (config 4's fill: 1602 -> 1546 ms).  H still holds that column.
 			   (k_filldb, where the branch is taken in most steps, got slower with the same change.) */
-			if (!CAPTURE && pend != 0ull) strip_record<R>(sbest, prep, tc - 1, x, st.H, sv, stc, srow);
+			if (!CAPTURE && pend != 0ull) strip_record<R>(sbest, prep, tc - 1, x, st.H, sv, stc, srow, FR ? (int)((fl - x.gapE2) & 0xffffu) : 0);
+			if (FR) { fl += x.gapE2; sbest += x.gapE2; }      /* the lane's record follows the frame of its column */
 			const u32 pre = pk_max(sbest, cm);   /* fill: the lane's running record and this column's rows above */
 #pragma unroll
 			for (int r = 0; r < R; ++r) {
 				const u32 hold = st.H[r];
 				const u32 sv = sc[r >> 2][r & 3];
+				u32 h;
+				if (FR) {
+					h = pk_max3_fr(d + sv, st.E[r], f);
+					const u32 t = h - fr_c1;
+					st.E[r] = pk_max3_fr(st.E[r], t, fl);
+					f = pk_max(f, t) - x.gapE2;
+				} else {
 				const u32 h0 = pk_max(pk_adds(d, sv), st.E[r]);
-				const u32 h = pk_max(h0, f);
+				h = pk_max(h0, f);
 				const u32 t0 = pk_subu(h0, x.gapO2);
 				st.E[r] = pk_max(pk_subu(st.E[r], x.gapE2), t0);
 				f = pk_max(pk_subu(f, x.gapE2), t0);
+				}
 				if (CAPTURE) lm = pk_max(lm, h);
 				else if (CM3 && !MASK8) {   /* column maximum of two rows in one instruction (scores below 31744: pk_max3_nonneg) */
 					if (r & 1) cm = pk_max3_nonneg(cm, st.H[r - 1 >= 0 ? r - 1 : 0], h);
@@ -1355,12 +1368,12 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			}
 		}
 	}
-	if (!CAPTURE && pend != 0ull) strip_record<R>(sbest, prep, x.nsteps - 1 - l16, x, st.H, sv, stc, srow);
+	if (!CAPTURE && pend != 0ull) strip_record<R>(sbest, prep, x.nsteps - 1 - l16, x, st.H, sv, stc, srow, FR ? (int)((fl - x.gapE2) & 0xffffu) : 0);
 	wave_lds_fence();
 	for (int base = x.nsteps - GL - 16; base < x.nsteps - GL + 16; base += 16) {
 		const int tc = base + l16;
 		if (stg && x.mine && tc >= 0 && tc < x.ncols) {
-			const u32x4 rec = lds_ld128(lds, x.bout + 16u * ((u32)tc & x.bmask));
+			const u32x4 rec = bnd_out(lds_ld128(lds, x.bout + 16u * ((u32)tc & x.bmask)), tc);
 			if (!x.last) *(u32x4*)(x.bnd + 4 * (int64_t)tc) = rec;
 			else if (!CAPTURE && tc >= x.store_from) { x.o16[tc] = rec[2]; x.o8[tc] = rec[3]; }
 		}
@@ -1442,6 +1455,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 	x.bout = x.bin + BND_RING_BYTES; x.nulloff = (u32)a.n * G::PSTRIDE;
 	const u32 red = x.bout + BND_RING_BYTES;
 	x.l16 = l16; x.gapO2 = a.gapO2; x.gapE2 = a.gapE2; x.n = a.n; x.tg = a.tgt; x.bmask = 63u;
+	x.fr_base = 0; x.fr_kmask = 0; x.gapEi = 0;
 	const int job = (int)blockIdx.x * (64 / GL) + grp;
 	const bool valid = job < a.njobs;
 
@@ -1581,6 +1595,7 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 	x.bout = x.bin + BND_RING_BYTES; x.nulloff = (u32)a.n * G::PSTRIDE; x.bmask = 31u;
 	const u32 red = x.bin;
 	x.l16 = l16; x.gapO2 = a.gapO2; x.gapE2 = a.gapE2; x.n = a.n; x.tg = a.tgt;
+	x.fr_base = a.fr_base; x.fr_kmask = a.fr_kmask; x.gapEi = (int)(a.gapE2 & 0xffffu);
 	const int S = a.strips, nitems = a.njobs * S;
 	int* const ticket = a.queue; int* const flags = a.queue + 1;
 
@@ -1665,7 +1680,7 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 				if (floorv > st.best[h]) { st.best[h] = floorv; st.btc[h] = 0x7fffffff; st.brow[h] = 0; }
 			}
 		}
-		build_profile_strip<R, GL>(lds, x.prof, l16, GL, a.mat, a.n, qa, lena, rev, rowsa, qb, lenb, rev, rowsb, x.row0);
+		build_profile_strip<R, GL, !CAPTURE && FORM == 3>(lds, x.prof, l16, GL, a.mat, a.n, qa, lena, rev, rowsa, qb, lenb, rev, rowsb, x.row0, (int)(a.gapE2 & 0xffffu));
 		u32 m8[R];
 		bool need_mask = false;
 		if (!CAPTURE) {
@@ -1679,8 +1694,8 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 #pragma unroll
 			for (int q = 0; q < R; ++q) m8[q] = 0;
 		}
-		if (!CAPTURE && need_mask) run_strip<R, CAPTURE, true, GL, false>(lds, x, st, m8);
-		else run_strip<R, CAPTURE, false, GL, FORM == 2>(lds, x, st, m8);
+		if (!CAPTURE && need_mask) run_strip<R, CAPTURE, true, GL, false, !CAPTURE && FORM == 3>(lds, x, st, m8);
+		else run_strip<R, CAPTURE, false, GL, FORM >= 2, !CAPTURE && FORM == 3>(lds, x, st, m8);
 
 		/* chain-wide winner of this strip merged with the strips above: value, then first column, then smallest row */
 		for (int h = 0; h < 2; ++h) {
@@ -2765,6 +2780,7 @@ extern "C" int ssw_shim_launch_chainq(int R, int capture, const ssw_chainx_args*
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * StripGeom<r, 64>::PSTRIDE + (capture ? QueueGeom<r, true>::EXTRA : QueueGeom<r, false>::EXTRA); \
 		if (capture) SSW_LAUNCH((k_chainq<r, true, 0>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
+		else if (args.form == 3) SSW_LAUNCH((k_chainq<r, false, 3>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
 		else if (args.form == 2) SSW_LAUNCH((k_chainq<r, false, 2>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
 		else SSW_LAUNCH((k_chainq<r, false, 0>), ssw_chainx_args, args, grid, 64, ldsb, stream); } break;
 		FOR_EACH_QR(X)

@@ -34,7 +34,10 @@ def reflib():
 @pytest.fixture(scope="session")
 def emu_lib_path():
     """The REAL host driver + REAL kernel source on the CPU SIMT emulator (tests/emu) -- test-only."""
-    subprocess.run(["make", "-C", os.path.join(HERE, "emu"), "-s"], check=True)
+    import fcntl
+    with open(os.path.join(HERE, "emu", ".build.lock"), "w") as lk:      # pytest-xdist workers build once, not against each other
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.run(["make", "-C", os.path.join(HERE, "emu"), "-s", "libssw_emu.so", "ssw_test_emu"], check=True)
     return os.path.join(HERE, "emu", "libssw_emu.so")
 
 

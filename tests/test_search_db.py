@@ -82,94 +82,75 @@ def test_streamed_search_equals_batch_gpu(gpu_ctx):
         assert (r2[f] == res[f][sub][:, :40]).all()
 
 
-# ---- the f16 form of the fused kernel saturates at 2048: workgroups that see it repeat in the int16 form ----
-def _f16_limit_case():
-    """n = 5 alphabet, A-A scores 7, C-C 1, G-G 5, every mismatch -4: the self-alignment of A^292 C^k scores 2044 + k --
-    2047 (exact in f16), 2048 (the saturation value itself) and 2049-2051 (beyond it), next to unrelated short sequences
-    and longer homologs far above the limit; several sequences per size class so that chains of one workgroup disagree."""
+# ---- scores around 2048 (where the f16 form of rounds 1-2 saturated and workgroups had to repeat): the column-frame form has no limit
+#      there -- same records as the plain int16 form and as the reference ----
+def _around_2048_case():
+    """n = 5 alphabet, A-A scores 7, C-C 1, G-G 5, every mismatch -4: the self-alignment of A^292 C^k scores 2044 + k -- 2047, 2048,
+    2049-2051 -- next to unrelated short sequences and longer homologs far above; several sequences per size class so that the
+    chains of one workgroup see very different scores."""
     mat = np.full((5, 5), -4, dtype=np.int8)
     mat[0, 0] = 7; mat[1, 1] = 1; mat[2, 2] = 5; mat[3, 3] = 2
     mat[4, :] = 0; mat[:, 4] = 0
     rng = np.random.default_rng(77)
     seqs = [np.array([0] * 292 + [1] * k, dtype=np.int8) for k in (0, 2, 3, 4, 5, 7)]
-    seqs.append(np.array([0] * 300 + [2] * 100, dtype=np.int8))          # 2600: far above, another size class
-    seqs.append(np.array([0] * 120 + [1] * 30, dtype=np.int8))           # 870: stays f16
+    seqs.append(np.array([0] * 300 + [2] * 100, dtype=np.int8))          # 2600: another size class
+    seqs.append(np.array([0] * 120 + [1] * 30, dtype=np.int8))           # 870
     seqs += [rng.integers(0, 4, size=int(L), dtype=np.int8) for L in (295, 299, 150, 301, 64)]
     return seqs, np.ascontiguousarray(mat.reshape(-1))
 
 
-def _f16_limit_check(ctx, monkeypatch):
-    seqs, mat = _f16_limit_case()
-    monkeypatch.setenv("SSW_GPU_DB_F16", "1")          # f16 form first in every call (most workgroups of this case repeat: the library would pause it)
+def _around_2048_check(ctx, monkeypatch):
+    seqs, mat = _around_2048_case()
     res = _case(ctx, seqs, seqs, mat, 5, 3, 1, chunks=(4, 0))
     s = np.array([[int(res["score1"][i, j]) for j in range(6)] for i in range(6)])
     assert s[2, 2] == 2047 and s[3, 3] == 2048 and s[4, 4] == 2049 and s[5, 5] == 2051 and s[0, 5] == 2044
     assert int(res["score1"][6, 6]) == 2600
     tm = ctx.timing()
-    assert "f16 first" in tm["fill_kernel"] and tm["db_repeats"] > 0, tm
-    monkeypatch.setenv("SSW_GPU_DB_F16", "0")          # the int16 form alone gives the same records
+    assert "frame" in tm["fill_kernel"] and tm["db_repeats"] == 0, tm
+    monkeypatch.setenv("SSW_GPU_DB_FORM", "0")         # the plain int16 form gives the same records
     res2 = _case(ctx, seqs, seqs, mat, 5, 3, 1, chunks=(0,), check_ref=False)
-    assert ctx.timing()["db_repeats"] == 0
-    monkeypatch.delenv("SSW_GPU_DB_F16")
+    assert "frame" not in ctx.timing()["fill_kernel"]
+    monkeypatch.delenv("SSW_GPU_DB_FORM")
     for f in ("score1", "score2", "ref_end1", "read_end1", "ref_end2"):
         assert (res2[f] == res[f]).all(), f
-    # left to itself the library notices the repeats and pauses the f16 form on this context
-    own = ssw_amd.Context(0, ctx.lib)          # (a context of its own: the pause would outlive this test on the shared one)
-    Q = own.upload(seqs); T = own.upload(seqs)
-    try:
-        own.align_batch(Q, T, mat, 5, 3, 1, 0, 0, 0, -1, 2)
-        first = own.timing()
-        own.align_batch(Q, T, mat, 5, 3, 1, 0, 0, 0, -1, 2)
-        second = own.timing()
-    finally:
-        Q.free(); T.free(); own.close()
-    assert first["db_repeats"] > 0 and second["db_repeats"] == 0 and "f16" not in second["fill_kernel"], (first, second)
+    monkeypatch.setenv("SSW_GPU_FRAME_K", "16")        # renormalised every 16 steps
+    res3 = _case(ctx, seqs, seqs, mat, 5, 3, 1, chunks=(3,), check_ref=False)
+    monkeypatch.delenv("SSW_GPU_FRAME_K")
+    for f in ("score1", "score2", "ref_end1", "read_end1", "ref_end2"):
+        assert (res3[f] == res[f]).all(), f
 
 
-def test_f16_form_limit_and_int16_repeat_emulated(ectx, monkeypatch):
-    _f16_limit_check(ectx, monkeypatch)
+def test_scores_around_2048_frame_and_int16_forms_emulated(ectx, monkeypatch):
+    _around_2048_check(ectx, monkeypatch)
 
 
 @pytest.mark.gpu
-def test_f16_form_limit_and_int16_repeat_gpu(gpu_ctx, monkeypatch):
-    _f16_limit_check(gpu_ctx, monkeypatch)
+def test_scores_around_2048_frame_and_int16_forms_gpu(gpu_ctx, monkeypatch):
+    _around_2048_check(gpu_ctx, monkeypatch)
 
 
-def _streamed_pause_check(ctx_factory):
-    """a database searched against itself, streamed in small chunks: the self-hits above 2048 make most workgroups of the first
-    chunks repeat in the int16 form, the library then starts the following chunks in the int16 form -- same records either way"""
-    seqs, mat = _f16_limit_case()
-    seqs = (seqs[:5] + seqs[8:9]) * 2        # 12 entries, long self-hits in every chunk of 3
+def _small_budget_check(ctx_factory, monkeypatch, nq):
+    """many queries of ONE length against >= 4 targets with a small column-maximum budget -- a size class whose pairs
+    do not fit a stream's slice of the scratch is cut into launches of fewer pairs instead of failing (or asking for terabytes)"""
+    monkeypatch.setenv("SSW_GPU_CM_BUDGET_MB", "1")
+    rng = np.random.default_rng(5)
+    ref = random_ref(3000, 21, 4)
+    db = [np.ascontiguousarray(ref[o:o + L]) for o, L in ((0, 900), (500, 1200), (1500, 700), (100, 333), (2000, 1000))]
+    qs = [np.ascontiguousarray(ref[o:o + 100]) for o in rng.integers(0, 2900, size=nq)]
     own = ctx_factory()
-    Q = own.upload(seqs); T = own.upload(seqs)
     try:
-        hits = own.search_db(Q, T, mat, 5, 3, 1, -1, 2, 3)
-        tm = own.timing()
-        res, _ = own.align_batch(Q, T, mat, 5, 3, 1, 0, 0, 0, -1, 2)
+        _case(own, qs, db, dna_matrix(2, 2), 5, 3, 1, chunks=(0, 2))
     finally:
-        Q.free(); T.free(); own.close()
-    _same(hits, res)
-    assert "f16 first" in tm["fill_kernel"] and tm["db_repeats"] > 0      # it started with the f16 form and noticed
-    forced = ctx_factory()                  # the same with the f16 form forced in every chunk: more repeats
-    os.environ["SSW_GPU_DB_F16"] = "1"
-    try:
-        Q = forced.upload(seqs); T = forced.upload(seqs)
-        hits2 = forced.search_db(Q, T, mat, 5, 3, 1, -1, 2, 3)
-        tm2 = forced.timing()
-        Q.free(); T.free()
-    finally:
-        del os.environ["SSW_GPU_DB_F16"]; forced.close()
-    _same(hits2, res)
-    assert tm["db_repeats"] < tm2["db_repeats"], (tm, tm2)
+        own.close()
 
 
-def test_streamed_search_pauses_f16_form_emulated(emu_lib_path):
-    _streamed_pause_check(lambda: ssw_amd.Context(0, ssw_amd.load(emu_lib_path)))
+def test_size_class_larger_than_the_scratch_budget_emulated(emu_lib_path, monkeypatch):
+    _small_budget_check(lambda: ssw_amd.Context(0, ssw_amd.load(emu_lib_path)), monkeypatch, 14)
 
 
 @pytest.mark.gpu
-def test_streamed_search_pauses_f16_form_gpu(gpu_ctx):
-    _streamed_pause_check(lambda: ssw_amd.Context(0, gpu_ctx.lib))
+def test_size_class_larger_than_the_scratch_budget_gpu(gpu_ctx, monkeypatch):
+    _small_budget_check(lambda: ssw_amd.Context(0, gpu_ctx.lib), monkeypatch, 400)
 
 
 # ---- random scoring systems through the fused kernel (f16 form first): matrices up to its limit of 49, large gap penalties, all
