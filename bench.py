@@ -22,7 +22,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields:
                   timed region: rate, roofline fraction of their fill kernel, parity against tests/golden/full
   roofline        HBM view of the dominant fill kernel: algorithmic bytes per launch / mean launch time (HIP events on the
                   library's stream), `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes of THIS kernel
-                  source (profiles/round2_traffic.json; null when the source changed since)
+                  source (profiles/round3_traffic.json; null when the source changed since)
   roofline_valu   the binding roofline of this integer max-plus recurrence: packed 16-bit VALU issue rate
   value_with_h2d  the same batch with the queries uploaded inside the step (PCIe-inclusive; `value` is the resident rate)
   cpu_baseline    the unmodified reference (oracle/_ref, its SSE2 path) on this host's usable cores, bounded sample
@@ -77,10 +77,10 @@ def kernel_source_id():
 
 
 def measured_traffic(key):
-    """HBM bytes per alignment of the dominant kernel from the rocprofv3 PMC passes (scripts/gpu_profile_round2.sh ->
-    profiles/round2_traffic.json), only if they were taken on this very kernel source"""
+    """HBM bytes per alignment of the dominant kernel from the rocprofv3 PMC passes (scripts/gpu_profile_round3.sh ->
+    profiles/round3_traffic.json), only if they were taken on this very kernel source"""
     try:
-        with open(os.path.join(ROOT, "profiles", "round2_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "round3_traffic.json")) as f:
             tj = json.load(f)
         ent = tj.get(key)
         if ent and tj.get("kernel_source_sha16") == kernel_source_id():
@@ -257,9 +257,10 @@ def bench_dna(args, world, rank, local_rank, dist):
             out["config"]["note"] = "in-library per-GPU work queues (ssw_gpu_pool): reads on the host, blocks uploaded by the workers inside the step"
             out["pool_stats"] = pool.stats()
         if tm is not None:
-            f16_form = tm["fill_ops_per_row"] == 7.5
-            if f16_form:
+            if tm["fill_ops_per_row"] == 7.5:
                 out["dtype"] = "f16x2 holding exact integers (scores/2048); reference u8/int16 semantics"
+            elif tm["fill_ops_per_row"] == 6.5:
+                out["dtype"] = "int16x2 in a column frame (value + phi(column); 32-bit adds on the packed pair, three-input maxima on the bit patterns); reference u8/int16 semantics"
             out["mix"] = {"word_rules": int(tm["n_word"]), "byte_rules": int(tm["n_byte"])}
             out["phases_ms_per_step"] = {"fill": round(acc["fill_ms"] / args.steps, 3), "locate": round(acc["locate_ms"] / args.steps, 3),
                                          "trace": round(acc["trace_ms"] / args.steps, 3), "reduce_and_copies": round(acc["reduce_ms"] / args.steps, 3)}
@@ -277,8 +278,8 @@ def bench_dna(args, world, rank, local_rank, dist):
             out["roofline"] = {"bound": "hbm", "kernel": tm["fill_kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "traffic_note": ("GB/s from rocprofv3 FETCH_SIZE + WRITE_SIZE of this kernel, PMC passes of this kernel source "
-                                                "(profiles/round2_traffic.json, source %s)" % kernel_source_id()) if traffic is not None else
-                                               "no PMC pass of this kernel source committed (scripts/gpu_profile_round2.sh writes profiles/round2_traffic.json)",
+                                                "(profiles/round3_traffic.json, source %s)" % kernel_source_id()) if traffic is not None else
+                                               "no PMC pass of this kernel source committed (scripts/gpu_profile_round3.sh writes profiles/round3_traffic.json)",
                                "launch_ms": round(launch_ms, 3), "launches": int(acc["fill_launches"]),
                                "algorithmic_bytes_per_alignment": int(bytes_per_aln),
                                "note": "integer max-plus recurrence: HBM is not the binding resource, see roofline_valu"}
@@ -290,7 +291,8 @@ def bench_dna(args, world, rank, local_rank, dist):
                                     "unit": "T lane-op/s", "frac": round(achieved_valu / VALU_PEAK_LANEOPS, 4),
                                     "frac_on_real_cells": round(real / VALU_PEAK_LANEOPS, 4), "measured_peak_probe": round(probe / 1e12, 2),
                                     "ops_per_pair_row": tm["fill_ops_per_row"],
-                                    "note": "packed 16-bit (VOP3P) instruction rate of the fill kernel: 16 lanes/clk/SIMD (peak = 256 CU x 4 SIMD x 16 x 2.4 GHz); "
+                                    "note": "VALU issue slots of the fill kernel's recurrence: 4 cycles per wave64 instruction (VOP3P always; the 2-cycle 32-bit adds of "
+                                            "the column-frame form too when they alternate with VOP3P: profiles/round3_mix_issue_probe.txt), peak = 256 CU x 4 SIMD x 16 x 2.4 GHz; "
                                             "`frac` counts every evaluated cell (padding rows, halo columns), `frac_on_real_cells` only readLen x refLen",
                                     "fill_gcups_padded": round(acc["fill_cells"] / (acc["fill_ms"] * 1e-3) / 1e9, 1) if acc["fill_ms"] > 0 else 0.0}
             # PCIe-inclusive rate: one more step with the reads uploaded (and freed) inside it
@@ -446,7 +448,8 @@ def bench_db(args, world, rank, local_rank, dist):
         qsum = float(sum(len(x) for x in qs)); tsum = float(sum(len(x) for x in db))
         out = {"metric": "GCUPS", "value": round(cells * args.steps * world / dt / 1e9, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "int16x2 (packed; reference u8/int16 semantics)", "data": "synthetic",
+               "dtype": "int16x2 in a column frame (value + phi(column)); reference u8/int16 semantics" if "frame" in tm["fill_kernel"] else "int16x2 (packed; reference u8/int16 semantics)",
+               "data": "synthetic",
                "config": {"workload": "BASELINE config 5: %d protein queries (~300 aa) x %d DB entries per GPU, BLOSUM50, 3/1, score only, "
                                       "results streamed in chunks of %d entries" % (nq, nt, args.db_chunk), "baseline_config": 5,
                           "sharding": "query block r on rank r, DB replicated, no collective"},
@@ -472,7 +475,8 @@ def bench_db(args, world, rank, local_rank, dist):
         out["roofline_valu"] = {"bound": "valu-packed16", "achieved": round(achieved_valu / 1e12, 3), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
                                 "unit": "T lane-op/s", "frac": round(achieved_valu / VALU_PEAK_LANEOPS, 4), "frac_on_real_cells": round(real / VALU_PEAK_LANEOPS, 4),
                                 "measured_peak_probe": round(probe / 1e12, 2), "ops_per_pair_row": ops,
-                                "note": "recurrence instructions only (8.5 per row of a query pair); best-cell tracking and the fused reduction are overhead on top",
+                                "note": "recurrence instructions only (%.1f per row of a query pair, each a 4-cycle issue slot in this mix: profiles/round3_mix_issue_probe.txt); "
+                                        "best-cell tracking and the fused reduction are overhead on top" % ops,
                                 "fill_gcups_padded": round(fill_cells / (fill_ms * 1e-3) / 1e9, 1) if fill_ms > 0 else 0.0}
         if world == 1:
             par = {}

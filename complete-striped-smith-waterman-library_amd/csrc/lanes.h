@@ -87,16 +87,21 @@ SSW_DEV void dev_flag_set(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELE
 /* The poll is a RELAXED agent-scope load: an acquire load puts a cache invalidate (buffer_inv sc1) into every iteration, and a
    dozen wavefronts polling that way keep the L2 of their XCD busy invalidating -- the wavefront they are waiting for then
    crawls (seen on MI355X: a test batch with more strips than jobs went from milliseconds to minutes).  One acquire fence after
-   the flag has been seen (the caller's dev_fence) is all that is needed.  Bounded: a flag that does not come within seconds
+   the flag has been seen (the caller's dev_fence) is all that is needed.  Bounded: a flag that does not come within 30 seconds
    means a broken queue -- the caller raises the launch's error word and goes on, so that the host fails the call instead
    of the device hanging. */
 SSW_DEV bool dev_flag_wait(int* flag)
 {
-	for (int spin = 0; spin < (1 << 20); ++spin) {
-		if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
-		__builtin_amdgcn_s_sleep(64);
+	/* bounded by WALL CLOCK (s_memrealtime: the 100 MHz constant clock), 30 s: a strip over a multi-megabase tile legitimately runs for
+	   seconds, longer when ranks or pool workers share the device -- a poll count would fail such calls spuriously */
+	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+	for (;;) {
+		for (int spin = 0; spin < 4096; ++spin) {
+			if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+			__builtin_amdgcn_s_sleep(64);
+		}
+		if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) return false;
 	}
-	return false;
 }
 #endif
 

@@ -219,8 +219,11 @@ typedef struct {
 	int32_t maskLen, bias, score_size;
 	int32_t flag, filters, filterd;
 	ssw_dres* res;
-	uint8_t* scratch;        /* nq regions of scratch_stride bytes */
+	uint8_t* scratch;        /* nq regions of scratch_stride bytes: [state (state_bytes, unused when it lives in LDS)][maxColumn] */
 	int64_t scratch_stride;
+	int64_t mc_off;          /* offset of maxColumn in a region (= state_bytes rounded up to 16) */
+	int64_t state_bytes;     /* H x2, E, Hmax as [segments][16] int16 + codes, sized for the 16-bit kernel of the longest read */
+	int32_t lds_stride;      /* set by the launcher: > 0 = per-alignment state in LDS */
 } ssw_literal_args;
 
 /* banded traceback */

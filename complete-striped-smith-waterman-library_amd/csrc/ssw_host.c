@@ -124,6 +124,34 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
 	return c;
 }
 
+const char* ssw_gpu_strerror(int rc)
+{
+	switch (rc) {
+	case 0: return "ok";
+	case SSW_GPU_BUSY: return "the context is inside another call (one call at a time per context: open one context per thread)";
+	case -1: return "the call failed: ssw_gpu_last_error(ctx) has the reason";
+	default: return rc > 0 ? "stopped by the caller's chunk function (its return value)" : "the call failed";
+	}
+}
+
+/* Column-maximum / scratch budget of this context in bytes (0: back to the default, min(64 GiB, half of the free HBM at the time of
+   the call)).  Contexts that SHARE a device -- pool workers with repeated device indices, several ranks per GPU -- each take what
+   they are given: ssw_gpu_pool_open divides the default by the workers on a device. */
+int ssw_gpu_set_budget(ssw_gpu_ctx* c, size_t bytes)
+{
+	if (!c) return -1;
+	if (__atomic_load_n(&c->busy, __ATOMIC_ACQUIRE)) return SSW_GPU_BUSY;
+	if (bytes == 0) {
+		ssw_shim_set_device(c->device);
+		bytes = (size_t)64 << 30;
+		size_t fr = ssw_shim_mem_free_bytes(); if (fr && bytes > fr / 2) bytes = fr / 2;
+	}
+	if (bytes < ((size_t)1 << 20)) bytes = (size_t)1 << 20;
+	c->cm_budget = bytes;
+	return 0;
+}
+size_t ssw_gpu_get_budget(const ssw_gpu_ctx* c) { return c ? c->cm_budget : 0; }
+
 void ssw_gpu_close(ssw_gpu_ctx* c)
 {
 	if (!c) return;
@@ -227,7 +255,16 @@ int ssw_gpu_seqs_download(ssw_gpu_ctx* c, const ssw_gpu_seqs* s, int8_t* codes_o
 
 int32_t ssw_gpu_seqs_count(const ssw_gpu_seqs* s) { return s ? s->count : 0; }
 
-int ssw_gpu_last_timing(const ssw_gpu_ctx* c, ssw_gpu_timing* out) { if (!c || !out) return -1; *out = c->tm; return 0; }
+/* The timing record only ever grows at its END: a caller compiled against an older header passes its own sizeof and gets the
+   fields it knows (ssw_gpu_last_timing_sized); ssw_gpu_last_timing is the current header's full record. */
+int ssw_gpu_last_timing_sized(const ssw_gpu_ctx* c, void* out, size_t out_size)
+{
+	if (!c || !out) return -1;
+	memcpy(out, &c->tm, out_size < sizeof c->tm ? out_size : sizeof c->tm);
+	if (out_size > sizeof c->tm) memset((char*)out + sizeof c->tm, 0, out_size - sizeof c->tm);
+	return 0;
+}
+int ssw_gpu_last_timing(const ssw_gpu_ctx* c, ssw_gpu_timing* out) { return ssw_gpu_last_timing_sized(c, out, sizeof *out); }
 
 /* ------------------------------------------------------------------------------------------------ */
 
@@ -632,7 +669,7 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seq
 	if (__atomic_exchange_n(&c->busy, 1, __ATOMIC_ACQUIRE)) {
 		if (cigar_pool) *cigar_pool = 0;
 		if (cigar_words) *cigar_words = 0;
-		return -2;      /* (the error text of the running call is left alone) another thread is inside this context: open one context per thread */
+		return SSW_GPU_BUSY;      /* another thread is inside this context (its error text is the running call's: left alone; ssw_gpu_strerror names the code) */
 	}
 	const int rc = align_batch_locked(c, Q, T, tfirst, tcount, prm, results, cigar_pool, cigar_words, 0);
 	__atomic_store_n(&c->busy, 0, __ATOMIC_RELEASE);
@@ -801,7 +838,8 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		if (refLen > 0 && literal) {
 			/* scratch per alignment: 4 x [segments][16] int16 + codes + maxColumn (sized for the 16-bit kernel: 8 lanes) */
 			const int64_t seg8 = ((int64_t)maxlen + 7) / 8;
-			const int64_t sstr = (seg8 * 16 * 2 * 4 + seg8 * 16 + 64 + (int64_t)refLen * 2 + 64 + 15) / 16 * 16;
+			const int64_t lstate = (seg8 * 16 * 2 * 4 + seg8 * 16 + 64 + 15) / 16 * 16;
+			const int64_t sstr = (lstate + (int64_t)refLen * 2 + 64 + 15) / 16 * 16;
 			int64_t per = (int64_t)(c->cm_budget / (size_t)sstr); if (per < 1) per = 1;
 			void* e0 = next_event(c); void* e1 = next_event(c);
 			ssw_shim_event_record(e0, c->stream);
@@ -814,7 +852,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 					la.tgt = d_tgt; la.refLen = refLen; la.qcodes = Q->d_codes; la.qoff = Q->d_off; la.qlist = d_qlist + q0; la.nq = cnt_q;
 					la.mat = d_mat; la.n = n; la.gapO = prm->gapO; la.gapE = prm->gapE; la.pass = pass; la.maskLen = prm->maskLen; la.bias = bias;
 					la.score_size = prm->score_size; la.flag = prm->flag; la.filters = prm->filters; la.filterd = prm->filterd; la.res = d_res;
-					la.scratch = d_scr; la.scratch_stride = sstr;
+					la.scratch = d_scr; la.scratch_stride = sstr; la.mc_off = lstate; la.state_bytes = lstate; la.lds_stride = 0;
 					if (ssw_shim_launch_literal(&la, c->stream)) { fail(c, "literal launch failed: %s", ssw_shim_last_error()); goto done; }
 				}
 			ssw_shim_event_record(e1, c->stream);
@@ -1268,7 +1306,7 @@ int ssw_gpu_search_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs*
 	if (!Q || !T || !prm || !fn || !prm->mat) return fail(c, "search_db: NULL argument%s", "");
 	if (Q->ctx != c || T->ctx != c) return fail(c, "search_db: sequences belong to another context%s", "");
 	if (prm->flag != 0) return fail(c, "search_db: scores and end positions only (flag must be 0)%s", "");
-	if (__atomic_exchange_n(&c->busy, 1, __ATOMIC_ACQUIRE)) return -2;
+	if (__atomic_exchange_n(&c->busy, 1, __ATOMIC_ACQUIRE)) return SSW_GPU_BUSY;
 	ssw_shim_set_device(c->device);
 	const int32_t nq = Q->count, nt_all = T->count;
 	int rc = 0;

@@ -131,9 +131,30 @@ SSW_DEV void chain_rows_cm3(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32& d, u
 /* column-frame form of rows [R0, R1) (lanes.h): 3 plain 32-bit adds + 3.5 packed maxima per row.  c1 = gapO - gapE (packed),
    fl = phi(column + 1): the floor that keeps E at "0" or above.
      h = max3(d + s', E, F)        t = h - c1        E' = max3(E, t, fl)        F' = max(F, t) - gapE        cm = max3(cm, h_r, h_r+1) */
+#ifndef FR_HOIST_ADDS      /* 1: the diag + score adds of a lane's rows as ONE run ahead of the maxima (experiment: runs of 2-cycle adds issue faster) */
+#define FR_HOIST_ADDS 0
+#endif
 template <int R, int R0, int R1>
 SSW_DEV void chain_rows_fr(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32& d, u32& f, u32& cm, u32 c1, u32 gapE2, u32 fl)
 {
+#if FR_HOIST_ADDS
+	u32 x[R1 - R0 > 0 ? R1 - R0 : 1];
+#pragma unroll
+	for (int r = R0; r < R1; ++r) x[r - R0] = (r == R0 ? d : H[r - 1]) + sc[r >> 2][r & 3];
+	if (R1 > R0) d = H[R1 - 1];
+	sched_fence();
+#pragma unroll
+	for (int r = R0; r < R1; ++r) {
+		const u32 h = pk_max3_fr(x[r - R0], E[r], f);
+		const u32 t = h - c1;
+		E[r] = pk_max3_fr(E[r], t, fl);
+		f = pk_max(f, t) - gapE2;
+		if (((r - R0) & 1) == 1) cm = pk_max3_fr(cm, H[r - 1 >= 0 ? r - 1 : 0], h);
+		else if (r == R1 - 1) cm = pk_max(cm, h);
+		H[r] = h;
+	}
+	return;
+#endif
 #pragma unroll
 	for (int r = R0; r < R1; ++r) {
 		const u32 hold = H[r];
@@ -694,8 +715,11 @@ SSW_DEV void filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 #ifndef DB_UNROLL
 #define DB_UNROLL 2
 #endif
+#ifndef DB_WAVES_PER_EU      /* register budget of k_filldb as wavefronts per SIMD (experiments: scripts/build_variants.sh) */
+#define DB_WAVES_PER_EU 1
+#endif
 template <int R, int NCH, bool FR>
-__global__ void __launch_bounds__(16 * NCH) k_filldb(ssw_filldb_args a)
+__global__ void __launch_bounds__(16 * NCH) SSW_WAVES_PER_EU(DB_WAVES_PER_EU, 8) k_filldb(ssw_filldb_args a)
 {
 	SSW_DYN_LDS(lds);
 	if (FR) filldb_pass<R, NCH, true, DB_UNROLL>(a, lds);
@@ -1271,7 +1295,10 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 		}
 		wave_lds_fence();
 		const u32 rpo = 2u * (u32)((s0 - l16) & (RB - 1));
-#pragma unroll 2
+#ifndef STRIP_UNROLL
+#define STRIP_UNROLL 2
+#endif
+#pragma unroll STRIP_UNROLL
 		for (int j = 0; j < 16; ++j) {
 			const int s = s0 + j, tc = s - l16;
 			u32x4 sc[C];
@@ -1745,18 +1772,19 @@ SSW_DEV int lit_rowmin(int v) { return -lit_rowmax(-v); }
 /* one call == sw_sse2_byte (is_byte) / sw_sse2_word on one row of lanes; `on` = this row takes part */
 SSW_DEV void literal_fill(bool on, bool is_byte, const int8_t* ref, int ref_dir, int refLen, const int8_t* read, int readLen, int rev_read,
                           const int8_t* mat, int n, int gapO, int gapE, int terminate, int bias, int maskLen,
-                          unsigned char* scratch, int tid, LitOut& out)
+                          unsigned char* state, uint16_t* mc, int tid, LitOut& out)
 {
+	/* `state`: the alignment's H / E / Hmax / code arrays -- every lane only touches its own column of them -- in LDS when they fit
+	   (short reads: 16 alignments per workgroup), else in HBM scratch; `mc`: maxColumn, always in HBM */
 	const int l16 = tid & 15, grp = (tid & 63) >> 4;
 	const int L = is_byte ? 16 : 8;
 	const bool lane_on = on && l16 < L;
 	const int segLen = on ? (readLen + L - 1) / L : 0;
-	int16_t* Hbuf0 = (int16_t*)scratch;
+	int16_t* Hbuf0 = (int16_t*)state;
 	int16_t* Hbuf1 = Hbuf0 + (size_t)segLen * 16;
 	int16_t* Eb = Hbuf1 + (size_t)segLen * 16;
 	int16_t* Hmx = Eb + (size_t)segLen * 16;
 	int8_t* code = (int8_t*)(Hmx + (size_t)segLen * 16);
-	uint16_t* mc = (uint16_t*)(code + (((size_t)segLen * 16 + 15) & ~(size_t)15));
 	/* uniform loop bounds for the 4 rows of the wavefront */
 	int maxseg = segLen, maxcol = on ? refLen : 0;
 #pragma unroll
@@ -1869,12 +1897,15 @@ SSW_DEV void literal_fill(bool on, bool is_byte, const int8_t* ref, int ref_dir,
 	out.ref = end_ref; out.read = end_read; out.score2 = s2m; out.ref2 = s2m > 0 ? i2m : 0;
 }
 
-__global__ void __launch_bounds__(64) k_literal(ssw_literal_args a)
+__global__ void __launch_bounds__(256) k_literal(ssw_literal_args a)
 {
+	SSW_DYN_LDS(lds);
 	const int tid = (int)threadIdx.x, l16 = tid & 15, grp = tid >> 4;
-	const int job = (int)blockIdx.x * 4 + grp;
+	const int job = (int)blockIdx.x * ((int)blockDim.x >> 4) + grp;
 	const int q = job < a.nq ? a.qlist[job] : -1;
-	unsigned char* scratch = a.scratch + (int64_t)(job < a.nq ? job : 0) * a.scratch_stride;
+	unsigned char* const gscr = a.scratch + (int64_t)(job < a.nq ? job : 0) * a.scratch_stride;
+	unsigned char* const scratch = a.lds_stride > 0 ? lds + (size_t)grp * (size_t)a.lds_stride : gscr;
+	uint16_t* const mc = (uint16_t*)(gscr + a.mc_off);
 	const int8_t* read = q >= 0 ? a.qcodes + a.qoff[q] : a.qcodes;
 	const int readLen = q >= 0 ? (int)(a.qoff[q + 1] - a.qoff[q]) : 0;
 	const int maskLen = a.maskLen >= 0 ? a.maskLen : readLen / 2;
@@ -1889,14 +1920,14 @@ __global__ void __launch_bounds__(64) k_literal(ssw_literal_args a)
 		bool done = q < 0;
 		if (wave_any(q >= 0 && have_byte)) {
 			literal_fill(q >= 0 && have_byte, true, a.tgt, 0, a.refLen, read, readLen, 0, a.mat, a.n, a.gapO, a.gapE, 255, a.bias, maskLen,
-			             scratch, tid, o);
+			             scratch, mc, tid, o);
 			if (q >= 0 && have_byte) {
 				if (o.score == 255) { if (have_word) need_word = true; else { r.status = 1; done = true; } }
 			}
 		}
 		if (wave_any(need_word)) {
 			LitOut w;
-			literal_fill(need_word, false, a.tgt, 0, a.refLen, read, readLen, 0, a.mat, a.n, a.gapO, a.gapE, 65535, 0, maskLen, scratch, tid, w);
+			literal_fill(need_word, false, a.tgt, 0, a.refLen, read, readLen, 0, a.mat, a.n, a.gapO, a.gapE, 65535, 0, maskLen, scratch, mc, tid, w);
 			if (need_word) { o = w; r.word = 1; }
 		}
 		if (q >= 0 && !done && o.score > 0) {
@@ -1913,12 +1944,12 @@ __global__ void __launch_bounds__(64) k_literal(ssw_literal_args a)
 		const int plen = act ? r.read_end1 + 1 : 0, cols = act ? r.ref_end1 + 1 : 0;
 		if (wave_any(actb)) {
 			LitOut w;
-			literal_fill(actb, true, a.tgt, 1, cols, read, plen, 1, a.mat, a.n, a.gapO, a.gapE, r.score1 & 0xff, a.bias, maskLen, scratch, tid, w);
+			literal_fill(actb, true, a.tgt, 1, cols, read, plen, 1, a.mat, a.n, a.gapO, a.gapE, r.score1 & 0xff, a.bias, maskLen, scratch, mc, tid, w);
 			if (actb) o = w;
 		}
 		if (wave_any(actw)) {
 			LitOut w;
-			literal_fill(actw, false, a.tgt, 1, cols, read, plen, 1, a.mat, a.n, a.gapO, a.gapE, r.score1 & 0xffff, 0, maskLen, scratch, tid, w);
+			literal_fill(actw, false, a.tgt, 1, cols, read, plen, 1, a.mat, a.n, a.gapO, a.gapE, r.score1 & 0xffff, 0, maskLen, scratch, mc, tid, w);
 			if (actw) o = w;
 		}
 		if (act && l16 == 0) {
@@ -2824,7 +2855,17 @@ extern "C" int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream)
 {
 	ssw_literal_args args = *a;
 	if (args.nq <= 0) return 0;
-	SSW_LAUNCH(k_literal, ssw_literal_args, args, (args.nq + 3) / 4, 64, 0, stream);
+	/* short reads: the per-alignment state lives in LDS, 16 alignments per 256-thread workgroup (up to 64 KiB), or 4 per wavefront-sized
+	   workgroup (up to 160 KiB); longer reads keep it in the HBM scratch */
+	const int64_t st = args.state_bytes;
+	int threads = 64;
+	args.lds_stride = 0;
+	/* (an alignment is one DPP row -- 16 lanes -- whatever the workgroup: small batches take wavefront-sized workgroups so that
+	   they spread over more CUs) */
+	if (st > 0 && st * 16 <= 65536 && args.nq >= 16 * 2048) { threads = 256; args.lds_stride = (int32_t)st; }
+	else if (st > 0 && st * 4 <= (int64_t)SSW_LDS_LIMIT) { threads = 64; args.lds_stride = (int32_t)st; }
+	const int per = threads / 16;
+	SSW_LAUNCH(k_literal, ssw_literal_args, args, (args.nq + per - 1) / per, threads, (size_t)args.lds_stride * per, stream);
 	return SSW_LAUNCH_OK();
 }
 

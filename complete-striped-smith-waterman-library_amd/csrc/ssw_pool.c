@@ -95,6 +95,14 @@ ssw_gpu_pool* ssw_gpu_pool_open(const int* devices, int n)
 		p->w[i].ctx = ssw_gpu_open(p->w[i].device);
 		if (!p->w[i].ctx) { ssw_gpu_pool_close(p); return 0; }   /* the reason stays in ssw_gpu_last_error(NULL) */
 	}
+	/* workers that share a device share its HBM: every context sized its scratch budget from what was free when IT was opened
+	   (half of it) -- divide by the number of workers on that device (an explicit SSW_GPU_CM_BUDGET_MB is per context and kept) */
+	if (!getenv("SSW_GPU_CM_BUDGET_MB"))
+		for (int i = 0; i < n; ++i) {
+			int same = 0;
+			for (int j = 0; j < n; ++j) if (p->w[j].device == p->w[i].device) ++same;
+			if (same > 1) ssw_gpu_set_budget(p->w[i].ctx, ssw_gpu_get_budget(p->w[i].ctx) / (size_t)same);
+		}
 	return p;
 }
 
@@ -117,7 +125,13 @@ int ssw_gpu_pool_set_targets(ssw_gpu_pool* p, const int8_t* codes, const int64_t
 	for (int i = 0; i < p->n; ++i) {
 		if (p->w[i].targets) { ssw_gpu_seqs_free(p->w[i].targets); p->w[i].targets = 0; }
 		p->w[i].targets = ssw_gpu_seqs_upload(p->w[i].ctx, codes, offsets, count);
-		if (!p->w[i].targets) { snprintf(p->err, sizeof p->err, "worker %d (device %d): %s", i, p->w[i].device, ssw_gpu_last_error(p->w[i].ctx)); return -1; }
+		if (!p->w[i].targets) {
+			snprintf(p->err, sizeof p->err, "worker %d (device %d): %s", i, p->w[i].device, ssw_gpu_last_error(p->w[i].ctx));
+			/* all or nothing: a pool with the new targets on some workers and the old count would answer with mixed data */
+			for (int j = 0; j < p->n; ++j) if (p->w[j].targets) { ssw_gpu_seqs_free(p->w[j].targets); p->w[j].targets = 0; }
+			p->tcount = 0;
+			return -1;
+		}
 	}
 	p->tcount = count;
 	return 0;

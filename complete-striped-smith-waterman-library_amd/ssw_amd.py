@@ -107,6 +107,14 @@ def load(path=None):
     L.ssw_gpu_align_batch.restype = C.c_int
     L.ssw_gpu_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.ssw_gpu_last_timing.restype = C.c_int
+    L.ssw_gpu_last_timing_sized.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.ssw_gpu_last_timing_sized.restype = C.c_int
+    L.ssw_gpu_strerror.argtypes = [C.c_int]
+    L.ssw_gpu_strerror.restype = C.c_char_p
+    L.ssw_gpu_set_budget.argtypes = [C.c_void_p, C.c_size_t]
+    L.ssw_gpu_set_budget.restype = C.c_int
+    L.ssw_gpu_get_budget.argtypes = [C.c_void_p]
+    L.ssw_gpu_get_budget.restype = C.c_size_t
     L.ssw_gpu_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
     L.ssw_gpu_host_alloc.restype = C.c_void_p
     L.ssw_gpu_host_free.argtypes = [C.c_void_p, C.c_void_p]
@@ -141,6 +149,42 @@ class CSsw(object):
         self.init_destroy = self.ssw.init_destroy
         self.ssw_align = self.ssw.ssw_align
         self.align_destroy = self.ssw.align_destroy
+        self._ctx = None
+
+    def align_many(self, lQueries, lTargets, mat, nOpen, nExt, nFlag, nMaskLen, nFilterScore=0, nFilterDist=0, device=0):
+        """The loop of the reference's pyssw.py (src/pyssw.py:236-275: for every query ssw_init, for every target align_one) as ONE
+        batch call.  lQueries / lTargets: number arrays as pyssw.to_int builds them (ctypes c_int8 arrays, numpy int8 arrays or lists);
+        mat: the flat score matrix (lScore); nMaskLen < 0: len(query) / 2 per query (pyssw.py:243).  Returns [query][target] of the
+        tuples align_one returns: (nScore, nScore2, nRefBeg, nRefEnd, nQryBeg, nQryEnd, nRefEnd2, nCigarLen, lCigar)."""
+        if self._ctx is None:
+            self._ctx = Context(device, self.ssw)
+        ctx = self._ctx
+        qs = [np.frombuffer(bytes(bytearray(x)), dtype=np.int8) if not isinstance(x, np.ndarray) else np.ascontiguousarray(x, dtype=np.int8) for x in
+              ([(int(v) & 0xff) for v in q] if not isinstance(q, np.ndarray) else q for q in lQueries)]
+        ts = [np.frombuffer(bytes(bytearray(x)), dtype=np.int8) if not isinstance(x, np.ndarray) else np.ascontiguousarray(x, dtype=np.int8) for x in
+              ([(int(v) & 0xff) for v in t] if not isinstance(t, np.ndarray) else t for t in lTargets)]
+        m = np.ascontiguousarray(np.array(list(mat), dtype=np.int8))
+        n = int(round(len(m) ** 0.5))
+        Q = ctx.upload(qs); T = ctx.upload(ts)
+        try:
+            res, cig = ctx.align_batch(Q, T, m, n, nOpen, nExt, nFlag, nFilterScore, nFilterDist, nMaskLen, 2)
+        finally:
+            Q.free(); T.free()
+        out = []
+        for qi in range(len(qs)):
+            row = []
+            for ti in range(len(ts)):
+                g = res[qi, ti]
+                k, o = int(g["cigarLen"]), int(g["cigar_off"])
+                row.append((int(g["score1"]), int(g["score2"]), int(g["ref_begin1"]), int(g["ref_end1"]), int(g["read_begin1"]), int(g["read_end1"]),
+                            int(g["ref_end2"]), k, [int(x) for x in cig[o:o + k]] if k > 0 else []))
+            out.append(row)
+        return out
+
+    def close(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
 
 
 class Seqs(object):
@@ -200,7 +244,7 @@ class Context(object):
                                           res.ctypes.data_as(C.c_void_p), C.byref(pool) if want_cigar else None,
                                           C.byref(words))
         if rc != 0:
-            raise RuntimeError("ssw_gpu_align_batch: " + self.error())
+            raise RuntimeError("ssw_gpu_align_batch: " + (self.lib.ssw_gpu_strerror(rc).decode() if rc == -2 else self.error()))
         if want_cigar and words.value > 0:
             cig = np.ctypeslib.as_array(pool, shape=(words.value,)).copy()
         else:
@@ -219,13 +263,17 @@ class Context(object):
         nq = queries.count
         whole = None if on_chunk is not None else np.zeros((nq, targets.count), dtype=HIT_DTYPE)
         err = []
+        stopped = []        # what the caller's function returned to stop the search (any non-zero int, negative ones included)
 
         def cb(_user, tfirst, tcount, ptr):
             try:
                 buf = (C.c_char * (nq * tcount * 16)).from_address(ptr)
                 hits = np.frombuffer(buf, dtype=HIT_DTYPE).reshape(nq, tcount)
                 if on_chunk is not None:
-                    return int(on_chunk(tfirst, hits) or 0)
+                    r = int(on_chunk(tfirst, hits) or 0)
+                    if r:
+                        stopped.append(r)
+                    return r
                 whole[:, tfirst:tfirst + tcount] = hits
                 return 0
             except Exception as e:     # noqa: BLE001 -- an exception must not unwind through the C caller
@@ -235,6 +283,10 @@ class Context(object):
         rc = self.lib.ssw_gpu_search_db(self.h, queries.h, targets.h, C.byref(p), chunk, HITS_FN(cb), None)
         if err:
             raise err[0]
+        if stopped and rc == stopped[0]:
+            return rc               # "non-zero to stop, that value is returned" (include/ssw_gpu.h): not a library failure
+        if rc == -2:
+            raise RuntimeError("ssw_gpu_search_db: " + self.lib.ssw_gpu_strerror(rc).decode())
         if rc < 0:
             raise RuntimeError("ssw_gpu_search_db: " + self.error())
         return whole if on_chunk is None else rc
@@ -251,7 +303,7 @@ class Context(object):
 
     def timing(self):
         t = Timing()
-        self.lib.ssw_gpu_last_timing(self.h, C.byref(t))
+        self.lib.ssw_gpu_last_timing_sized(self.h, C.byref(t), C.sizeof(t))     # sized: this mirror may be older than the library
         d = {k: getattr(t, k) for k, _ in Timing._fields_}
         d["fill_kernel"] = d["fill_kernel"].decode()
         return d

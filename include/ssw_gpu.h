@@ -74,11 +74,12 @@ typedef struct {
 	int64_t n_word;        /* alignments decided under 16-bit semantics */
 	int64_t n_byte;        /* alignments decided under 8-bit semantics */
 	/* the fill kernel that evaluated most cells in the call (for roofline accounting) */
-	char fill_kernel[48];  /* e.g. "k_fill<10,f16>", "k_chainq<12,cm3> x 14 strips", "k_filldb<19>" */
-	double fill_ops_per_row; /* packed 16-bit VALU instructions per (row, column) of a query pair in that kernel: 7.5 / 8.5 / 9 */
+	char fill_kernel[48];  /* e.g. "k_fill<10,frame>", "k_chainq<12,frame> x 14 strips", "k_filldb<19,frame>" */
+	double fill_ops_per_row; /* VALU instructions of the recurrence per (row, column) of a query pair in that kernel: 6.5 (column frame) / 7.5 / 8.5 / 9 */
 	int32_t fill_rows_per_lane;
 	int32_t fill_strips;
-	int64_t db_repeats;    /* database search: workgroups whose f16 form saturated (a score >= 2048) and that repeated in the int16 form */
+	int64_t db_repeats;    /* (rounds 1-2: workgroups of the database search that repeated in the int16 form; always 0 since the column-frame form) */
+	/* new fields are only ever appended here; ssw_gpu_last_timing_sized lets a caller built against an older header keep its layout */
 } ssw_gpu_timing;
 
 int ssw_gpu_device_count(void);
@@ -109,6 +110,21 @@ int ssw_gpu_align_batch(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* queries, const ssw
                         ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words);
 
 int ssw_gpu_last_timing(const ssw_gpu_ctx* ctx, ssw_gpu_timing* out);
+/* the first min(out_size, sizeof(ssw_gpu_timing)) bytes of the record (the rest of `out`, if any, zeroed): a binary built against
+   an earlier, shorter ssw_gpu_timing passes ITS sizeof and is not written past it */
+int ssw_gpu_last_timing_sized(const ssw_gpu_ctx* ctx, void* out, size_t out_size);
+
+/* Return codes of the batch calls: 0 ok; -1 failed, ssw_gpu_last_error(ctx) says why; SSW_GPU_BUSY another thread is inside this
+   context (no message is written: the running call owns the error text); > 0 from ssw_gpu_search_db: the value the caller's chunk
+   function returned to stop the search. */
+#define SSW_GPU_BUSY (-2)
+const char* ssw_gpu_strerror(int rc);
+
+/* Scratch budget of a context in bytes (column maxima, boundary records, traceback scratch): default min(64 GiB, half of the HBM
+   that was free when the context was opened), or SSW_GPU_CM_BUDGET_MB.  Contexts sharing one device (several ranks or pool workers
+   per GPU) should each get their share: ssw_gpu_pool_open does that for its workers.  0 = recompute the default now. */
+int ssw_gpu_set_budget(ssw_gpu_ctx* ctx, size_t bytes);
+size_t ssw_gpu_get_budget(const ssw_gpu_ctx* ctx);
 
 /*
  * Database search with streamed results.  Every query against every target, scores and end positions only -- what the

@@ -254,6 +254,13 @@ def test_layout_dependent_gap_regime(ectx):
         _run(ectx, reads, [ref], mat, n, gapO, gapE, flag=int(rng.choice([0, 1, 2, 8, 9, 15, 4, 6, 3])),
              filters=int(rng.choice([0, 0, 30, 80])), filterd=int(rng.choice([0, 20, 1000])),
              maskLen=int(rng.choice([-1, -1, 15, 10, 40])), ss=int(rng.choice([2, 2, 2, 0, 1])))
+    # the per-alignment state of short reads lives in LDS (16 alignments per workgroup; 4 up to ~2.2 kb); longer reads keep it in HBM
+    # scratch: one batch of each kind (17 short reads = two workgroups, the second nearly empty)
+    ref = random_ref(700, 77, 4, 0.01)
+    _run(ectx, make_reads(rng, ref, 17, rng.integers(20, 160, size=17), 4), [ref], dna_matrix(2, 2), 5, 2, 2, flag=2)
+    _run(ectx, make_reads(rng, ref, 3, [600, 150, 333], 4), [ref], dna_matrix(2, 2), 5, 1, 3, flag=1)
+    ref = random_ref(420, 78, 4)
+    _run(ectx, [np.ascontiguousarray(np.concatenate([ref, ref[::-1], ref, ref[::-1], ref, ref[:300]])), ref[:90].copy()], [ref], dna_matrix(1, 3), 5, 2, 2, flag=0)
 
 
 def test_bad_arguments_fail_loudly(ectx):
