@@ -4,9 +4,11 @@
  * gfx950 view: a 64-lane wavefront is four DPP "rows" of 16 lanes.  One row is
  * one systolic chain: lane i owns a block of consecutive query rows, and each
  * step hands H/F/column-max to lane i+1 with row_shr / row_ror DPP moves.  Scores
- * are two signed 16-bit values packed in a 32-bit VGPR (two queries per chain)
- * and use the packed saturating VOP3P instructions (v_pk_add_i16 clamp,
- * v_pk_sub_u16 clamp, v_pk_max_i16) -- gfx950 has no packed 8-bit arithmetic.
+ * are two 16-bit values packed in a 32-bit VGPR (two queries per chain); the hot
+ * form keeps them in a "column frame" (below) where the adds are plain 32-bit adds
+ * and the maxima are v_pk_maximum3_f16 on the bit patterns; the fallback form uses
+ * the packed saturating VOP3P instructions (v_pk_add_i16 clamp, v_pk_sub_u16 clamp,
+ * v_pk_max_i16).  gfx950 has no packed 8-bit arithmetic.
  *
  * When SSW_SIMT_EMU is defined (tests/emu only) the same names are provided by a
  * fibre-based SIMT emulator so that the very same kernel source can be executed
@@ -145,115 +147,6 @@ SSW_DEV u32 pk_perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, 
 #endif
 #define PK_LO2 0x05040100u
 #define PK_HI2 0x07060302u
-/* packed 2 x f16 arithmetic on scores scaled by 1/2048 (k/2048 is exact in f16 for every integer |k| <= 2048, and so are sums
-   and differences of such values): `clamp` (result -> [0, 1]) is the max(0, .) of local alignment for free, and gfx950's
-   v_pk_maximum3_f16 takes three inputs -- together one instruction less per DP cell than the int16 form.  Used where
-   no score can reach 2048 (k_fill: the host checks the bucket), or where reaching it is detected and repaired (k_filldb: the form
-   saturates at 2048, a workgroup that sees a best cell there repeats in the int16 form). */
-#ifdef SSW_SIMT_EMU
-/* emulation through exact integer tables (every value that occurs is k/2048): f16 bits -> k and k -> f16 bits */
-struct emu_f16_tables {
-	short to_k[65536]; unsigned short to_h[2049];
-	emu_f16_tables()
-	{
-		for (unsigned i = 0; i < 65536; ++i) {
-			const float f = (float)__builtin_bit_cast(_Float16, (unsigned short)i) * 2048.0f;
-			to_k[i] = (f == f && f >= -4096.0f && f <= 4096.0f) ? (short)(int)f : (short)0;
-		}
-		for (int k = 0; k <= 2048; ++k) to_h[k] = __builtin_bit_cast(unsigned short, (_Float16)((float)k * (1.0f / 2048.0f)));
-	}
-};
-static const emu_f16_tables& emu_f16() { static const emu_f16_tables t; return t; }
-SSW_DEV u32 pkf_addc(u32 a, u32 b)
-{
-	const emu_f16_tables& t = emu_f16();
-	int lo = t.to_k[a & 0xffffu] + t.to_k[b & 0xffffu], hi = t.to_k[a >> 16] + t.to_k[b >> 16];
-	lo = lo < 0 ? 0 : lo > 2048 ? 2048 : lo; hi = hi < 0 ? 0 : hi > 2048 ? 2048 : hi;
-	return (u32)t.to_h[lo] | ((u32)t.to_h[hi] << 16);
-}
-SSW_DEV u32 pkf_max(u32 a, u32 b)
-{
-	const emu_f16_tables& t = emu_f16();
-	const u32 lo = t.to_k[b & 0xffffu] > t.to_k[a & 0xffffu] ? (b & 0xffffu) : (a & 0xffffu);
-	const u32 hi = t.to_k[b >> 16] > t.to_k[a >> 16] ? (b >> 16) : (a >> 16);
-	return lo | (hi << 16);
-}
-SSW_DEV u32 pkf_max3(u32 a, u32 b, u32 c) { return pkf_max(pkf_max(a, b), c); }
-#else
-SSW_DEV u32 pkf_addc(u32 a, u32 b) { u32 r; asm("v_pk_add_f16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
-SSW_DEV u32 pkf_max(u32 a, u32 b) { u32 r; asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-SSW_DEV u32 pkf_max3(u32 a, u32 b, u32 c) { u32 r; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-#endif
-/* one DP cell pair in the f16 form (8 instructions; see chain_rows): h = max(0, d + s, E, f); t = max(0, h - gapO);
-   E = max(max(0, E - gapE), t); f likewise; cm = max(cm, h).  nO / nE are the negative scaled penalties.  On the device this
-   is ONE asm block: between separate asm statements hipcc pads every dependent pair with s_nop (it cannot see what they are). */
-#ifdef SSW_SIMT_EMU
-SSW_DEV void pkf_cell(u32 d, u32 s, u32& E, u32& f, u32& cm, u32& h, u32 nO, u32 nE)
-{
-	h = pkf_max3(pkf_addc(d, s), E, f);
-	const u32 t = pkf_addc(h, nO);
-	E = pkf_max(pkf_addc(E, nE), t);
-	f = pkf_max(pkf_addc(f, nE), t);
-	cm = pkf_max(cm, h);
-}
-#else
-SSW_DEV void pkf_cell(u32 d, u32 s, u32& E, u32& f, u32& cm, u32& h, u32 nO, u32 nE)
-{
-	u32 t;
-	asm("v_pk_add_f16 %[h], %[d], %[s] clamp\n\t"
-	    "v_pk_maximum3_f16 %[h], %[h], %[E], %[f]\n\t"
-	    "v_pk_add_f16 %[t], %[h], %[nO] clamp\n\t"
-	    "v_pk_add_f16 %[E], %[E], %[nE] clamp\n\t"
-	    "v_pk_add_f16 %[f], %[f], %[nE] clamp\n\t"
-	    "v_pk_max_f16 %[E], %[E], %[t]\n\t"
-	    "v_pk_max_f16 %[f], %[f], %[t]\n\t"
-	    "v_pk_max_f16 %[cm], %[cm], %[h]"
-	    : [h] "=&v"(h), [t] "=&v"(t), [E] "+v"(E), [f] "+v"(f), [cm] "+v"(cm)
-	    : [d] "v"(d), [s] "v"(s), [nO] "v"(nO), [nE] "v"(nE));
-}
-#endif
-/* two consecutive rows of a lane: 15 instructions -- the column maximum takes both rows in one v_pk_maximum3_f16.
-   d0 / d1 = diagonal inputs (d1 is row 0's previous H), h0 / h1 = the new H values. */
-#ifdef SSW_SIMT_EMU
-SSW_DEV void pkf_cell2(u32 d0, u32 s0, u32 d1, u32 s1, u32& E0, u32& E1, u32& f, u32& cm, u32& h0, u32& h1, u32 nO, u32 nE)
-{
-	u32 c0 = 0, c1 = 0;
-	pkf_cell(d0, s0, E0, f, c0, h0, nO, nE);
-	pkf_cell(d1, s1, E1, f, c1, h1, nO, nE);
-	cm = pkf_max3(cm, h0, h1);
-}
-#else
-SSW_DEV void pkf_cell2(u32 d0, u32 s0, u32 d1, u32 s1, u32& E0, u32& E1, u32& f, u32& cm, u32& h0, u32& h1, u32 nO, u32 nE)
-{
-	u32 t;
-	asm("v_pk_add_f16 %[h0], %[d0], %[s0] clamp\n\t"
-	    "v_pk_maximum3_f16 %[h0], %[h0], %[E0], %[f]\n\t"
-	    "v_pk_add_f16 %[t], %[h0], %[nO] clamp\n\t"
-	    "v_pk_add_f16 %[E0], %[E0], %[nE] clamp\n\t"
-	    "v_pk_add_f16 %[f], %[f], %[nE] clamp\n\t"
-	    "v_pk_max_f16 %[E0], %[E0], %[t]\n\t"
-	    "v_pk_max_f16 %[f], %[f], %[t]\n\t"
-	    "v_pk_add_f16 %[h1], %[d1], %[s1] clamp\n\t"
-	    "v_pk_maximum3_f16 %[h1], %[h1], %[E1], %[f]\n\t"
-	    "v_pk_add_f16 %[t], %[h1], %[nO] clamp\n\t"
-	    "v_pk_add_f16 %[E1], %[E1], %[nE] clamp\n\t"
-	    "v_pk_add_f16 %[f], %[f], %[nE] clamp\n\t"
-	    "v_pk_max_f16 %[E1], %[E1], %[t]\n\t"
-	    "v_pk_max_f16 %[f], %[f], %[t]\n\t"
-	    "v_pk_maximum3_f16 %[cm], %[cm], %[h0], %[h1]"
-	    : [h0] "=&v"(h0), [h1] "=&v"(h1), [t] "=&v"(t), [E0] "+v"(E0), [E1] "+v"(E1), [f] "+v"(f), [cm] "+v"(cm)
-	    : [d0] "v"(d0), [s0] "v"(s0), [d1] "v"(d1), [s1] "v"(s1), [nO] "v"(nO), [nE] "v"(nE));
-}
-#endif
-SSW_DEV u32 pkf_from_int(int v) { const _Float16 h = (_Float16)((float)v * (1.0f / 2048.0f)); return (u32)__builtin_bit_cast(unsigned short, h); }
-SSW_DEV u32 pkf_make(int lo, int hi) { return pkf_from_int(lo) | (pkf_from_int(hi) << 16); }
-SSW_DEV u32 pkf_to_int2(u32 v)   /* two scaled f16 -> two 16-bit integers */
-{
-	const float lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu)) * 2048.0f;
-	const float hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)) * 2048.0f;
-	return ((u32)(int)lo & 0xffffu) | ((u32)(int)hi << 16);
-}
-#define PKF_DEAD2 0xBC00BC00u   /* (-1.0, -1.0) = -2048: pins H to max(E, F) like DEAD2 */
 /* max of three packed NON-NEGATIVE int16 pairs below 0x7C00 (31744) in one instruction: such bit patterns are positive
    finite binary16 numbers (denormals included) whose order is the integer order, and v_pk_maximum3_f16 returns one of its
    operands unchanged (checked on the device against integer max on 5e8 random triples, denormal range included).  Used

@@ -60,9 +60,9 @@ typedef struct {
 	uint32_t* sg16;          /* optional: [npairs][seg_stride] maxima of every aligned group of 16 columns of cm16 ... */
 	uint32_t* sg8;           /* ... and of cm8 (k_reduce_seg scans these instead of the columns) */
 	int64_t seg_stride;
-	int32_t f16;             /* form of the recurrence: 1: no score can reach 2048 -> f16 (scores / 2048, exact), 7.5 instructions per row;
-	                            2: no score can reach 31744 -> int16 with a two-row column maximum, 8.5; 0: plain int16, 9;
-	                            3: column frame (ssw_frame_params says when), 6.5 of which 3 are 2-cycle 32-bit adds */
+	int32_t f16;             /* form of the recurrence: 3: column frame (ssw_frame_params in ssw_host.c says when), 6.5 instructions per row of
+	                            which 3 are 32-bit adds; 0: plain int16 with the reference's saturation, 9  (the name is historic: rounds 1-2
+	                            had an f16 form) */
 	int32_t fr_base, fr_kmask;   /* form 3: phi(column) = fr_base + ((step & fr_kmask) + lanes - lane) * gapE */
 } ssw_fill_args;
 
@@ -192,8 +192,7 @@ typedef struct {
 	int32_t* queue;          /* [0] ticket counter, [1 + job * strips + strip] completion flags, [1 + items] error word (a wait
 	                            that timed out); zeroed before the launch */
 	int32_t* cand_strip;     /* [job * strips + strip][half][4]: best cell of the job up to and including that strip */
-	int32_t form;            /* fill mode: 3 = column frame (fr_base / fr_kmask as in ssw_fill_args), 2 = no score of the bucket reaches 31744
-	                            (two-row column maximum), 0 = plain */
+	int32_t form;            /* fill mode: 3 = column frame (fr_base / fr_kmask as in ssw_fill_args), 0 = plain int16 */
 	int32_t fr_base, fr_kmask;
 	int32_t whole_jobs;      /* 1: a ticket is a whole job (its strips in sequence on one wavefront); 0: a ticket is one strip */
 } ssw_chainx_args;

@@ -793,10 +793,9 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 
 	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
 	double fill_ms = 0, reduce_ms = 0, locate_ms = 0, trace_ms = 0;
-	int fill_f16 = 1, fill_form = -1;
-	{ const char* e = getenv("SSW_GPU_FILL_F16"); if (e && e[0] == '0') fill_f16 = 0; }     /* experiment / test: int16 form everywhere */
-	{ const char* e = getenv("SSW_GPU_FILL_FORM"); if (e && e[0] >= '0' && e[0] <= '3') fill_form = e[0] - '0'; }   /* tests: cap the form of k_fill (0 int16, 1 f16, 2 int16 + max3, 3 / unset: column frame where it fits) */
-	if (!fill_f16) fill_form = 0;
+	int fill_form = -1;      /* tests: SSW_GPU_FILL_FORM=0 (or the older SSW_GPU_FILL_F16=0) keeps the plain int16 form everywhere */
+	{ const char* e = getenv("SSW_GPU_FILL_FORM"); if (e && e[0] == '0') fill_form = 0; }
+	{ const char* e = getenv("SSW_GPU_FILL_F16"); if (e && e[0] == '0') fill_form = 0; }
 
 	{   /* database search: scores only, several short targets -> fused kernel for the short-query buckets */
 		int any_short = 0, any_long = 0; int64_t maxt = 0;
@@ -944,18 +943,13 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 					fa.bpp = (ntiles + 15) / 16; fa.cm16 = d_cm16; fa.cm8 = d_cm8; fa.cm_stride = stride;
 					fa.sg16 = d_sg16; fa.sg8 = d_sg8; fa.seg_stride = seg_stride;
 					/* no cell of this bucket can score 2048 or more -> f16 form of the recurrence (8 instead of 9 instructions per cell) */
-					{
-						const int64_t top = (int64_t)16 * B->R * (maxmat > 0 ? maxmat : 0);     /* no cell of the bucket scores more */
-						fa.f16 = !fill_f16 ? 0 : top <= 2047 ? 1 : top < 31744 ? 2 : 0;
-						fa.fr_base = 0; fa.fr_kmask = 0;
-						if (fill_form != 0 && fill_form != 1 && fill_form != 2 &&
-						    ssw_frame_params(top, prm->gapO, prm->gapE, minmat, 16, &fa.fr_base, &fa.fr_kmask)) fa.f16 = 3;
-						else if (fill_form >= 0 && fill_form < fa.f16) fa.f16 = fill_form == 1 && top > 2047 ? fa.f16 : fill_form;
-					}
-					/* strip kernel: two-row column maximum when no score of the bucket can reach 31744 */
-					int xform = fill_f16 && (int64_t)B->P16 * (maxmat > 0 ? maxmat : 0) < 31744 ? 2 : 0;
+					/* column-frame form of the recurrence whenever the bucket's scores leave room for the frame offsets below 31744 (no cell of
+					   the bucket scores more than its padded length x max(mat)); else plain int16 */
+					fa.f16 = 0; fa.fr_base = 0; fa.fr_kmask = 0;
+					if (fill_form != 0 && ssw_frame_params((int64_t)16 * B->R * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, minmat, 16, &fa.fr_base, &fa.fr_kmask)) fa.f16 = 3;
+					int xform = 0;
 					int32_t xfr_base = 0, xfr_kmask = 0;
-					if (xform == 2 && (fill_form < 0 || fill_form == 3) && B->lanes == 64 &&
+					if (fill_form != 0 && B->lanes == 64 &&
 					    ssw_frame_params((int64_t)B->P16 * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, minmat, 64, &xfr_base, &xfr_kmask)) xform = 3;
 					void* e0 = next_event(c); void* e1 = next_event(c);
 					ssw_shim_event_record(e0, c->stream);
@@ -989,10 +983,10 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 						const int64_t lc = cols * (int64_t)(B->lanes * B->R * B->strips) * 2 * np;
 						c->tm.fill_cells += lc;
 						char nm[48];
-						if (!use_x) snprintf(nm, sizeof nm, "k_fill<%d,%s>", B->R, fa.f16 == 3 ? "frame" : fa.f16 == 1 ? "f16" : fa.f16 == 2 ? "int16+max3" : "int16");
-						else if (B->lanes == 64) snprintf(nm, sizeof nm, "k_chainq<%d,%s> x %d strips", B->R, xform == 3 ? "frame" : xform == 2 ? "int16+max3" : "int16", B->strips);
+						if (!use_x) snprintf(nm, sizeof nm, "k_fill<%d,%s>", B->R, fa.f16 == 3 ? "frame" : "int16");
+						else if (B->lanes == 64) snprintf(nm, sizeof nm, "k_chainq<%d,%s> x %d strips", B->R, xform == 3 ? "frame" : "int16", B->strips);
 						else snprintf(nm, sizeof nm, "k_chainx<%d,16 lanes> x %d strips", B->R, B->strips);
-						note_fill_kernel(c, lc, &best_fill_cells, nm, !use_x ? (fa.f16 == 3 ? 6.5 : fa.f16 == 1 ? 7.5 : fa.f16 == 2 ? 8.5 : 9.0) : (B->lanes == 64 && xform == 3 ? 6.5 : B->lanes == 64 && xform == 2 ? 8.5 : 9.0), B->R, B->strips);
+						note_fill_kernel(c, lc, &best_fill_cells, nm, !use_x ? (fa.f16 == 3 ? 6.5 : 9.0) : (B->lanes == 64 && xform == 3 ? 6.5 : 9.0), B->R, B->strips);
 					}
 					ssw_reduce_args ra;
 					ra.cm16 = d_cm16; ra.cm8 = d_cm8; ra.cm_stride = stride; ra.refLen = refLen; ra.pairs = fa.pairs; ra.npairs = np;

@@ -8,9 +8,7 @@
  *                 group of 16 columns
  *   k_chainq      the same fill for longer queries, cut into row strips of 64 x R rows that a persistent launch draws from a
  *                 work queue (k_chainx: the 16-lane form, strips in sequence); its window mode does the "where" passes
- *   k_filldb      database search: fill + best cell + reduction of one query pair against 16 short targets in one launch -- in
- *                 the f16 form (exact below 2048) with the rare workgroup that saturates repeating in int16, the role ssw_align
- *                 gives its 16-bit kernel after a saturated 8-bit pass (887-890)
+ *   k_filldb      database search: fill + best cell + reduction of one query pair against 16 short targets in one launch
  *   k_reduce_seg  the bookkeeping around the fill: best score / first best column (317-340, 523-542) and the masked
  *   / k_reduce    second-best scan (368-381 / 570-583), plus ssw_align's choice between 8-bit and 16-bit rules (881-899) and its
  *                 early exits (900-916) -- over the group maxima / over the strip kernel's columns
@@ -57,14 +55,13 @@ template <int R> struct ChainGeom {
 };
 
 /* build one packed profile: rows of query A in the low halves, query B in the high halves */
-/* PM: 0 packed int16, 1 f16 (scores / 2048), 2 column frame (score + gapE per live row, FR_DEAD for dead rows: lanes.h) */
+/* PM: 0 packed int16, 2 column frame (score + gapE per live row, FR_DEAD for dead rows: lanes.h) */
 template <int R, int PM = 0>
 SSW_DEV void build_profile(unsigned char* lds, u32 base, int first, int nthreads,
                            const int8_t* mat, int n,
                            const int8_t* qa, int lena, int reva,
                            const int8_t* qb, int lenb, int p16a = 0x7fffffff, int p16b = 0x7fffffff, int gapE = 0)
 {
-	constexpr bool F16 = PM == 1;
 	constexpr int C = ChainGeom<R>::C;
 	const int total = (n + 1) * C * 64;
 	for (int w = first; w < total; w += nthreads) {
@@ -72,62 +69,20 @@ SSW_DEV void build_profile(unsigned char* lds, u32 base, int first, int nthreads
 		const int c = rem >> 6, l = (rem & 63) >> 2, k = rem & 3;
 		const int r = c * 4 + k, row = l * R + r;
 		u32 v;
-		if (b == n) v = F16 ? PKF_DEAD2 : PM == 2 ? fr_pack(FR_DEAD, FR_DEAD) : DEAD2;
+		if (b == n) v = PM == 2 ? fr_pack(FR_DEAD, FR_DEAD) : DEAD2;
 		else if (r >= R) v = 0;
 		else {
 			int lo = row < p16a ? 0 : -32768, hi = row < p16b ? 0 : -32768;   /* rows below a padded query are dead */
 			if (row < lena) lo = mat[b * n + (reva ? qa[lena - 1 - row] : qa[row])];
 			if (qb && row < lenb) hi = mat[b * n + qb[row]];
 			if (PM == 2) v = fr_pack(lo == -32768 ? FR_DEAD : lo + gapE, hi == -32768 ? FR_DEAD : hi + gapE);
-			else v = F16 ? pkf_make(lo < -2048 ? -2048 : lo, hi < -2048 ? -2048 : hi) : pk_make(lo, hi);
+			else v = pk_make(lo, hi);
 		}
 		lds_st32(lds, base + (u32)w * 4u, v);
 	}
 }
 
 /* one DP step of a chain lane: R rows of one target column for two packed queries */
-/* f16 form of rows [R0, R1) of a lane (see lanes.h): pairs of rows, 7.5 instructions per row */
-template <int R, int R0, int R1>
-SSW_DEV void chain_rows_f16(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32& d, u32& f, u32& cm, u32 nO, u32 nE)
-{
-#pragma unroll
-	for (int r = R0; r + 1 < R1; r += 2) {
-		const u32 d1 = H[r], hold = H[r + 1];
-		u32 h0, h1;
-		pkf_cell2(d, sc[r >> 2][r & 3], d1, sc[(r + 1) >> 2][(r + 1) & 3], E[r], E[r + 1], f, cm, h0, h1, nO, nE);
-		H[r] = h0; H[r + 1] = h1;
-		d = hold;
-	}
-	if ((R1 - R0) & 1) {
-		constexpr int r = R1 - 1 >= 0 ? R1 - 1 : 0;
-		const u32 hold = H[r];
-		u32 h;
-		pkf_cell(d, sc[r >> 2][r & 3], E[r], f, cm, h, nO, nE);
-		H[r] = h;
-		d = hold;
-	}
-}
-
-/* int16 form of rows [R0, R1) with the column maximum of two rows taken in one instruction (pk_max3_nonneg: every score of the
-   bucket is below 31744): 8.5 instead of 9 instructions per row */
-template <int R, int R0, int R1>
-SSW_DEV void chain_rows_cm3(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32& d, u32& f, u32& cm, u32 gapO2, u32 gapE2)
-{
-#pragma unroll
-	for (int r = R0; r < R1; ++r) {
-		const u32 hold = H[r];
-		const u32 h0 = pk_max(pk_adds(d, sc[r >> 2][r & 3]), E[r]);
-		const u32 h = pk_max(h0, f);
-		const u32 t0 = pk_subu(h0, gapO2);
-		E[r] = pk_max(pk_subu(E[r], gapE2), t0);
-		f = pk_max(pk_subu(f, gapE2), t0);
-		if (((r - R0) & 1) == 1) cm = pk_max3_nonneg(cm, H[r - 1 >= 0 ? r - 1 : 0], h);      /* H[r-1] was just written: this pair's first row */
-		else if (r == R1 - 1) cm = pk_max(cm, h);                                             /* odd row left over */
-		H[r] = h;
-		d = hold;
-	}
-}
-
 /* column-frame form of rows [R0, R1) (lanes.h): 3 plain 32-bit adds + 3.5 packed maxima per row.  c1 = gapO - gapE (packed),
    fl = phi(column + 1): the floor that keeps E at "0" or above.
      h = max3(d + s', E, F)        t = h - c1        E' = max3(E, t, fl)        F' = max(F, t) - gapE        cm = max3(cm, h_r, h_r+1) */
@@ -169,37 +124,19 @@ SSW_DEV void chain_rows_fr(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32& d, u3
 	}
 }
 
-/* FORM 0: int16, 9 instructions per row; 1: f16 (scores < 2048), 7.5; 2: int16 with the two-row column maximum (scores < 31744), 8.5;
-   3: column frame (scores + frame offsets < 31744), 6.5 of which 3 are 2-cycle adds (gapO2 then carries gapO - gapE) */
+/* FORM 0: plain int16 with the reference's saturation, 9 instructions per row (buckets whose scores may pass the frame form's range);
+   3: column frame (scores + frame offsets < 31744), 6.5 of which 3 are 32-bit adds (gapO2 then carries gapO - gapE) */
 template <int R, bool TRACK8, int FORM = 0>
 SSW_DEV void chain_rows(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f, u32& cm, u32& ck,
                         u32 gapO2, u32 gapE2, u32 fl = 0)
 {
 	constexpr int K8 = ChainGeom<R>::K8;
-	constexpr bool F16 = FORM == 1, CM3 = FORM == 2;
 	if (FORM == 3) {
 		if (TRACK8) {
 			chain_rows_fr<R, 0, K8>(sc, H, E, d, f, cm, gapO2, gapE2, fl);
 			ck = cm;
 			chain_rows_fr<R, K8, R>(sc, H, E, d, f, cm, gapO2, gapE2, fl);
 		} else chain_rows_fr<R, 0, R>(sc, H, E, d, f, cm, gapO2, gapE2, fl);
-		return;
-	}
-	if (CM3 && !F16) {
-		if (TRACK8) {
-			chain_rows_cm3<R, 0, K8>(sc, H, E, d, f, cm, gapO2, gapE2);
-			ck = cm;
-			chain_rows_cm3<R, K8, R>(sc, H, E, d, f, cm, gapO2, gapE2);
-		} else chain_rows_cm3<R, 0, R>(sc, H, E, d, f, cm, gapO2, gapE2);
-		return;
-	}
-	if (F16) {   /* scores / 2048 in f16, gapO2 / gapE2 hold the NEGATIVE penalties; H = max(0, d + s, E, F); gaps open from H:
-	                same H matrix as opening from the F-free value */
-		if (TRACK8) {
-			chain_rows_f16<R, 0, K8>(sc, H, E, d, f, cm, gapO2, gapE2);
-			ck = cm;
-			chain_rows_f16<R, K8, R>(sc, H, E, d, f, cm, gapO2, gapE2);
-		} else chain_rows_f16<R, 0, R>(sc, H, E, d, f, cm, gapO2, gapE2);
 		return;
 	}
 #pragma unroll
@@ -225,7 +162,6 @@ SSW_DEV void fill_flush16(unsigned char* lds, u32 out16, u32 out8, int base, int
                           uint32_t* o16, uint32_t* o8, uint32_t* g16, uint32_t* g8, int fr_base = 0, int fr_kmask = 0, int gapE = 0)
 {
 	typedef ChainGeom<R> G;
-	constexpr bool F16 = FORM == 1;
 	const int tc = base + l16;
 	u32 i16 = 0, i8 = 0;
 	if (tc >= store_from && tc < ncols) {
@@ -233,10 +169,7 @@ SSW_DEV void fill_flush16(unsigned char* lds, u32 out16, u32 out8, int base, int
 		if (FORM == 3) {   /* parked in the frame of the step that finished them: column tc at step tc + 15 (lane 15) / tc + TAP (lane TAP) */
 			i16 = v16 - pk_dup(fr_phi(tc + 15, 15, 16, fr_base, fr_kmask, gapE));
 			i8 = v8 - pk_dup(fr_phi(tc + G::TAP, G::TAP, 16, fr_base, fr_kmask, gapE));
-		} else {
-		i16 = F16 ? pkf_to_int2(v16) : v16;
-		i8 = F16 ? pkf_to_int2(v8) : v8;
-		}
+		} else { i16 = v16; i8 = v8; }
 		o16[tc] = i16;
 		o8[tc] = i8;
 	}
@@ -253,13 +186,13 @@ SSW_DEV void fill_flush16(unsigned char* lds, u32 out16, u32 out8, int base, int
 /* ================================================================================================
  * k_fill: forward fill, column maxima only.  grid = npairs * bpp workgroups of 256 threads.
  * ================================================================================================ */
-/* FORM 0: int16, 9 instructions per row; 1: f16 (scores < 2048), 7.5; 2: int16 with the two-row column maximum (scores < 31744), 8.5 */
+/* FORM 0: plain int16, 9 instructions per row; 3: column frame, 6.5 (chain_rows) */
 /* (up to 10 rows per lane the kernel is held to 72 registers -- seven wavefronts per SIMD; hipcc otherwise takes 74, i.e. 80, and
    the one spill this costs is a pointer reloaded once per 16 steps) */
 template <int R, int FORM>
 __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fill(ssw_fill_args a)
 {
-	constexpr bool F16 = FORM == 1, FR = FORM == 3;
+	constexpr bool FR = FORM == 3;
 	typedef ChainGeom<R> G;
 	constexpr int C = G::C;
 	SSW_DYN_LDS(lds);
@@ -276,7 +209,7 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
 		const int lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
 		const int8_t* qb = pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0;
 		const int lenb = pr.qb >= 0 ? (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]) : 0;
-		build_profile<R, FR ? 2 : F16 ? 1 : 0>(lds, 0, tid, 256, a.mat, a.n, qa, lena, 0, qb, lenb, 0x7fffffff, 0x7fffffff, gapEi);
+		build_profile<R, FR ? 2 : 0>(lds, 0, tid, 256, a.mat, a.n, qa, lena, 0, qb, lenb, 0x7fffffff, 0x7fffffff, gapEi);
 	}
 
 	/* this chain's tile */
@@ -323,9 +256,8 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
 	for (int r = 0; r < R; ++r) { H[r] = zero0; E[r] = FR ? fl : 0u; }
 	u32 Hlast = zero0, Fout = zero0, cmout = zero0, ck = 0, hsave = zero0;
 	const u32 lane_prof = (u32)l16 * 16u;
-	/* f16 form: the penalties enter as negative scaled constants; frame form: gapO - gapE */
-	const u32 gO = F16 ? pkf_make(-(int)(a.gapO2 & 0xffffu), -(int)(a.gapO2 & 0xffffu)) : FR ? a.gapO2 - a.gapE2 : a.gapO2;
-	const u32 gE = F16 ? pkf_make(-(int)(a.gapE2 & 0xffffu), -(int)(a.gapE2 & 0xffffu)) : a.gapE2;
+	const u32 gO = FR ? a.gapO2 - a.gapE2 : a.gapO2;      /* frame form: gapO - gapE */
+	const u32 gE = a.gapE2;
 
 	for (int s0 = 0; s0 < nsteps; s0 += 16) {
 		if (FR && s0 > 0 && (s0 & a.fr_kmask) == 0) {   /* renormalisation: every frame value drops by K x gapE */
@@ -339,9 +271,14 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
 			lds_st16(lds, ring + 2u * p, nxt);
 			if (p < 16) lds_st16(lds, ring + 2u * (64 + p), nxt);
 			const int tc = s0 + 32 + l16;
+#ifdef FILL_STAGE_FREE      /* MEASUREMENT ONLY (wrong results): no target load, no range check -- the upper bound of what any cheaper target staging
+                               (2-bit / 4-bit packed targets) could gain; see DESIGN.md "packed targets: closed by measurement" */
+			nxt = (u32)((tc >> 2) & 3) * G::PSTRIDE;
+#else
 			int code = tc < ncols ? tg[tc] : a.n;
 			if (code < 0 || code > a.n) code = a.n;
 			nxt = (u32)code * G::PSTRIDE;
+#endif
 		}
 		wave_lds_fence();   /* lane 0's ring writes of the previous 16 steps are visible to the chain */
 		if (s0 >= 32) fill_flush16<R, FORM>(lds, out16, out8, s0 - 32, l16, store_from, ncols, o16, o8, g16, g8, a.fr_base, a.fr_kmask, gapEi);   /* columns [s0-32, s0-16) are complete in the out rings */
@@ -383,11 +320,7 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
  * grid = npairs * ceil(ntl / NCH) workgroups of NCH chains (16 * NCH threads: the profile of a pair -- 25 residues x R rows x
  * 64 bytes for proteins -- is what limits the wavefronts per CU, and more chains per workgroup share it).
  *
- * F16 form first (a.f16): scores / 2048 in f16 -- `clamp` is the max(0, .) and v_pk_maximum3_f16 folds two maxima, 7.5 instead
- * of 8.5 instructions per row -- which is exact as long as no cell reaches 2048 and SATURATES there (clamp at 1.0; sums above
- * round, then clamp).  Every value below 2048 that only depends on values below 2048 is exact, so a pass whose best cells all
- * stay below 2048 has computed the true matrix; a workgroup that sees a best cell at 2048 writes nothing and repeats its
- * targets in the int16 form (the role the reference gives its 16-bit kernel after a saturated 8-bit pass, ssw.c:887-890).
+ * a.f16 != 0: the column-frame form of the recurrence (chain_rows_fr), else plain int16 with the two-row column maximum.
  * ================================================================================================ */
 #define DB_OUT_RING 32                                   /* finished column maxima parked per chain (k_fill keeps 64) */
 #define DB_RING_BYTES 192                                /* target ring: 64 entries + 32 mirrored (entries are read two steps ahead) */
@@ -1598,7 +1531,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
  * which was drawn J tickets earlier and is normally long done.  What a wavefront carried in registers from strip to
  * strip (the best cell so far) travels through a 32-byte record per item instead; the boundary rows travel through HBM as
  * before.  LDS is trimmed (one target ring in fill mode, 32-entry boundary-out ring, reduction scratch aliased) so that
- * 12 rows per lane leave room for 8 wavefronts per CU.  FORM 2: two-row column maximum (scores below 31744).
+ * 12 rows per lane leave room for 8 wavefronts per CU.  FORM 3: column-frame form of the fill (run_strip<..., FR>), 0: plain int16.
  * ================================================================================================ */
 template <int R, bool CAPTURE> struct QueueGeom {
 	static constexpr int C = (R + 3) / 4;
@@ -1722,7 +1655,7 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 			for (int q = 0; q < R; ++q) m8[q] = 0;
 		}
 		if (!CAPTURE && need_mask) run_strip<R, CAPTURE, true, GL, false, !CAPTURE && FORM == 3>(lds, x, st, m8);
-		else run_strip<R, CAPTURE, false, GL, FORM >= 2, !CAPTURE && FORM == 3>(lds, x, st, m8);
+		else run_strip<R, CAPTURE, false, GL, FORM == 3, !CAPTURE && FORM == 3>(lds, x, st, m8);
 
 		/* chain-wide winner of this strip merged with the strips above: value, then first column, then smallest row */
 		for (int h = 0; h < 2; ++h) {
@@ -2711,8 +2644,6 @@ extern "C" int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream)
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
 		if (args.f16 == 3) SSW_LAUNCH((k_fill<r, 3>), ssw_fill_args, args, grid, 256, ldsb, stream); \
-		else if (args.f16 == 1) SSW_LAUNCH((k_fill<r, 1>), ssw_fill_args, args, grid, 256, ldsb, stream); \
-		else if (args.f16 == 2) SSW_LAUNCH((k_fill<r, 2>), ssw_fill_args, args, grid, 256, ldsb, stream); \
 		else SSW_LAUNCH((k_fill<r, 0>), ssw_fill_args, args, grid, 256, ldsb, stream); } break;
 		FOR_EACH_R(X)
 #undef X
@@ -2812,7 +2743,6 @@ extern "C" int ssw_shim_launch_chainq(int R, int capture, const ssw_chainx_args*
 #define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * StripGeom<r, 64>::PSTRIDE + (capture ? QueueGeom<r, true>::EXTRA : QueueGeom<r, false>::EXTRA); \
 		if (capture) SSW_LAUNCH((k_chainq<r, true, 0>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
 		else if (args.form == 3) SSW_LAUNCH((k_chainq<r, false, 3>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
-		else if (args.form == 2) SSW_LAUNCH((k_chainq<r, false, 2>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
 		else SSW_LAUNCH((k_chainq<r, false, 0>), ssw_chainx_args, args, grid, 64, ldsb, stream); } break;
 		FOR_EACH_QR(X)
 #undef X

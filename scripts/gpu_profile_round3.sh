@@ -1,0 +1,26 @@
+# rocprofv3 evidence of round 3 (outputs under gpurun_out/prof3, summaries copied to profiles/ by scripts/summarize_round3.py):
+#   kernel-trace --stats of the bench commands of configs 2, 4, 5;  PMC passes (FETCH_SIZE / WRITE_SIZE / SQ counters, one pass
+#   per counter group, no tracing domains next to --pmc) on reduced batches of the same workloads
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+P=$GRAFT_REPO_ROOT/gpurun_out/prof3
+rm -rf $P; mkdir -p $P
+B=$GRAFT_REPO_ROOT/bench.py
+cd /tmp
+trace() { timeout $1 rocprofv3 --kernel-trace --stats -d $P/$2 -o bench -- python $B $3 > $P/$2.log 2>&1; echo "$2 rc=$?"; }
+pmc() { timeout $1 rocprofv3 --pmc $4 -d $P/$2 -o bench -- python $B $3 > $P/$2.log 2>&1; echo "$2 rc=$?"; }
+trace 200 trace_config2 "--config 2 --steps 1 --warmup 1 --cpu-sample 0 --also none"
+trace 200 trace_config4 "--config 4 --steps 1 --warmup 1 --cpu-sample 0"
+trace 300 trace_config5 "--config 5 --steps 1 --warmup 0 --cpu-sample 0"
+S2="--config 2 --reads 16000 --steps 1 --warmup 0 --cpu-sample 0 --also none"
+S4="--config 4 --steps 1 --warmup 0 --cpu-sample 0"      # full size: below ~2048 jobs the queue hands out whole jobs and runs one wavefront per SIMD
+S5="--config 5 --reads 8192 --db-targets 2048 --steps 1 --warmup 0 --cpu-sample 0"
+SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY"
+GR="GRBM_GUI_ACTIVE GRBM_COUNT"
+pmc 150 pmc2_fetch "$S2" FETCH_SIZE; pmc 150 pmc2_write "$S2" WRITE_SIZE; pmc 150 pmc2_sq1 "$S2" "$SQ1"; pmc 150 pmc2_grbm "$S2" "$GR"
+pmc 150 pmc4_fetch "$S4" FETCH_SIZE; pmc 150 pmc4_write "$S4" WRITE_SIZE; pmc 150 pmc4_sq1 "$S4" "$SQ1"; pmc 150 pmc4_grbm "$S4" "$GR"
+pmc 150 pmc5_fetch "$S5" FETCH_SIZE; pmc 150 pmc5_write "$S5" WRITE_SIZE; pmc 150 pmc5_sq1 "$S5" "$SQ1"; pmc 150 pmc5_grbm "$S5" "$GR"
+cd $GRAFT_REPO_ROOT
+python scripts/summarize_round3.py gpurun_out/prof3 > gpurun_out/prof3_summary.log 2>&1; tail -n 30 gpurun_out/prof3_summary.log
+find $P -name "*.db" -size +30M -delete
+du -sh gpurun_out

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""rocprofv3 outputs of scripts/gpu_profile_round3.sh (rocpd sqlite) -> the small summaries committed under profiles/:
+per-kernel time statistics of the kernel-trace runs, per-kernel PMC counter sums, and profiles/round3_traffic.json (HBM bytes
+per alignment of the dominant fill kernel of each config, with the hash of the kernel source they were measured on).
+Run on the GPU box right after the passes (the databases are too big to travel); writes into gpurun_out/ and profiles/."""
+import glob
+import hashlib
+import json
+import os
+import sqlite3
+import sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof3"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = os.path.join(ROOT, "gpurun_out", "profiles_round3")
+os.makedirs(out_dir, exist_ok=True)
+
+
+def dbs(pattern):
+    return sorted(glob.glob(os.path.join(src, pattern, "**", "*results.db"), recursive=True))
+
+
+for cfg in (2, 4, 5):
+    for d in dbs("trace_config%d" % cfg):
+        db = sqlite3.connect(d)
+        rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), max(sgpr_count), "
+                          "max(lds_size), max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
+        tot = sum(r[2] for r in rows) or 1
+        with open(os.path.join(out_dir, "round3_config%d_kernel_stats.csv" % cfg), "w") as f:
+            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --config %d --steps 1 --warmup %d --cpu-sample 0 [--also none]   (durations in ns; vgpr = the trace record's arch_vgpr field, NOT the allocation: the code objects say 72 for k_fill<10,frame>)\n" % (cfg, 0 if cfg == 5 else 1))
+            f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent,vgpr,sgpr,lds_bytes,max_grid_x,workgroup_x\n")
+            for r in rows:
+                f.write("\"%s\",%d,%d,%.0f,%d,%d,%.3f,%d,%d,%d,%d,%d\n" % (r[0], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot, r[6], r[7], r[8], r[9], r[10]))
+        print(open(os.path.join(out_dir, "round3_config%d_kernel_stats.csv" % cfg)).read()[:1500])
+
+traffic = {"kernel_source_sha16": hashlib.sha256(open(os.path.join(ROOT, "complete-striped-smith-waterman-library_amd", "csrc", "ssw_kernels.hip"), "rb").read()).hexdigest()[:16],
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (scripts/gpu_profile_round3.sh); FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 reports half of a wide coalesced read); KB -> bytes"}
+# bench.py runs the batch `steps + warmup` times and once more (the upload-inclusive step of the DNA configs, the verification
+# step of config 5): the PMC commands use --steps 1 --warmup 0, i.e. TWO passes of the fill kernel over the batch
+PASSES = 2
+alns = {2: 16000 * PASSES, 4: 10000 * PASSES, 5: 8192 * 2048 * PASSES}
+dominant = {2: "k_fill", 4: "k_chainq", 5: "k_filldb"}
+with open(os.path.join(out_dir, "round3_pmc.csv"), "w") as f:
+    f.write("# rocprofv3 --pmc <counters> -- python bench.py --config N (config 2: 16000 reads, config 4: full size, config 5: 8192 x 2048), one pass per counter group\n")
+    f.write("pass,kernel,counter,dispatches,sum,avg_per_dispatch,avg_dispatch_ns\n")
+    sums = {}
+    for d in dbs("pmc*"):
+        name = [p for p in d.split(os.sep) if p.startswith("pmc")][0]
+        c = sqlite3.connect(d)
+        for r in c.execute("select kernel_name, counter_name, count(*), sum(value), avg(value), avg(duration) from counters_collection "
+                           "where kernel_name like '%k_%' group by kernel_name, counter_name order by kernel_name, counter_name"):
+            f.write("%s,\"%s\",%s,%d,%.6g,%.6g,%.0f\n" % (name, r[0], r[1], r[2], r[3], r[4], r[5]))
+            cfg = int(name[3])
+            if dominant[cfg] in r[0] and not ("k_chainq" in r[0] and ", true," in r[0]) and r[1] in ("FETCH_SIZE", "WRITE_SIZE"):   # (window passes of the strip kernel excluded)
+                sums.setdefault(cfg, {}).setdefault(r[1], 0.0)
+                sums[cfg][r[1]] += r[3]
+for cfg, v in sums.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        hbm = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+        traffic["config%d" % cfg] = {"kernel": dominant[cfg] + "<...> (fill launches only; window passes of the same template excluded)", "alignments_counted": alns[cfg], "passes_over_the_batch": PASSES,
+                                     "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"], "hbm_bytes_per_alignment": hbm / alns[cfg]}
+if 2 in sums:
+    traffic["config3"] = dict(traffic.get("config2", {}), note="config 3 shares config 2's kernel (k_fill<10,frame>); per-alignment traffic scales with the target length: not measured separately")
+    traffic.pop("config3")
+with open(os.path.join(out_dir, "round3_traffic.json"), "w") as f:
+    json.dump(traffic, f, indent=1)
+print(json.dumps(traffic, indent=1))

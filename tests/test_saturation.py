@@ -3,9 +3,11 @@
 * scores at and beyond 32767 -- the reference's 16-bit kernel saturates (`_mm_adds_epi16`, reference src/ssw.c:483) and
   has no overflow detection, so score1 = 32767 and everything derived from it (end positions, the reverse pass that
   terminates on that value, the traceback that cannot re-score its CIGAR) is part of the contract;
-* the 31744 boundary between k_fill<R, 2> (two-row column maximum through v_pk_maximum3_f16 on int16 bit patterns)
-  and k_fill<R, 0> (csrc/ssw_host.c, `fa.f16`), and the same guard of the fused database-search kernel (max(mat) <= 49);
-* the 2048 boundary of the f16 form, for several rows-per-lane R.
+* the range limit of the column-frame form (csrc/ssw_host.c ssw_frame_params: bucket bound + frame offsets < 31744), on both
+  sides of which k_fill / k_chainq / k_filldb run as <.., frame> or as plain int16 -- with reads that REACH the bound (exact
+  copies of padded length x the match score), so the largest frame values really occur;
+* the boundaries rounds 1-2 had (31744 of the two-row maximum, 2048 of the f16 form, max(mat) <= 49 of the database path): kept
+  as ordinary cases -- nothing special happens there any more.
 
 The same seeded cases run on the CPU emulator (small, `not gpu`) and on the MI355X (`gpu`), against the compiled reference.
 """
@@ -67,6 +69,18 @@ def cases(scale):
         out.append(("form_boundary_R%d_m%d" % (R, mm), reads, [ref], _mat(mm, 11), 5, 7, 2, 1, -1, 2, {}))
         out.append(("form_boundary_R%d_m%d_int16" % (R, mm), reads, [ref], _mat(mm, 11), 5, 7, 2, 0, -1, 2, {"SSW_GPU_FILL_F16": "0"}))
 
+    # --- the range limit of the column-frame form: gaps 7/2 -> K = 1024, offsets up to ~2114 (16-lane chains) / ~2210 (64-lane chains)
+    for R, mm in ((24, 77), (24, 78), (16, 115), (16, 116), (20, 92), (20, 93)):       # 16 R mm = 29568 / 29952, 29440 / 29696, 29440 / 29760
+        L = 16 * R
+        reads = [_clean(ref, rng, L), _clean(ref, rng, L - 1), _clean(ref, rng, L - 9, sub=0.01), _clean(ref, rng, L, sub=0.02)]
+        out.append(("frame_limit_R%d_m%d" % (R, mm), reads, [ref], _mat(mm, 11), 5, 7, 2, 1, -1, 2, {}))
+    for mm in (41, 42):       # strip kernel: 704 rows x 41 = 28864 (frame), x 42 = 29568 (plain int16)
+        reads = [_clean(ref, rng, 704), _clean(ref, rng, 700, sub=0.01), _clean(ref, rng, 690)]
+        out.append(("frame_limit_strip_m%d" % mm, reads, [ref], _mat(mm, 11), 5, 7, 2, 2, -1, 2, {}))
+    for K in ("16", "64"):    # ... and with the frame renormalised every 16 / 64 steps, scores still near the top of the range
+        reads = [_clean(ref, rng, 384), _clean(ref, rng, 383), _clean(ref, rng, 300, sub=0.02)]
+        out.append(("frame_limit_K%s" % K, reads, [ref], _mat(80, 11), 5, 7, 2, 1, -1, 2, {"SSW_GPU_FRAME_K": K}))
+
     # --- 2048: the guard of the f16 form, 16 R max(mat) <= 2047, reads that reach the bound
     for R, mm in ((8, 15), (8, 16), (10, 12), (10, 13), (4, 31), (4, 32), (2, 63), (2, 64), (1, 127), (16, 7), (16, 8), (21, 6), (21, 7)):
         L = 16 * R
@@ -78,7 +92,7 @@ def cases(scale):
     dbn = 24 if big else 6
     db = [np.ascontiguousarray(ref[int(o):int(o) + int(L)]) for o, L in zip(rng.integers(0, len(ref) - 700, size=dbn), rng.integers(200, 700, size=dbn))]
     qs = [db[0][:640].copy(), db[1][:384].copy(), db[2][:400].copy(), db[3][:150].copy(), _clean(ref, rng, 640, sub=0.02), _clean(ref, rng, 333)]
-    for mm in (49, 50):
+    for mm in (46, 47, 49, 50):       # 640 x 46 = 29440: frame; 47: plain int16 in k_filldb; 50: outside the fused kernel
         out.append(("db_guard_m%d" % mm, qs, db, _mat(mm, 20), 5, 11, 3, 0, -1, 2, {}))
     # protein matrix scaled so that long homologous queries go far beyond 255 and towards the 16-bit limit
     b50 = blosum50().astype(np.int64)
