@@ -1308,7 +1308,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 				sched_fence();
 			}
 			st.hsave = hin; st.Hlast = st.H[R - 1]; st.Fout = f; st.cmout = cm; st.cm8out = MASK8 ? cm8 : cm;
-			if (l16 == GL - 1) {
+			if (l16 == GL - 1) {   /* (one 16-byte store; four dword stores instead -- no register copies to make the four consecutive -- measured 2.4 % slower) */
 				const u32x4 o = { st.Hlast, st.Fout, st.cmout, st.cm8out };
 				lds_st128(lds, x.bout + 16u * ((u32)(s - (GL - 1)) & x.bmask), o);
 			}
