@@ -1690,6 +1690,7 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
  * Per alignment scratch (HBM, L1/L2 resident): H buffers x2, E, Hmax as [segment][16] int16, read codes, maxColumn.
  * ================================================================================================ */
 struct LitOut { int score, ref, read, score2, ref2; };
+#define LIT_U 8
 
 SSW_DEV int lit_rowmax(int v)   /* maximum over the 16 lanes of a row, in every lane */
 {
@@ -1746,26 +1747,43 @@ SSW_DEV void literal_fill(bool on, bool is_byte, const int8_t* ref, int ref_dir,
 		int prevlast = (colact && lane_on) ? (int)Hld[(segLen - 1) * 16 + l16] : 0;
 		int vH = (int)xl_row_shr1_zero((u32)prevlast);
 		int vF = 0, vMax = 0;
-		for (int j = 0; j < maxseg; ++j) {
-			const bool act = colact && lane_on && j < segLen;
-			if (act) {
-				const int cd = code[j * 16 + l16];
-				const int sc = cd >= 0 ? mrow[cd] : 0;
-				int h;
-				if (is_byte) { h = vH + sc + bias; if (h > 255) h = 255; h -= bias; if (h < 0) h = 0; }
-				else { h = vH + sc; if (h > 32767) h = 32767; if (h < -32768) h = -32768; }
-				int e = Eb[j * 16 + l16];
-				h = h > e ? h : e; h = h > vF ? h : vF;
-				vMax = vMax > h ? vMax : h;
-				Hst[j * 16 + l16] = (int16_t)h;
-				if (is_byte) { h = h - gapO; if (h < 0) h = 0; e = e - gapE; if (e < 0) e = 0; }
-				else { const unsigned uh = (uint16_t)h, ue = (uint16_t)e; h = (int16_t)(uint16_t)(uh > (unsigned)gapO ? uh - gapO : 0); e = (int16_t)(uint16_t)(ue > (unsigned)gapE ? ue - gapE : 0); }
-				e = e > h ? e : h;
-				Eb[j * 16 + l16] = (int16_t)e;
-				if (is_byte) { vF = vF - gapE; if (vF < 0) vF = 0; }
-				else { const unsigned uf = (uint16_t)vF; vF = (int16_t)(uint16_t)(uf > (unsigned)gapE ? uf - gapE : 0); }
-				vF = vF > h ? vF : h;
-				vH = Hld[j * 16 + l16];
+		/* the segments of a column in chunks of LIT_U: the chunk's inputs (read codes, E, the previous column's H -- addresses that do not
+		   depend on the arithmetic) are requested together, then its scores, then the chunk is computed: one wavefront per SIMD (a batch of
+		   a few thousand alignments is a few hundred wavefronts) cannot hide a memory round trip per segment, it can hide one per chunk */
+		for (int j0 = 0; j0 < maxseg; j0 += LIT_U) {
+			int cdv[LIT_U], ev[LIT_U], hlv[LIT_U], scv[LIT_U];
+#pragma unroll
+			for (int u = 0; u < LIT_U; ++u) {
+				const int j = j0 + u;
+				const bool act = colact && lane_on && j < segLen;
+				cdv[u] = act ? (int)code[j * 16 + l16] : -1;
+				ev[u] = act ? (int)Eb[j * 16 + l16] : 0;
+				hlv[u] = act ? (int)Hld[j * 16 + l16] : 0;
+			}
+#pragma unroll
+			for (int u = 0; u < LIT_U; ++u) scv[u] = cdv[u] >= 0 ? (int)mrow[cdv[u]] : 0;
+#pragma unroll
+			for (int u = 0; u < LIT_U; ++u) {
+				const int j = j0 + u;
+				const bool act = colact && lane_on && j < segLen;
+				if (act) {
+					const int sc = scv[u];
+					int h;
+					if (is_byte) { h = vH + sc + bias; if (h > 255) h = 255; h -= bias; if (h < 0) h = 0; }
+					else { h = vH + sc; if (h > 32767) h = 32767; if (h < -32768) h = -32768; }
+					int e = ev[u];
+					h = h > e ? h : e; h = h > vF ? h : vF;
+					vMax = vMax > h ? vMax : h;
+					Hst[j * 16 + l16] = (int16_t)h;
+					if (is_byte) { h = h - gapO; if (h < 0) h = 0; e = e - gapE; if (e < 0) e = 0; }
+					else { const unsigned uh = (uint16_t)h, ue = (uint16_t)e; h = (int16_t)(uint16_t)(uh > (unsigned)gapO ? uh - gapO : 0); e = (int16_t)(uint16_t)(ue > (unsigned)gapE ? ue - gapE : 0); }
+					e = e > h ? e : h;
+					Eb[j * 16 + l16] = (int16_t)e;
+					if (is_byte) { vF = vF - gapE; if (vF < 0) vF = 0; }
+					else { const unsigned uf = (uint16_t)vF; vF = (int16_t)(uint16_t)(uf > (unsigned)gapE ? uf - gapE : 0); }
+					vF = vF > h ? vF : h;
+					vH = hlv[u];
+				}
 			}
 		}
 		/* lazy-F loop (ssw.c:302-315 / 509-520): stops as soon as no lane's F can still raise an H */
@@ -1774,7 +1792,7 @@ SSW_DEV void literal_fill(bool on, bool is_byte, const int8_t* ref, int ref_dir,
 			if (!wave_any(lazy && k < L)) break;
 			const bool kact = lazy && k < L;
 			vF = (int)xl_row_shr1_zero((u32)vF);
-			for (int j = 0; j < maxseg; ++j) {
+			for (int j = 0; j < maxseg; ++j) {      /* (reading a chunk of segments ahead here, like the sweep above does, measured 12 % slower: the loop usually ends within a segment or two) */
 				if (!wave_any(lazy && k < L && j < segLen)) break;
 				const bool act = kact && lazy && j < segLen;
 				bool more = false;
@@ -1839,6 +1857,10 @@ __global__ void __launch_bounds__(256) k_literal(ssw_literal_args a)
 	unsigned char* const gscr = a.scratch + (int64_t)(job < a.nq ? job : 0) * a.scratch_stride;
 	unsigned char* const scratch = a.lds_stride > 0 ? lds + (size_t)grp * (size_t)a.lds_stride : gscr;
 	uint16_t* const mc = (uint16_t*)(gscr + a.mc_off);
+	/* the scoring matrix in LDS, behind the per-alignment state regions: mat[ref][read] is a dependent look-up in every segment */
+	int8_t* const lmat = (int8_t*)(lds + (size_t)((int)blockDim.x >> 4) * (size_t)a.lds_stride);
+	for (int k = tid; k < a.n * a.n; k += (int)blockDim.x) lmat[k] = a.mat[k];
+	__syncthreads();
 	const int8_t* read = q >= 0 ? a.qcodes + a.qoff[q] : a.qcodes;
 	const int readLen = q >= 0 ? (int)(a.qoff[q + 1] - a.qoff[q]) : 0;
 	const int maskLen = a.maskLen >= 0 ? a.maskLen : readLen / 2;
@@ -1852,7 +1874,7 @@ __global__ void __launch_bounds__(256) k_literal(ssw_literal_args a)
 		bool need_word = q >= 0 && !have_byte;
 		bool done = q < 0;
 		if (wave_any(q >= 0 && have_byte)) {
-			literal_fill(q >= 0 && have_byte, true, a.tgt, 0, a.refLen, read, readLen, 0, a.mat, a.n, a.gapO, a.gapE, 255, a.bias, maskLen,
+			literal_fill(q >= 0 && have_byte, true, a.tgt, 0, a.refLen, read, readLen, 0, lmat, a.n, a.gapO, a.gapE, 255, a.bias, maskLen,
 			             scratch, mc, tid, o);
 			if (q >= 0 && have_byte) {
 				if (o.score == 255) { if (have_word) need_word = true; else { r.status = 1; done = true; } }
@@ -1860,7 +1882,7 @@ __global__ void __launch_bounds__(256) k_literal(ssw_literal_args a)
 		}
 		if (wave_any(need_word)) {
 			LitOut w;
-			literal_fill(need_word, false, a.tgt, 0, a.refLen, read, readLen, 0, a.mat, a.n, a.gapO, a.gapE, 65535, 0, maskLen, scratch, mc, tid, w);
+			literal_fill(need_word, false, a.tgt, 0, a.refLen, read, readLen, 0, lmat, a.n, a.gapO, a.gapE, 65535, 0, maskLen, scratch, mc, tid, w);
 			if (need_word) { o = w; r.word = 1; }
 		}
 		if (q >= 0 && !done && o.score > 0) {
@@ -1877,12 +1899,12 @@ __global__ void __launch_bounds__(256) k_literal(ssw_literal_args a)
 		const int plen = act ? r.read_end1 + 1 : 0, cols = act ? r.ref_end1 + 1 : 0;
 		if (wave_any(actb)) {
 			LitOut w;
-			literal_fill(actb, true, a.tgt, 1, cols, read, plen, 1, a.mat, a.n, a.gapO, a.gapE, r.score1 & 0xff, a.bias, maskLen, scratch, mc, tid, w);
+			literal_fill(actb, true, a.tgt, 1, cols, read, plen, 1, lmat, a.n, a.gapO, a.gapE, r.score1 & 0xff, a.bias, maskLen, scratch, mc, tid, w);
 			if (actb) o = w;
 		}
 		if (wave_any(actw)) {
 			LitOut w;
-			literal_fill(actw, false, a.tgt, 1, cols, read, plen, 1, a.mat, a.n, a.gapO, a.gapE, r.score1 & 0xffff, 0, maskLen, scratch, mc, tid, w);
+			literal_fill(actw, false, a.tgt, 1, cols, read, plen, 1, lmat, a.n, a.gapO, a.gapE, r.score1 & 0xffff, 0, maskLen, scratch, mc, tid, w);
 			if (actw) o = w;
 		}
 		if (act && l16 == 0) {
@@ -2793,9 +2815,9 @@ extern "C" int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream)
 	/* (an alignment is one DPP row -- 16 lanes -- whatever the workgroup: small batches take wavefront-sized workgroups so that
 	   they spread over more CUs) */
 	if (st > 0 && st * 16 <= 65536 && args.nq >= 16 * 2048) { threads = 256; args.lds_stride = (int32_t)st; }
-	else if (st > 0 && st * 4 <= (int64_t)SSW_LDS_LIMIT) { threads = 64; args.lds_stride = (int32_t)st; }
+	else if (st > 0 && st * 4 + 1024 <= (int64_t)SSW_LDS_LIMIT) { threads = 64; args.lds_stride = (int32_t)st; }
 	const int per = threads / 16;
-	SSW_LAUNCH(k_literal, ssw_literal_args, args, (args.nq + per - 1) / per, threads, (size_t)args.lds_stride * per, stream);
+	SSW_LAUNCH(k_literal, ssw_literal_args, args, (args.nq + per - 1) / per, threads, (size_t)args.lds_stride * per + 1024, stream);
 	return SSW_LAUNCH_OK();
 }
 

@@ -117,6 +117,7 @@ void ssw_gpu_pool_close(ssw_gpu_pool* p)
 }
 
 int ssw_gpu_pool_size(const ssw_gpu_pool* p) { return p ? p->n : 0; }
+size_t ssw_gpu_pool_budget(const ssw_gpu_pool* p, int worker) { return p && worker >= 0 && worker < p->n ? ssw_gpu_get_budget(p->w[worker].ctx) : 0; }
 const char* ssw_gpu_pool_last_error(const ssw_gpu_pool* p) { return p ? p->err : ssw_gpu_last_error(0); }
 
 int ssw_gpu_pool_set_targets(ssw_gpu_pool* p, const int8_t* codes, const int64_t* offsets, int32_t count)

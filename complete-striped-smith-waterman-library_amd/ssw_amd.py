@@ -115,6 +115,8 @@ def load(path=None):
     L.ssw_gpu_set_budget.restype = C.c_int
     L.ssw_gpu_get_budget.argtypes = [C.c_void_p]
     L.ssw_gpu_get_budget.restype = C.c_size_t
+    L.ssw_gpu_pool_budget.argtypes = [C.c_void_p, C.c_int]
+    L.ssw_gpu_pool_budget.restype = C.c_size_t
     L.ssw_gpu_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
     L.ssw_gpu_host_alloc.restype = C.c_void_p
     L.ssw_gpu_host_free.argtypes = [C.c_void_p, C.c_void_p]

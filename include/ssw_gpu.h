@@ -166,6 +166,7 @@ typedef struct ssw_gpu_pool ssw_gpu_pool;
 ssw_gpu_pool* ssw_gpu_pool_open(const int* devices, int n);      /* NULL on failure: ssw_gpu_last_error(NULL) */
 void ssw_gpu_pool_close(ssw_gpu_pool* pool);
 int ssw_gpu_pool_size(const ssw_gpu_pool* pool);
+size_t ssw_gpu_pool_budget(const ssw_gpu_pool* pool, int worker);   /* scratch budget of that worker's context: workers sharing a device share its HBM */
 const char* ssw_gpu_pool_last_error(const ssw_gpu_pool* pool);
 int ssw_gpu_pool_set_targets(ssw_gpu_pool* pool, const int8_t* codes, const int64_t* offsets, int32_t count);
 int ssw_gpu_pool_align(ssw_gpu_pool* pool, const int8_t* qcodes, const int64_t* qoffsets, int32_t nq, int32_t block,

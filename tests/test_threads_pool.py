@@ -16,7 +16,7 @@ import pytest
 
 import ssw_amd
 from parity import compare_batch, make_reads
-from sswutil import RES_FIELDS, dna_matrix, random_ref, ref_align
+from sswutil import RES_FIELDS, dna_matrix, random_ref, ref_align, sample_reads
 
 i8p = C.POINTER(C.c_int8)
 
@@ -134,3 +134,61 @@ def test_single_pair_abi_from_four_threads_gpu(product_lib_path):
 def test_pool_two_workers_one_gpu(product_lib_path):
     st = _pool_vs_single(ssw_amd.load(product_lib_path), [0, 0], nreads=1500, reflen=30000, block=128)
     assert len(st) == 2 and sum(s["queries"] for s in st) == 1500
+
+
+# ---- return codes, the sized timing record, per-context budgets ----
+def test_busy_context_returns_its_own_code_and_timing_is_sized(emu_lib_path):
+    """a second thread entering a busy context gets SSW_GPU_BUSY (-2, named by ssw_gpu_strerror; no stale message is reported);
+    ssw_gpu_last_timing_sized writes no more than the caller's sizeof; a chunk function's negative return value comes back as it is"""
+    import ctypes as C
+    import threading
+    lib = ssw_amd.load(emu_lib_path)
+    assert lib.ssw_gpu_strerror(-2).decode().startswith("the context is inside another call")
+    ctx = ssw_amd.Context(0, lib)
+    ref = random_ref(4000, 3, 4)
+    reads = sample_reads(ref, 6, 100, seed=4)
+    Q = ctx.upload(reads); T = ctx.upload([ref, ref[:900].copy(), ref[1000:2500].copy(), ref[50:700].copy()])
+    seen = []
+
+    def worker():
+        try:
+            ctx.align_batch(Q, T, dna_matrix(2, 2), 5, 3, 1, 2, 0, 0, -1, 2)
+            seen.append("done")
+        except RuntimeError as e:
+            seen.append(str(e))
+    th = [threading.Thread(target=worker) for _ in range(3)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert "done" in seen and all(s == "done" or "inside another call" in s for s in seen), seen
+    # sized timing: 24 bytes = total_ms, fill_ms, fill_launches; the rest of a larger caller buffer is left alone
+    buf = (C.c_ubyte * 64)(*([0xEE] * 64))
+    assert lib.ssw_gpu_last_timing_sized(ctx.h, buf, 24) == 0
+    assert bytes(buf[24:]) == b"\xee" * 40 and C.cast(buf, C.POINTER(C.c_double))[0] > 0
+    # a negative stop value of the caller's chunk function is returned, not raised
+    assert ctx.search_db(Q, T, dna_matrix(2, 2), 5, 3, 1, -1, 2, 2, lambda t0, h: -7) == -7
+    # budget setter
+    b0 = lib.ssw_gpu_get_budget(ctx.h)
+    assert lib.ssw_gpu_set_budget(ctx.h, 64 << 20) == 0 and lib.ssw_gpu_get_budget(ctx.h) == 64 << 20
+    assert lib.ssw_gpu_set_budget(ctx.h, 0) == 0 and lib.ssw_gpu_get_budget(ctx.h) == b0
+    Q.free(); T.free(); ctx.close()
+
+
+def test_pool_workers_on_one_device_share_its_budget(emu_lib_path, monkeypatch):
+    """every context sizes its scratch budget from the HBM that is free when IT is opened; a pool divides that by the workers it put
+    on the same device (an explicit SSW_GPU_CM_BUDGET_MB is per context and kept as it is)"""
+    monkeypatch.setenv("SSW_EMU_DEVICES", "2")
+    monkeypatch.delenv("SSW_GPU_CM_BUDGET_MB", raising=False)
+    lib = ssw_amd.load(emu_lib_path)
+    solo = ssw_amd.Context(0, lib); full = lib.ssw_gpu_get_budget(solo.h); solo.close()
+    pool = ssw_amd.Pool([0, 0, 1], lib)
+    try:
+        b = [lib.ssw_gpu_pool_budget(pool.h, i) for i in range(3)]
+        assert b[0] == full // 2 and b[1] == full // 2 and b[2] == full, (b, full)
+    finally:
+        pool.close()
+    monkeypatch.setenv("SSW_GPU_CM_BUDGET_MB", "32")
+    pool = ssw_amd.Pool([0, 0], lib)
+    try:
+        assert [lib.ssw_gpu_pool_budget(pool.h, i) for i in range(2)] == [32 << 20, 32 << 20]
+    finally:
+        pool.close()
