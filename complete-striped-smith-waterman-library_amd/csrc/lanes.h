@@ -195,6 +195,9 @@ SSW_DEV u32 pk_max3_fr(u32 a, u32 b, u32 c) { return pk_max3_nonneg(a, b, c); }
 #define FR_DEAD 32768
 SSW_DEV u32 fr_pack(int lo, int hi) { return (u32)lo + ((u32)hi << 16); }
 SSW_DEV u32 umax32(u32 a, u32 b) { return a > b ? a : b; }
+/* v_pk_add_u16 (wrapping, per half): the frame add where the two halves of a score register come from DIFFERENT profile entries (window
+   passes: one target column per query half), so that the packed-sum trick of fr_pack does not apply -- entries are per-half two's complement there */
+SSW_DEV u32 pk_addw(u32 a, u32 b) { return __builtin_bit_cast(u32, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b))); }
 /* phi of the column that lane `lane` of a GL-lane chain works on at step `step`: base + ((step mod K) + GL - lane) * gapE (all
    registers drop by K * gapE when step reaches a multiple of K) */
 SSW_DEV int fr_phi(int step, int lane, int GL, int base, int kmask, int gapE) { return base + ((step & kmask) + GL - lane) * gapE; }

@@ -381,8 +381,8 @@ static int launch_window_pass(ssw_gpu_ctx* c, int32_t R, int32_t lanes, int32_t 
 	if (lanes != 64) return ssw_shim_launch_chainx(R, 1, xa, c->stream);
 	const int qgrid = chainq_grid(R, 1, n);
 	if (chainq_prepare(c, xa, strips, ((int64_t)xa->njobs + 1) / 2, qgrid)) return -1;
-	if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] chainq window pass (reverse %d): R %d, %d queries x %d strips, %d wavefronts, %s tickets\n",
-	                                     xa->reverse, R, xa->njobs, strips, qgrid, xa->whole_jobs ? "job" : "strip");
+	if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] chainq window pass (reverse %d): R %d, %d queries x %d strips, %d wavefronts, %s tickets, form %d\n",
+	                                     xa->reverse, R, xa->njobs, strips, qgrid, xa->whole_jobs ? "job" : "strip", xa->form);
 	const int rc = ssw_shim_launch_chainq(R, 1, xa, qgrid, c->stream);
 	if (getenv("SSW_GPU_DEBUG")) { const int src = ssw_shim_stream_sync(c->stream); fprintf(stderr, "[ssw_gpu] chainq window pass done (sync rc %d: %s)\n", src, src ? ssw_shim_last_error() : "ok"); }
 	return rc;
@@ -1039,6 +1039,10 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 							if (!d_retry) goto done;
 							int32_t missed = 0;
 							xa.window_extra = pass ? 64 : -1; xa.retry_count = d_retry;
+							/* the window passes of the 64-lane chains in the column-frame form too, when the bucket fits its range */
+							xa.form = 0; xa.fr_base = 0; xa.fr_kmask = 0;
+							if (fill_form != 0 && capL == 64 && !getenv("SSW_GPU_WINDOW_INT16") &&
+							    ssw_frame_params((int64_t)B->P16 * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, minmat, 64, &xa.fr_base, &xa.fr_kmask)) xa.form = 3;
 							const int32_t capS = (B->P16 + capL * capR - 1) / (capL * capR);
 							if (ssw_shim_memset(d_retry, 0, sizeof(int32_t), c->stream) ||
 							    launch_window_pass(c, capR, capL, capS, &xa, n)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }

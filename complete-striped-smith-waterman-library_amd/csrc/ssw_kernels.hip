@@ -1043,7 +1043,9 @@ template <bool ALL4> SSW_DEV u32x4 lds_ld_bnd(const unsigned char* lds, u32 off)
 
 /* profile of one strip: word = (score of query a's row, score of query b's row) against residue b; rows at or below a
    query's padded length are dead for that half */
-template <int R, int GL, bool FR = false>
+/* PM 0: packed int16; 2: column frame, packed-sum entries (fr_pack: both halves look at the same target column); 3: column frame,
+   per-half two's complement entries (window passes: every query half has its own target column; added with pk_addw) */
+template <int R, int GL, int PM = 0>
 SSW_DEV void build_profile_strip(unsigned char* lds, u32 base, int first, int nthreads, const int8_t* mat, int n,
                                  const int8_t* qa, int lena, int reva, int rowsa, const int8_t* qb, int lenb, int revb, int rowsb, int row0, int gapE = 0)
 {
@@ -1055,12 +1057,14 @@ SSW_DEV void build_profile_strip(unsigned char* lds, u32 base, int first, int nt
 		const int r = c * 4 + k, row = row0 + l * R + r;
 		u32 v;
 		if (r >= R) v = 0;
-		else if (b == n) v = FR ? fr_pack(FR_DEAD, FR_DEAD) : DEAD2;                            /* null residue */
+		else if (b == n) v = PM ? fr_pack(FR_DEAD, FR_DEAD) : DEAD2;                            /* null residue */
 		else {
 			int lo = -32768, hi = -32768;                      /* rows below the padded query */
 			if (row < rowsa) lo = row < lena ? mat[b * n + (reva ? qa[lena - 1 - row] : qa[row])] : 0;
 			if (row < rowsb) hi = qb && row < lenb ? mat[b * n + (revb ? qb[lenb - 1 - row] : qb[row])] : 0;
-			v = FR ? fr_pack(lo == -32768 ? FR_DEAD : lo + gapE, hi == -32768 ? FR_DEAD : hi + gapE) : pk_make(lo, hi);
+			if (PM == 2) v = fr_pack(lo == -32768 ? FR_DEAD : lo + gapE, hi == -32768 ? FR_DEAD : hi + gapE);
+			else if (PM == 3) v = pk_make(lo == -32768 ? FR_DEAD : lo + gapE, hi == -32768 ? FR_DEAD : hi + gapE);
+			else v = pk_make(lo, hi);
 		}
 		lds_st32(lds, base + (u32)w * 4u, v);
 	}
@@ -1171,7 +1175,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	st.Hlast = zero0; st.Fout = zero0; st.cmout = zero0; st.cm8out = zero0; st.hsave = zero0;
 	const u32 lane_prof = x.prof + (u32)l16 * 16u;
 	u32 sbest = zero0; int sv[2] = { 0, 0 }, stc[2] = { 0x7fffffff, 0x7fffffff }, srow[2] = { 0x7fffffff, 0x7fffffff };   /* this strip's tracking */
-	if (CAPTURE) sbest = pk_subu(pk_make(st.best[0], st.best[1]), 0x00010001u);
+	if (CAPTURE) sbest = pk_subu(pk_make(st.best[0], st.best[1]), 0x00010001u) + zero0;      /* (frame form: in the frame of the lane's column, like everything it is compared with) */
 	unsigned long long pend = 0ull; u32 prep = 0;   /* fill: lanes whose rows set a record in the step before, and that step's `pre` */
 	wave_lds_fence();
 	/* software pipeline of the LDS reads (two waves per SIMD do not hide their latency): the scores and the boundary record
@@ -1279,7 +1283,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 				const u32 sv = sc[r >> 2][r & 3];
 				u32 h;
 				if (FR) {
-					h = pk_max3_fr(d + sv, st.E[r], f);
+					h = pk_max3_fr(CAPTURE ? pk_addw(d, sv) : d + sv, st.E[r], f);
 					const u32 t = h - fr_c1;
 					st.E[r] = pk_max3_fr(st.E[r], t, fl);
 					f = pk_max(f, t) - x.gapE2;
@@ -1290,7 +1294,10 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 				st.E[r] = pk_max(pk_subu(st.E[r], x.gapE2), t0);
 				f = pk_max(pk_subu(f, x.gapE2), t0);
 				}
-				if (CAPTURE) lm = pk_max(lm, h);
+				if (CAPTURE && FR) {   /* the lane's own maximum of this column, two rows per instruction */
+					if (r & 1) lm = pk_max3_fr(lm, st.H[r - 1 >= 0 ? r - 1 : 0], h);
+					else if (r == R - 1) lm = pk_max(lm, h);
+				} else if (CAPTURE) lm = pk_max(lm, h);
 				else if (CM3 && !MASK8) {   /* column maximum of two rows in one instruction (scores below 31744: pk_max3_nonneg) */
 					if (r & 1) cm = pk_max3_nonneg(cm, st.H[r - 1 >= 0 ? r - 1 : 0], h);
 					else if (r == R - 1) cm = pk_max(cm, h);
@@ -1314,16 +1321,17 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			}
 			if (CAPTURE) {   /* rarely taken: some half reaches (at least) its best so far -- sbest holds best - 1 per half */
 				if (pk_max(sbest, lm) != sbest && x.mine && tc >= 0) {
+					const int phi = FR ? (int)((fl - x.gapE2) & 0xffffu) : 0;      /* lm, H and sbest carry the frame of this column */
 #pragma unroll
 					for (int h = 0; h < 2; ++h) {
-						const int m = (int)((lm >> (16 * h)) & 0xffffu);
+						const int mf = (int)((lm >> (16 * h)) & 0xffffu), m = mf - phi;
 						if (tc < x.ncols2[h] && (m > st.best[h] || (m == st.best[h] && m > 0 && tc < st.btc[h]))) {
 							st.best[h] = m; st.btc[h] = tc;
 #pragma unroll
-							for (int k = R - 1; k >= 0; --k) if ((int)((st.H[k] >> (16 * h)) & 0xffffu) == m) st.brow[h] = x.row0 + l16 * R + k;
+							for (int k = R - 1; k >= 0; --k) if ((int)((st.H[k] >> (16 * h)) & 0xffffu) == mf) st.brow[h] = x.row0 + l16 * R + k;
 						}
 					}
-					sbest = pk_subu(pk_make(st.best[0], st.best[1]), 0x00010001u);
+					sbest = pk_subu(pk_make(st.best[0], st.best[1]), 0x00010001u) + (FR ? fl - x.gapE2 : 0u);
 				}
 			}
 		}
@@ -1640,7 +1648,7 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 				if (floorv > st.best[h]) { st.best[h] = floorv; st.btc[h] = 0x7fffffff; st.brow[h] = 0; }
 			}
 		}
-		build_profile_strip<R, GL, !CAPTURE && FORM == 3>(lds, x.prof, l16, GL, a.mat, a.n, qa, lena, rev, rowsa, qb, lenb, rev, rowsb, x.row0, (int)(a.gapE2 & 0xffffu));
+		build_profile_strip<R, GL, FORM == 3 ? (CAPTURE ? 3 : 2) : 0>(lds, x.prof, l16, GL, a.mat, a.n, qa, lena, rev, rowsa, qb, lenb, rev, rowsb, x.row0, (int)(a.gapE2 & 0xffffu));
 		u32 m8[R];
 		bool need_mask = false;
 		if (!CAPTURE) {
@@ -1654,8 +1662,8 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 #pragma unroll
 			for (int q = 0; q < R; ++q) m8[q] = 0;
 		}
-		if (!CAPTURE && need_mask) run_strip<R, CAPTURE, true, GL, false, !CAPTURE && FORM == 3>(lds, x, st, m8);
-		else run_strip<R, CAPTURE, false, GL, FORM == 3, !CAPTURE && FORM == 3>(lds, x, st, m8);
+		if (!CAPTURE && need_mask) run_strip<R, CAPTURE, true, GL, false, FORM == 3>(lds, x, st, m8);
+		else run_strip<R, CAPTURE, false, GL, FORM == 3, FORM == 3>(lds, x, st, m8);
 
 		/* chain-wide winner of this strip merged with the strips above: value, then first column, then smallest row */
 		for (int h = 0; h < 2; ++h) {
@@ -2763,7 +2771,8 @@ extern "C" int ssw_shim_launch_chainq(int R, int capture, const ssw_chainx_args*
 	if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * StripGeom<r, 64>::PSTRIDE + (capture ? QueueGeom<r, true>::EXTRA : QueueGeom<r, false>::EXTRA); \
-		if (capture) SSW_LAUNCH((k_chainq<r, true, 0>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
+		if (capture && args.form == 3) SSW_LAUNCH((k_chainq<r, true, 3>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
+		else if (capture) SSW_LAUNCH((k_chainq<r, true, 0>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
 		else if (args.form == 3) SSW_LAUNCH((k_chainq<r, false, 3>), ssw_chainx_args, args, grid, 64, ldsb, stream); \
 		else SSW_LAUNCH((k_chainq<r, false, 0>), ssw_chainx_args, args, grid, 64, ldsb, stream); } break;
 		FOR_EACH_QR(X)
