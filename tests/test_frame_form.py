@@ -132,3 +132,42 @@ print("ok", total)
         env["SSW_GPU_FRAME_K"] = K
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=1800)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_frame_form_with_large_gap_penalties_and_extreme_matrices_on_the_emulator(emu_lib_path):
+    """gap extension up to 255 (renormalisation period 64, frame offsets of the order of 10^4), matrices using the whole int8 range,
+    a protein alphabet -- short queries (k_fill), long queries (strips + window passes) and the database path; the emulator aborts on
+    any operand outside the frame form's range, the records are compared with the reference"""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import ssw_amd
+from parity import compare_batch, make_reads
+from sswutil import blosum50, random_ref
+lib = ssw_amd.load(%r)
+ctx = ssw_amd.Context(0, lib)
+rng = np.random.default_rng(23)
+frames = 0
+for case, (gO, gE, hi, lo) in enumerate(((120, 60, 40, -90), (255, 254, 9, -9), (90, 20, 127, -128), (30, 7, 5, -128), (200, 100, 2, -3), (16, 15, 60, -60))):
+    n = 5 if case %% 2 == 0 else 24
+    mat = rng.integers(lo, hi + 1, size=(n, n)).astype(np.int8)
+    for k in range(n): mat[k, k] = hi
+    mat = np.ascontiguousarray(mat.reshape(-1))
+    nc = n - 1 if n == 5 else 20
+    ref = rng.integers(0, nc, size=1300, dtype=np.int8)
+    short = make_reads(rng, ref, 5, [150, 33, 90, 200, 61], nc, sub=0.05, ins=0.01, dele=0.01)
+    longq = make_reads(rng, ref, 2, [500, 401], nc, sub=0.03, ins=0.01, dele=0.01, frac_random=0.0)
+    for reads, flag in ((short, 2), (longq, 2), (short, 0)):
+        refs = [ref] if flag else [ref[:400].copy(), ref[300:900].copy(), ref[100:333].copy(), ref[700:1300].copy(), ref[:77].copy()]
+        Q = ctx.upload(reads); T = ctx.upload(refs)
+        res, cig = ctx.align_batch(Q, T, mat, n, gO, gE, flag, 0, 0, -1, 2)
+        frames += "frame" in ctx.timing()["fill_kernel"]
+        Q.free(); T.free()
+        bad = compare_batch(res, cig, reads, refs, mat, n, gO, gE, flag, 0, 0, -1, 2)
+        assert not bad, "case %%d gaps %%d/%%d flag %%d: " %% (case, gO, gE, flag) + "\n".join(bad)
+ctx.close()
+print("ok", frames)
+''' % (os.path.join(os.path.dirname(HERE), "complete-striped-smith-waterman-library_amd"), HERE, emu_lib_path)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
+    assert int(r.stdout.split()[1]) >= 10          # most of these launches did run in the frame form (the rest: buckets beyond its range)
