@@ -171,3 +171,44 @@ print("ok", frames)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
     assert int(r.stdout.split()[1]) >= 10          # most of these launches did run in the frame form (the rest: buckets beyond its range)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", ["16", "64"])
+def test_frame_renormalised_often_on_the_gpu(gpu_ctx, K, monkeypatch):
+    """the default period is 1024 steps: tests on kilobase targets would never renormalise on the hardware.  Config 2's first 4000 reads
+    against the 1 Mb target (k_fill), 600 long reads (strips + window passes) and a protein search with the frame renormalised every
+    16 / 64 steps, against the full-size fixtures / the reference"""
+    import workloads as W
+    monkeypatch.setenv("SSW_GPU_FRAME_K", K)
+    z = np.load(os.path.join(HERE, "golden", "full", "config2_block0.npz"))
+    ref, reads, p = W.dna_config(2, 0)
+    k = 4000
+    Q = gpu_ctx.upload(list(reads[:k])); T = gpu_ctx.upload([ref])
+    try:
+        res, cig = gpu_ctx.align_batch(Q, T, dna_matrix(2, 2), 5, 3, 1, 2, 0, 0, -1, 2)
+    finally:
+        Q.free(); T.free()
+    g = res[:, 0]
+    got = np.stack([g["score1"], g["score2"], g["ref_begin1"], g["ref_end1"], g["read_begin1"], g["read_end1"], g["ref_end2"], g["cigarLen"], g["flag"]], axis=1).astype(np.int32)
+    assert (got == z["fields"][:k]).all()
+    z4 = np.load(os.path.join(HERE, "golden", "full", "config4_block0.npz"))
+    ref4, reads4, p4 = W.dna_config(4, 0)
+    k4 = 600
+    Q = gpu_ctx.upload(list(reads4[:k4])); T = gpu_ctx.upload([ref4])
+    try:
+        res, cig = gpu_ctx.align_batch(Q, T, dna_matrix(2, 2), 5, 3, 1, 2, 0, 0, p4["mask_len"], 2)
+    finally:
+        Q.free(); T.free()
+    g = res[:, 0]
+    got = np.stack([g["score1"], g["score2"], g["ref_begin1"], g["ref_end1"], g["read_begin1"], g["read_end1"], g["ref_end2"], g["cigarLen"], g["flag"]], axis=1).astype(np.int32)
+    assert (got == z4["fields"][:k4]).all()
+    z5 = np.load(os.path.join(HERE, "golden", "full", "config5_block0.npz"))
+    db, qs, mat = W.protein_config(0)
+    Q = gpu_ctx.upload(qs[:16]); T = gpu_ctx.upload(db)
+    try:
+        hits = gpu_ctx.search_db(Q, T, mat, 24, 3, 1, -1, 2, 2500)
+    finally:
+        Q.free(); T.free()
+    rows = np.stack([hits["score1"], hits["score2"], hits["ref_end1"], hits["read_end1"], hits["ref_end2"]], axis=2).astype(np.int32)
+    assert (rows == z5["first16"]).all()
