@@ -195,6 +195,19 @@ SSW_DEV u32 pk_max3_fr(u32 a, u32 b, u32 c) { return pk_max3_nonneg(a, b, c); }
 #define FR_DEAD 32768
 SSW_DEV u32 fr_pack(int lo, int hi) { return (u32)lo + ((u32)hi << 16); }
 SSW_DEV u32 umax32(u32 a, u32 b) { return a > b ? a : b; }
+/* 0xffff in every half where a > b (unsigned), else 0: saturating difference, min(., 1), x 0xffff -- three packed instructions.  One asm
+   block on the device: written with the builtins, LLVM recognises the idiom at every step (umin(x, 1) -> x != 0, ...) and emits two 16-bit
+   compares, two selects and a permute instead, also through empty-asm barriers */
+#ifdef SSW_SIMT_EMU
+SSW_DEV u32 pk_gt_mask(u32 a, u32 b) { return ((a & 0xffffu) > (b & 0xffffu) ? 0xffffu : 0u) | ((a >> 16) > (b >> 16) ? 0xffff0000u : 0u); }
+#else
+SSW_DEV u32 pk_gt_mask(u32 a, u32 b)
+{
+	u32 r;
+	asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, %3\n\tv_pk_mul_lo_u16 %0, %0, %4" : "=&v"(r) : "v"(a), "v"(b), "v"(0x00010001u), "v"(0xffffffffu));
+	return r;
+}
+#endif
 /* v_pk_add_u16 (wrapping, per half): the frame add where the two halves of a score register come from DIFFERENT profile entries (window
    passes: one target column per query half), so that the packed-sum trick of fr_pack does not apply -- entries are per-half two's complement there */
 SSW_DEV u32 pk_addw(u32 a, u32 b) { return __builtin_bit_cast(u32, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b))); }

@@ -347,6 +347,7 @@ SSW_DEV void db_rows(const unsigned char* lds, u32 pa_next, u32x4 (&sc)[(R + 3) 
                      u32 gO, u32 gE, u32 fl)
 {
 	constexpr int C = (R + 3) / 4, K8 = ChainGeom<R>::K8;
+	u32 pa = pa_next;
 #pragma unroll
 	for (int r = 0; r < R; ++r) {
 		const int seg0 = r < K8 ? 0 : K8, seg1 = r < K8 ? K8 : R;
@@ -377,7 +378,9 @@ SSW_DEV void db_rows(const unsigned char* lds, u32 pa_next, u32x4 (&sc)[(R + 3) 
 		for (int c = 0; c < C; ++c) {
 			const int last = 4 * c + 3 < R - 1 ? 4 * c + 3 : R - 1;      /* the chunk's last row */
 			if (last <= db_done<R>(r) && last > db_done<R>(r - 1)) {
-				const u32 pa = after(pa_next, H[last]);      /* not before the chunk's rows have used the old scores */
+				pa = after(pa, H[last]);      /* not before the chunk's rows have used the old scores.  (CHAINED through one variable: `after`
+				                                 on the untouched pa_next cost a register copy per chunk -- the original stayed live -- i.e. four
+				                                 vector instructions per step of a 20-row lane) */
 				if (c + 1 < C) sc[c] = lds_ld128(lds, pa + 256u * c);
 				else sc[c] = lds_ld_rows<R - 4 * (C - 1)>(lds, pa + 256u * c);
 			}
@@ -396,7 +399,7 @@ SSW_DEV void db_rows(const unsigned char* lds, u32 pa_next, u32x4 (&sc)[(R + 3) 
 template <int R>
 SSW_DEV void db_record(u32 now, u32 pre, int tc, const u32 (&H)[R], u32 (&snap)[R], u32& btc2)
 {
-	const u32 m = opaque(pk_mullo(pk_minu(pk_subu(now, pre), 0x00010001u), 0xffffffffu));      /* 0xffff in the halves that rose */
+	const u32 m = pk_gt_mask(now, pre);      /* 0xffff in the halves that rose */
 	btc2 = bfi32(m, (u32)tc * 0x00010001u, btc2);
 #pragma unroll
 	for (int r = 0; r < R; ++r) snap[r] = bfi32(m, H[r], snap[r]);
