@@ -76,6 +76,18 @@ def kernel_source_id():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
+def measured_issue(key):
+    """SQ_INSTS_VALU / GRBM_GUI_ACTIVE statistics of the dominant fill kernel from the committed PMC passes, for this kernel source only"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round3_traffic.json")) as f:
+            tj = json.load(f)
+        if tj.get("kernel_source_sha16") == kernel_source_id():
+            return (tj.get("valu_issue") or {}).get(key)
+    except Exception:
+        pass
+    return None
+
+
 def measured_traffic(key):
     """HBM bytes per alignment of the dominant kernel from the rocprofv3 PMC passes (scripts/gpu_profile_round3.sh ->
     profiles/round3_traffic.json), only if they were taken on this very kernel source"""
@@ -294,7 +306,8 @@ def bench_dna(args, world, rank, local_rank, dist):
                                     "note": "VALU issue slots of the fill kernel's recurrence: 4 cycles per wave64 instruction (VOP3P always; the 2-cycle 32-bit adds of "
                                             "the column-frame form too when they alternate with VOP3P: profiles/round3_mix_issue_probe.txt), peak = 256 CU x 4 SIMD x 16 x 2.4 GHz; "
                                             "`frac` counts every evaluated cell (padding rows, halo columns), `frac_on_real_cells` only readLen x refLen",
-                                    "fill_gcups_padded": round(acc["fill_cells"] / (acc["fill_ms"] * 1e-3) / 1e9, 1) if acc["fill_ms"] > 0 else 0.0}
+                                    "fill_gcups_padded": round(acc["fill_cells"] / (acc["fill_ms"] * 1e-3) / 1e9, 1) if acc["fill_ms"] > 0 else 0.0,
+                                    "counters": measured_issue("config%d" % args.config) if is_preset else None}
             # PCIe-inclusive rate: one more step with the reads uploaded (and freed) inside it
             if world == 1 and not args.quiet:
                 t1 = time.perf_counter()
@@ -477,7 +490,8 @@ def bench_db(args, world, rank, local_rank, dist):
                                 "measured_peak_probe": round(probe / 1e12, 2), "ops_per_pair_row": ops,
                                 "note": "recurrence instructions only (%.1f per row of a query pair, each a 4-cycle issue slot in this mix: profiles/round3_mix_issue_probe.txt); "
                                         "best-cell tracking and the fused reduction are overhead on top" % ops,
-                                "fill_gcups_padded": round(fill_cells / (fill_ms * 1e-3) / 1e9, 1) if fill_ms > 0 else 0.0}
+                                "fill_gcups_padded": round(fill_cells / (fill_ms * 1e-3) / 1e9, 1) if fill_ms > 0 else 0.0,
+                                "counters": measured_issue("config5") if is_preset else None}
         if world == 1:
             par = {}
             fix = os.path.join(FULL, "config5_block0.npz")

@@ -62,6 +62,20 @@ for cfg, v in sums.items():
 if 2 in sums:
     traffic["config3"] = dict(traffic.get("config2", {}), note="config 3 shares config 2's kernel (k_fill<10,frame>); per-alignment traffic scales with the target length: not measured separately")
     traffic.pop("config3")
+# VALU issue statistics of the dominant fill kernels from the SQ / GRBM passes just written (GRBM_GUI_ACTIVE sums the 8 XCDs)
+import csv
+rows = [r for r in csv.reader(l for l in open(os.path.join(out_dir, "round3_pmc.csv")) if not l.startswith("#"))][1:]
+issue = {}
+for cfg, k in ((2, "k_fill<10, 3>"), (4, "k_chainq<12, false, 3>"), (5, "k_filldb<20, 16, true>")):
+    d = {r[2]: (float(r[5]), float(r[6])) for r in rows if r[0].startswith("pmc%d" % cfg) and k in r[1]}
+    if "SQ_INSTS_VALU" in d and "GRBM_GUI_ACTIVE" in d:
+        valu, (gui, ns) = d["SQ_INSTS_VALU"][0], d["GRBM_GUI_ACTIVE"]
+        issue["config%d" % cfg] = {"kernel": k, "SQ_INSTS_VALU_per_dispatch": valu, "GRBM_GUI_ACTIVE_per_dispatch": gui, "dispatch_ms": ns / 1e6,
+                                  "effective_clock_GHz": round(gui / 8.0 / ns, 3), "cycles_per_valu_instruction": round(gui / 8.0 * 1024.0 / valu, 3),
+                                  "issue_slot_occupancy_at_4_cycles": round(4.0 * valu / (gui / 8.0 * 1024.0), 3)}
+issue["note"] = ("SQ_INSTS_VALU and GRBM_GUI_ACTIVE (summed over the 8 XCDs) of the dominant fill kernel, separate PMC passes (round3_pmc.csv): "
+                 "SIMD-cycles per VALU instruction = 1024 SIMDs x GRBM_GUI_ACTIVE / 8 / SQ_INSTS_VALU; above 1.0 occupancy = some 2-cycle adds pair up")
+traffic["valu_issue"] = issue
 with open(os.path.join(out_dir, "round3_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
 print(json.dumps(traffic, indent=1))
