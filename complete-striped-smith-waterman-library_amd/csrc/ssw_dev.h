@@ -60,9 +60,8 @@ typedef struct {
 	uint32_t* sg16;          /* optional: [npairs][seg_stride] maxima of every aligned group of 16 columns of cm16 ... */
 	uint32_t* sg8;           /* ... and of cm8 (k_reduce_seg scans these instead of the columns) */
 	int64_t seg_stride;
-	int32_t f16;             /* form of the recurrence: 3: column frame (ssw_frame_params in ssw_host.c says when), 6.5 instructions per row of
-	                            which 3 are 32-bit adds; 0: plain int16 with the reference's saturation, 9  (the name is historic: rounds 1-2
-	                            had an f16 form) */
+	int32_t form;            /* form of the recurrence: 3: column frame (ssw_frame_params in ssw_host.c says when), 6.5 instructions per row of
+	                            which 3 are 32-bit adds; 0: plain int16 with the reference's saturation, 9 */
 	int32_t fr_base, fr_kmask;   /* form 3: phi(column) = fr_base + ((step & fr_kmask) + lanes - lane) * gapE */
 } ssw_fill_args;
 
@@ -109,7 +108,7 @@ typedef struct {
 	int32_t chain_best;      /* 1: lanes learn the chain's best every 16 steps (fewer best-cell records); 0: lane-local records only (experiments) */
 	struct ssw_hit_rec* hits;/* optional (takes precedence): compact 16-byte records [query][res_nt] of the streaming search */
 	int32_t* counters;       /* optional: [0] alignments decided under 16-bit rules, [1] under 8-bit rules, [2] workgroups repeated in the int16 form */
-	int32_t f16;             /* 1: column-frame form of the recurrence (fr_base / fr_kmask as in ssw_fill_args), 0: plain int16 with the two-row maximum */
+	int32_t form;            /* 1: column-frame form of the recurrence (fr_base / fr_kmask as in ssw_fill_args), 0: plain int16 with the two-row maximum */
 	int32_t fr_base, fr_kmask;
 } ssw_filldb_args;
 

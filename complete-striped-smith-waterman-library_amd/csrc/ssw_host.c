@@ -567,7 +567,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 					fa.tfirst = tfirst + t0; fa.res_nt = nt; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off; fa.pairs = bpairs + B->first_pair + p0;
 					fa.npairs = B->npairs - p0 < ppl ? B->npairs - p0 : (int32_t)ppl; fa.mat = d_mat; fa.n = n; fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.cm16 = d_cm16; fa.cm8 = d_cm8;
 					fa.cm_stride = stride; fa.maskLen = prm->maskLen; fa.bias = bias; fa.score_size = prm->score_size; fa.res = d_res; fa.out = d_out; fa.counters = d_cnt;
-					fa.hits = d_hits; fa.f16 = fr; fa.fr_base = fr_base; fa.fr_kmask = fr_kmask;
+					fa.hits = d_hits; fa.form = fr; fa.fr_base = fr_base; fa.fr_kmask = fr_kmask;
 					{ const char* e = getenv("SSW_GPU_DB_CHAIN_BEST"); fa.chain_best = !(e && e[0] == '0'); }
 					if (ssw_shim_launch_filldb(B->R, &fa, st)) { fail(c, "filldb launch failed: %s", ssw_shim_last_error()); goto done; }
 					int64_t lc = 0;
@@ -942,11 +942,10 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 					fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.tile = tile; fa.halo = halo; fa.ntiles = ntiles;
 					fa.bpp = (ntiles + 15) / 16; fa.cm16 = d_cm16; fa.cm8 = d_cm8; fa.cm_stride = stride;
 					fa.sg16 = d_sg16; fa.sg8 = d_sg8; fa.seg_stride = seg_stride;
-					/* no cell of this bucket can score 2048 or more -> f16 form of the recurrence (8 instead of 9 instructions per cell) */
 					/* column-frame form of the recurrence whenever the bucket's scores leave room for the frame offsets below 31744 (no cell of
 					   the bucket scores more than its padded length x max(mat)); else plain int16 */
-					fa.f16 = 0; fa.fr_base = 0; fa.fr_kmask = 0;
-					if (fill_form != 0 && ssw_frame_params((int64_t)16 * B->R * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, minmat, 16, &fa.fr_base, &fa.fr_kmask)) fa.f16 = 3;
+					fa.form = 0; fa.fr_base = 0; fa.fr_kmask = 0;
+					if (fill_form != 0 && ssw_frame_params((int64_t)16 * B->R * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, minmat, 16, &fa.fr_base, &fa.fr_kmask)) fa.form = 3;
 					int xform = 0;
 					int32_t xfr_base = 0, xfr_kmask = 0;
 					if (fill_form != 0 && B->lanes == 64 &&
@@ -983,10 +982,10 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 						const int64_t lc = cols * (int64_t)(B->lanes * B->R * B->strips) * 2 * np;
 						c->tm.fill_cells += lc;
 						char nm[48];
-						if (!use_x) snprintf(nm, sizeof nm, "k_fill<%d,%s>", B->R, fa.f16 == 3 ? "frame" : "int16");
+						if (!use_x) snprintf(nm, sizeof nm, "k_fill<%d,%s>", B->R, fa.form == 3 ? "frame" : "int16");
 						else if (B->lanes == 64) snprintf(nm, sizeof nm, "k_chainq<%d,%s> x %d strips", B->R, xform == 3 ? "frame" : "int16", B->strips);
 						else snprintf(nm, sizeof nm, "k_chainx<%d,16 lanes> x %d strips", B->R, B->strips);
-						note_fill_kernel(c, lc, &best_fill_cells, nm, !use_x ? (fa.f16 == 3 ? 6.5 : 9.0) : (B->lanes == 64 && xform == 3 ? 6.5 : 9.0), B->R, B->strips);
+						note_fill_kernel(c, lc, &best_fill_cells, nm, !use_x ? (fa.form == 3 ? 6.5 : 9.0) : (B->lanes == 64 && xform == 3 ? 6.5 : 9.0), B->R, B->strips);
 					}
 					ssw_reduce_args ra;
 					ra.cm16 = d_cm16; ra.cm8 = d_cm8; ra.cm_stride = stride; ra.refLen = refLen; ra.pairs = fa.pairs; ra.npairs = np;

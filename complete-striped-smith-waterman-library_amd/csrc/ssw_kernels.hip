@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
  * grid = npairs * ceil(ntl / NCH) workgroups of NCH chains (16 * NCH threads: the profile of a pair -- 25 residues x R rows x
  * 64 bytes for proteins -- is what limits the wavefronts per CU, and more chains per workgroup share it).
  *
- * a.f16 != 0: the column-frame form of the recurrence (chain_rows_fr), else plain int16 with the two-row column maximum.
+ * a.form != 0: the column-frame form of the recurrence (chain_rows_fr), else plain int16 with the two-row column maximum.
  * ================================================================================================ */
 #define DB_OUT_RING 32                                   /* finished column maxima parked per chain (k_fill keeps 64) */
 #define DB_RING_BYTES 192                                /* target ring: 64 entries + 32 mirrored (entries are read two steps ahead) */
@@ -2676,7 +2676,7 @@ extern "C" int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream)
 	if (grid <= 0) return 0;
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + 16 * CHAIN_BYTES; \
-		if (args.f16 == 3) SSW_LAUNCH((k_fill<r, 3>), ssw_fill_args, args, grid, 256, ldsb, stream); \
+		if (args.form == 3) SSW_LAUNCH((k_fill<r, 3>), ssw_fill_args, args, grid, 256, ldsb, stream); \
 		else SSW_LAUNCH((k_fill<r, 0>), ssw_fill_args, args, grid, 256, ldsb, stream); } break;
 		FOR_EACH_R(X)
 #undef X
@@ -2697,7 +2697,7 @@ extern "C" int ssw_shim_launch_filldb(int R, const ssw_filldb_args* a, void* str
 	if (grid <= 0) return 0;
 	switch (R) {
 #define X(r) case r: { const size_t ldsb = (size_t)(args.n + 1) * ChainGeom<r>::PSTRIDE + (size_t)nch * DB_CHAIN_BYTES + 16; \
-		if (args.f16) SSW_LAUNCH((k_filldb<r, SSW_DB_NCH, true>), ssw_filldb_args, args, grid, 16 * SSW_DB_NCH, ldsb, stream); \
+		if (args.form) SSW_LAUNCH((k_filldb<r, SSW_DB_NCH, true>), ssw_filldb_args, args, grid, 16 * SSW_DB_NCH, ldsb, stream); \
 		else SSW_LAUNCH((k_filldb<r, SSW_DB_NCH, false>), ssw_filldb_args, args, grid, 16 * SSW_DB_NCH, ldsb, stream); } break;
 		FOR_EACH_R(X)
 		FOR_EACH_DBR_LONG(X)
