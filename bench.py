@@ -232,6 +232,16 @@ def bench_dna(args, world, rank, local_rank, dist):
         def step(Qx=None):
             return ctx.align_batch(Qx or Q, T, mat, 5, args.gap_open, args.gap_extend, flag, 0, 0, p["mask_len"], 2, want_cigar=want_cigar)
 
+    closed = []
+
+    def cleanup():
+        if not closed:
+            closed.append(1)
+            if pool is not None:
+                pool.close()
+            else:
+                Q.free(); T.free(); ctx.close()
+
     def barrier():
         # align_batch() returns only after its stream is synchronised and the results are on the host, so every rank is
         # idle here; the barrier aligns the ranks' clocks around the timed region.
@@ -380,6 +390,7 @@ def bench_dna(args, world, rank, local_rank, dist):
                                        "kind": "port", "sample": "%d reads, scalar lane-model oracle (oracle/_ref not shipped)" % ns}
                 out.setdefault("parity", {"sample": ns, "mismatching_alignments": mism})
         if not args.quiet:
+            cleanup()        # this config's device buffers go first: the `also` runs get the whole device, like a run of their own
             attach_also(args, out, world)
             print(json.dumps(out))
             sys.stdout.flush()
@@ -389,10 +400,7 @@ def bench_dna(args, world, rank, local_rank, dist):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if pool is not None:
-        pool.close()
-    else:
-        Q.free(); T.free(); ctx.close()
+    cleanup()
     return out, res
 
 

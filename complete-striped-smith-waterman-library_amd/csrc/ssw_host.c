@@ -119,8 +119,11 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
 		return 0;
 	}
 	const char* e = getenv("SSW_GPU_CM_BUDGET_MB");
-	c->cm_budget = e ? (size_t)atoll(e) << 20 : (size_t)64 << 30;
-	if (!e) { size_t fr = ssw_shim_mem_free_bytes(); if (fr && c->cm_budget > fr / 2) c->cm_budget = fr / 2; }
+	/* scratch budget (column maxima, boundary records, traceback scratch): sized for 288 GB of HBM -- two thirds of what is free now, at most
+	   200 GiB (config 2 then needs 2 fill launches per 100k reads instead of 6: +1.2 %); a context that finds the device shared after all
+	   halves it when an allocation fails (SSW_ALLOC_RETRY) */
+	c->cm_budget = e ? (size_t)atoll(e) << 20 : (size_t)200 << 30;
+	if (!e) { size_t fr = ssw_shim_mem_free_bytes(); if (fr && c->cm_budget > fr / 3 * 2) c->cm_budget = fr / 3 * 2; }
 	return c;
 }
 
@@ -143,8 +146,8 @@ int ssw_gpu_set_budget(ssw_gpu_ctx* c, size_t bytes)
 	if (__atomic_load_n(&c->busy, __ATOMIC_ACQUIRE)) return SSW_GPU_BUSY;
 	if (bytes == 0) {
 		ssw_shim_set_device(c->device);
-		bytes = (size_t)64 << 30;
-		size_t fr = ssw_shim_mem_free_bytes(); if (fr && bytes > fr / 2) bytes = fr / 2;
+		bytes = (size_t)200 << 30;
+		size_t fr = ssw_shim_mem_free_bytes(); if (fr && bytes > fr / 3 * 2) bytes = fr / 3 * 2;
 	}
 	if (bytes < ((size_t)1 << 20)) bytes = (size_t)1 << 20;
 	c->cm_budget = bytes;
@@ -864,6 +867,10 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 			for (int b = 0; b < nb; ++b) {
 				const bucket* B = &bk[b];
 				if (qdone[order[B->first_q]]) continue;     /* bucket already answered by the database-search path */
+				/* The scratch budget is sized for a device this context has to itself (ssw_gpu_open).  When the device turns out to be
+				   shared -- another rank or pool worker took its share first -- an allocation fails: halve the budget, size again. */
+#define SSW_ALLOC_RETRY() do { if (c->cm_budget > ((size_t)512 << 20)) { c->cm_budget /= 2; c->err[0] = 0; goto size_again; } goto done; } while (0)
+size_again:;
 				const int32_t P = B->P16, halo_full = halo_for(P, maxmat, prm->gapE);
 				const int use_x = B->use_x;     /* long queries: strip kernel, one job per chain */
 				const int gran = use_x ? 1 : 16;     /* k_fill: one workgroup = 16 tiles of one pair */
@@ -911,14 +918,14 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 				if (use_x) {
 					d_bnd = (uint32_t*)ensure(c, &c->bnd, (size_t)(16 * maxcols * ntiles * chunk));
 					d_cand = (int32_t*)ensure(c, &c->cand, (size_t)(32 * ntiles * chunk));   /* 2 halves x 4 ints per job */
-					if (!d_bnd || !d_cand) goto done;
+					if (!d_bnd || !d_cand) SSW_ALLOC_RETRY();
 					{ const char* nt_ = getenv("SSW_GPU_NO_TRACK"); if (nt_ && nt_[0] == '1') d_cand = 0; }   /* diagnostic: always run the locate pass */
 				}
 				uint32_t* d_cmA16 = (uint32_t*)ensure(c, &c->cm16, (size_t)(4 * stride * chunk));
 				uint32_t* d_cmA8 = (uint32_t*)ensure(c, &c->cm8, (size_t)(4 * stride * chunk));
 				uint32_t* d_cmB16 = dbl ? (uint32_t*)ensure(c, &c->cm16b, (size_t)(4 * stride * chunk)) : d_cmA16;
 				uint32_t* d_cmB8 = dbl ? (uint32_t*)ensure(c, &c->cm8b, (size_t)(4 * stride * chunk)) : d_cmA8;
-				if (!d_cmA16 || !d_cmA8 || !d_cmB16 || !d_cmB8) goto done;
+				if (!d_cmA16 || !d_cmA8 || !d_cmB16 || !d_cmB8) SSW_ALLOC_RETRY();
 				/* short-query buckets: k_fill also leaves the maxima of 16-column groups, which is all the reduction reads */
 				const int64_t seg_stride = stride / 16 + 1;
 				uint32_t *d_sg16 = 0, *d_sg8 = 0;
@@ -927,7 +934,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 					if (!use_x && !dbl && !(e && e[0] == '0')) {
 						d_sg16 = (uint32_t*)ensure(c, &c->sg16, (size_t)(4 * seg_stride * chunk));
 						d_sg8 = (uint32_t*)ensure(c, &c->sg8, (size_t)(4 * seg_stride * chunk));
-						if (!d_sg16 || !d_sg8) goto done;
+						if (!d_sg16 || !d_sg8) SSW_ALLOC_RETRY();
 					}
 				}
 				int launch_i = 0;
@@ -1136,7 +1143,11 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 					int64_t* hoff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)npend * 2 + 2));
 					int32_t* hall = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)npend);
 					if (!hoff || !hall) { free(hoff); free(hall); free(nextp); fail(c, "out of host memory%s", ""); trace_ok = 0; break; }
-					const int64_t budget = (int64_t)c->cm_budget * 2;
+					int64_t budget = (int64_t)c->cm_budget * 2;
+					{   /* ... but not more than the device has left now (the fill's buffers stay with the context) */
+						const int64_t room = (int64_t)c->scratch.cap + (int64_t)(ssw_shim_mem_free_bytes() / 5 * 4);
+						if (room > ((int64_t)1 << 30) && budget > room) budget = room;
+					}
 					for (int32_t k = 0; k < npend; ++k) lst[k] = pend[k].q;
 					int64_t* d_soff = (int64_t*)ensure(c, &c->goff, sizeof(int64_t) * ((size_t)npend * 2 + 2));
 					if (!d_soff || ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)npend, c->stream)) { trace_ok = 0; free(hoff); free(hall); free(nextp); break; }

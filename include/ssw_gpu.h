@@ -120,8 +120,9 @@ int ssw_gpu_last_timing_sized(const ssw_gpu_ctx* ctx, void* out, size_t out_size
 #define SSW_GPU_BUSY (-2)
 const char* ssw_gpu_strerror(int rc);
 
-/* Scratch budget of a context in bytes (column maxima, boundary records, traceback scratch): default min(64 GiB, half of the HBM
-   that was free when the context was opened), or SSW_GPU_CM_BUDGET_MB.  Contexts sharing one device (several ranks or pool workers
+/* Scratch budget of a context in bytes (column maxima, boundary records, traceback scratch): default min(200 GiB, two thirds of the HBM
+   that was free when the context was opened), or SSW_GPU_CM_BUDGET_MB; halved on the spot when an allocation fails because the device
+   is shared after all.  Contexts sharing one device (several ranks or pool workers
    per GPU) should each get their share: ssw_gpu_pool_open does that for its workers.  0 = recompute the default now. */
 int ssw_gpu_set_budget(ssw_gpu_ctx* ctx, size_t bytes);
 size_t ssw_gpu_get_budget(const ssw_gpu_ctx* ctx);
