@@ -139,6 +139,11 @@ def parse_args(argv=None):
     return a
 
 
+def own_device(world, lib):
+    """every rank of this run has a GPU of its own (N <= visible devices): the contexts may size their scratch for the whole HBM"""
+    return world <= max(1, lib.ssw_gpu_device_count()) and os.environ.get("SSW_BENCH_SHARED_DEVICE", "0") != "1"
+
+
 def init_dist():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -219,6 +224,7 @@ def bench_dna(args, world, rank, local_rank, dist):
             return pool.align(None, mat, 5, args.gap_open, args.gap_extend, flag, 0, 0, p["mask_len"], 2, want_cigar=want_cigar, packed=(reads.reshape(-1), off))
     else:
         ctx = ssw_amd.Context(local_rank % ndev, lib)
+        budget = ctx.set_exclusive() if own_device(world, lib) else int(lib.ssw_gpu_get_budget(ctx.h))
 
         def upload_reads():
             qh = lib.ssw_gpu_seqs_upload(ctx.h, reads.ctypes.data_as(C.POINTER(C.c_int8)), off.ctypes.data_as(C.POINTER(C.c_int64)), nreads)
@@ -274,6 +280,8 @@ def bench_dna(args, world, rank, local_rank, dist):
                "config": {"workload": "%s; %d/-%d/%d/%d, score_size 2, flag %d" % (name, args.match, args.mismatch, args.gap_open, args.gap_extend, flag),
                           "baseline_config": args.config, "reads_per_gpu": nreads, "read_len": rlen, "ref_len": p["ref_len"],
                           "sharding": "read block r on rank r, target replicated, no collective"}}
+        if pool is None:
+            out["config"]["scratch_budget_gib"] = round(budget / 2.0 ** 30, 1)
         if pool is not None:
             out["config"]["pool_workers"] = args.pool
             out["config"]["note"] = "in-library per-GPU work queues (ssw_gpu_pool): reads on the host, blocks uploaded by the workers inside the step"
@@ -415,6 +423,8 @@ def bench_db(args, world, rank, local_rank, dist):
     if lib.ssw_gpu_device_count() < 1:
         raise RuntimeError("bench.py: no HIP device visible; libssw.so has no CPU path")
     ctx = ssw_amd.Context(local_rank % max(1, lib.ssw_gpu_device_count()), lib)
+    if own_device(world, lib):
+        ctx.set_exclusive()
     nq = args.reads if args.reads is not None else 50_000
     nt = args.db_targets if args.db_targets is not None else 10_000
     db, qs, mat = W.protein_config(rank, queries=nq, db_entries=nt)

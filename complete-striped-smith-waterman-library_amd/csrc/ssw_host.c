@@ -51,6 +51,7 @@ struct ssw_gpu_ctx {
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d, *ev_db;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
 	int busy;                           /* a batch call is running on this context (one call at a time per context) */
+	int budget_shrunk;                  /* an allocation failed once: the device is shared, the budget was cut (SSW_ALLOC_RETRY) */
 	const int32_t* queue_err;           /* device error word of the last work-queue launch, not yet checked */
 	void* hits_d[2]; void* hits_h[2]; size_t hits_cap;     /* streamed database search: two device + two page-locked host buffers, kept between calls */
 };
@@ -119,11 +120,13 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
 		return 0;
 	}
 	const char* e = getenv("SSW_GPU_CM_BUDGET_MB");
-	/* scratch budget (column maxima, boundary records, traceback scratch): sized for 288 GB of HBM -- two thirds of what is free now, at most
-	   200 GiB (config 2 then needs 2 fill launches per 100k reads instead of 6: +1.2 %); a context that finds the device shared after all
-	   halves it when an allocation fails (SSW_ALLOC_RETRY) */
-	c->cm_budget = e ? (size_t)atoll(e) << 20 : (size_t)200 << 30;
-	if (!e) { size_t fr = ssw_shim_mem_free_bytes(); if (fr && c->cm_budget > fr / 3 * 2) c->cm_budget = fr / 3 * 2; }
+	/* scratch budget (column maxima, boundary records, traceback scratch).  The DEFAULT assumes nothing about who else uses the device: half
+	   of what is free now, at most 64 GiB -- several processes per GPU (ranks, single-pair callers) then still fit, and HIP does not refuse
+	   an over-subscribing hipMalloc of another process: the failure would only show at a kernel launch.  A caller that has the device to
+	   itself says so with ssw_gpu_set_budget_exclusive (bench.py does when every rank has its own GPU): 288 GB then hold 3 fill launches
+	   per 100k reads of config 2 instead of 6. */
+	c->cm_budget = e ? (size_t)atoll(e) << 20 : (size_t)64 << 30;
+	if (!e) { size_t fr = ssw_shim_mem_free_bytes(); if (fr && c->cm_budget > fr / 2) c->cm_budget = fr / 2; }
 	return c;
 }
 
@@ -146,14 +149,25 @@ int ssw_gpu_set_budget(ssw_gpu_ctx* c, size_t bytes)
 	if (__atomic_load_n(&c->busy, __ATOMIC_ACQUIRE)) return SSW_GPU_BUSY;
 	if (bytes == 0) {
 		ssw_shim_set_device(c->device);
-		bytes = (size_t)200 << 30;
-		size_t fr = ssw_shim_mem_free_bytes(); if (fr && bytes > fr / 3 * 2) bytes = fr / 3 * 2;
+		bytes = (size_t)64 << 30;
+		size_t fr = ssw_shim_mem_free_bytes(); if (fr && bytes > fr / 2) bytes = fr / 2;
 	}
 	if (bytes < ((size_t)1 << 20)) bytes = (size_t)1 << 20;
 	c->cm_budget = bytes;
 	return 0;
 }
 size_t ssw_gpu_get_budget(const ssw_gpu_ctx* c) { return c ? c->cm_budget : 0; }
+
+/* "This context has its device to itself": budget = min(200 GiB, 60 % of the free HBM).  Sized for the 288 GB of an MI355X. */
+int ssw_gpu_set_budget_exclusive(ssw_gpu_ctx* c)
+{
+	if (!c) return -1;
+	ssw_shim_set_device(c->device);
+	size_t bytes = (size_t)200 << 30;
+	const size_t fr = ssw_shim_mem_free_bytes();
+	if (fr && bytes > fr / 5 * 3) bytes = fr / 5 * 3;
+	return ssw_gpu_set_budget(c, bytes);
+}
 
 void ssw_gpu_close(ssw_gpu_ctx* c)
 {
@@ -867,9 +881,10 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 			for (int b = 0; b < nb; ++b) {
 				const bucket* B = &bk[b];
 				if (qdone[order[B->first_q]]) continue;     /* bucket already answered by the database-search path */
-				/* The scratch budget is sized for a device this context has to itself (ssw_gpu_open).  When the device turns out to be
-				   shared -- another rank or pool worker took its share first -- an allocation fails: halve the budget, size again. */
-#define SSW_ALLOC_RETRY() do { if (c->cm_budget > ((size_t)512 << 20)) { c->cm_budget /= 2; c->err[0] = 0; goto size_again; } goto done; } while (0)
+				/* An allocation that fails although it is within the budget (contexts of ONE process sharing a device; across processes HIP
+				   over-subscribes silently): shrink the budget and size again -- to a quarter the first time, a budget that only just fits
+				   leaves nothing for the rest of the call, then by halves. */
+#define SSW_ALLOC_RETRY() do { if (c->cm_budget > ((size_t)512 << 20)) { c->cm_budget /= c->budget_shrunk ? 2 : 4; c->budget_shrunk = 1; c->err[0] = 0; goto size_again; } goto done; } while (0)
 size_again:;
 				const int32_t P = B->P16, halo_full = halo_for(P, maxmat, prm->gapE);
 				const int use_x = B->use_x;     /* long queries: strip kernel, one job per chain */

@@ -115,6 +115,8 @@ def load(path=None):
     L.ssw_gpu_set_budget.restype = C.c_int
     L.ssw_gpu_get_budget.argtypes = [C.c_void_p]
     L.ssw_gpu_get_budget.restype = C.c_size_t
+    L.ssw_gpu_set_budget_exclusive.argtypes = [C.c_void_p]
+    L.ssw_gpu_set_budget_exclusive.restype = C.c_int
     L.ssw_gpu_pool_budget.argtypes = [C.c_void_p, C.c_int]
     L.ssw_gpu_pool_budget.restype = C.c_size_t
     L.ssw_gpu_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
@@ -222,6 +224,11 @@ class Context(object):
 
     def error(self):
         return self.lib.ssw_gpu_last_error(self.h).decode()
+
+    def set_exclusive(self):
+        """this context has its device to itself: scratch budget sized for the whole HBM (ssw_gpu_set_budget_exclusive) -> bytes"""
+        self.lib.ssw_gpu_set_budget_exclusive(self.h)
+        return int(self.lib.ssw_gpu_get_budget(self.h))
 
     def upload(self, seqs):
         return Seqs(self, seqs)

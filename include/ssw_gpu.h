@@ -120,11 +120,15 @@ int ssw_gpu_last_timing_sized(const ssw_gpu_ctx* ctx, void* out, size_t out_size
 #define SSW_GPU_BUSY (-2)
 const char* ssw_gpu_strerror(int rc);
 
-/* Scratch budget of a context in bytes (column maxima, boundary records, traceback scratch): default min(200 GiB, two thirds of the HBM
-   that was free when the context was opened), or SSW_GPU_CM_BUDGET_MB; halved on the spot when an allocation fails because the device
-   is shared after all.  Contexts sharing one device (several ranks or pool workers
-   per GPU) should each get their share: ssw_gpu_pool_open does that for its workers.  0 = recompute the default now. */
+/* Scratch budget of a context in bytes (column maxima, boundary records, traceback scratch).  Default: min(64 GiB, half of the HBM that
+   was free when the context was opened), or SSW_GPU_CM_BUDGET_MB -- it assumes nothing about other users of the device (HIP does not
+   refuse another process's over-subscribing allocation; the failure would only show at a kernel launch).  Contexts sharing a device
+   (several ranks or pool workers per GPU) should each get their share: ssw_gpu_pool_open does that for its workers.
+   ssw_gpu_set_budget(ctx, 0) recomputes the default; ssw_gpu_set_budget_exclusive(ctx) is the caller's statement that the context
+   has the device to itself: min(200 GiB, 60 % of the free HBM) -- the 288 GB of an MI355X then hold 3 fill launches per 100 000
+   150-bp reads against 1 Mb instead of 6 (+1 %). */
 int ssw_gpu_set_budget(ssw_gpu_ctx* ctx, size_t bytes);
+int ssw_gpu_set_budget_exclusive(ssw_gpu_ctx* ctx);
 size_t ssw_gpu_get_budget(const ssw_gpu_ctx* ctx);
 
 /*
