@@ -86,37 +86,18 @@ SSW_DEV void build_profile(unsigned char* lds, u32 base, int first, int nthreads
 /* column-frame form of rows [R0, R1) (lanes.h): 3 plain 32-bit adds + 3.5 packed maxima per row.  c1 = gapO - gapE (packed),
    fl = phi(column + 1): the floor that keeps E at "0" or above.
      h = max3(d + s', E, F)        t = h - c1        E' = max3(E, t, fl)        F' = max(F, t) - gapE        cm = max3(cm, h_r, h_r+1) */
-#ifndef FR_HOIST_ADDS      /* 1: the diag + score adds of a lane's rows as ONE run ahead of the maxima (experiment: runs of 2-cycle adds issue faster) */
-#define FR_HOIST_ADDS 0
-#endif
-template <int R, int R0, int R1>
+/* OPEN: the last row leaves f BEFORE its "- gapE": the lane below subtracts while it takes the value over (xl_row_shr1_sub_keep) */
+template <int R, int R0, int R1, bool OPEN = false>
 SSW_DEV void chain_rows_fr(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32& d, u32& f, u32& cm, u32 c1, u32 gapE2, u32 fl)
 {
-#if FR_HOIST_ADDS
-	u32 x[R1 - R0 > 0 ? R1 - R0 : 1];
-#pragma unroll
-	for (int r = R0; r < R1; ++r) x[r - R0] = (r == R0 ? d : H[r - 1]) + sc[r >> 2][r & 3];
-	if (R1 > R0) d = H[R1 - 1];
-	sched_fence();
-#pragma unroll
-	for (int r = R0; r < R1; ++r) {
-		const u32 h = pk_max3_fr(x[r - R0], E[r], f);
-		const u32 t = h - c1;
-		E[r] = pk_max3_fr(E[r], t, fl);
-		f = pk_max(f, t) - gapE2;
-		if (((r - R0) & 1) == 1) cm = pk_max3_fr(cm, H[r - 1 >= 0 ? r - 1 : 0], h);
-		else if (r == R1 - 1) cm = pk_max(cm, h);
-		H[r] = h;
-	}
-	return;
-#endif
 #pragma unroll
 	for (int r = R0; r < R1; ++r) {
 		const u32 hold = H[r];
 		const u32 h = pk_max3_fr(d + sc[r >> 2][r & 3], E[r], f);
 		const u32 t = h - c1;
 		E[r] = pk_max3_fr(E[r], t, fl);
-		f = pk_max(f, t) - gapE2;
+		f = pk_max(f, t);
+		if (!(OPEN && r == R1 - 1)) f -= gapE2;
 		if (((r - R0) & 1) == 1) cm = pk_max3_fr(cm, H[r - 1 >= 0 ? r - 1 : 0], h);      /* H[r-1] was just written: this pair's first row */
 		else if (r == R1 - 1) cm = pk_max(cm, h);                                         /* odd row left over */
 		H[r] = h;
@@ -125,7 +106,7 @@ SSW_DEV void chain_rows_fr(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32& d, u3
 }
 
 /* FORM 0: plain int16 with the reference's saturation, 9 instructions per row (buckets whose scores may pass the frame form's range);
-   3: column frame (scores + frame offsets < 31744), 6.5 of which 3 are 32-bit adds (gapO2 then carries gapO - gapE) */
+   3: column frame (scores + frame offsets < 31744), 6.5 of which 3 are 32-bit adds (gapO2 then carries gapO - gapE); f comes back OPEN (chain_rows_fr) */
 template <int R, bool TRACK8, int FORM = 0>
 SSW_DEV void chain_rows(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f, u32& cm, u32& ck,
                         u32 gapO2, u32 gapE2, u32 fl = 0)
@@ -135,8 +116,8 @@ SSW_DEV void chain_rows(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32 d, u32& f
 		if (TRACK8) {
 			chain_rows_fr<R, 0, K8>(sc, H, E, d, f, cm, gapO2, gapE2, fl);
 			ck = cm;
-			chain_rows_fr<R, K8, R>(sc, H, E, d, f, cm, gapO2, gapE2, fl);
-		} else chain_rows_fr<R, 0, R>(sc, H, E, d, f, cm, gapO2, gapE2, fl);
+			chain_rows_fr<R, K8, R, true>(sc, H, E, d, f, cm, gapO2, gapE2, fl);
+		} else chain_rows_fr<R, 0, R, true>(sc, H, E, d, f, cm, gapO2, gapE2, fl);
 		return;
 	}
 #pragma unroll
@@ -254,10 +235,12 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
 	u32 H[R], E[R];
 #pragma unroll
 	for (int r = 0; r < R; ++r) { H[r] = zero0; E[r] = FR ? fl : 0u; }
-	u32 Hlast = zero0, Fout = zero0, cmout = zero0, ck = 0, hsave = zero0;
+	u32 Hlast = zero0, Fout = FR ? zero0 + a.gapE2 : zero0, cmout = zero0, ck = 0, hsave = zero0;      /* (frame form: Fout is OPEN, one gapE above what the next lane takes) */
 	const u32 lane_prof = (u32)l16 * 16u;
 	const u32 gO = FR ? a.gapO2 - a.gapE2 : a.gapO2;      /* frame form: gapO - gapE */
 	const u32 gE = a.gapE2;
+	const u32 gEv = opaque(gE);                             /* in a vector register: the second operand of a DPP instruction cannot be scalar */
+	u32 fin = 0;                                            /* frame form: the F a lane takes over; lane 0 keeps this zero (below every frame value) */
 
 	for (int s0 = 0; s0 < nsteps; s0 += 16) {
 		if (FR && s0 > 0 && (s0 & a.fr_kmask) == 0) {   /* renormalisation: every frame value drops by K x gapE */
@@ -294,9 +277,12 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
 			u32x4 sc[C];
 #pragma unroll
 			for (int c = 0; c < C; ++c) sc[c] = lds_ld128(lds, paddr + 256u * c);
-			u32 hin = xl_row_shr1_zero(Hlast);
-			if (FR) { hin = umax32(hin, fl); fl += gE; }      /* lane 0: the zero that row_shr fills in becomes phi(column) -- a plain u32 max is exact here, both halves of every H are >= phi */
-			u32 f = xl_row_shr1_zero(Fout);
+			u32 hin, f;
+			if (FR) {   /* two hand-offs fused with the arithmetic behind them (lanes.h) */
+				hin = xl_row_shr1_umax(Hlast, fl); fl += gE;      /* lane 0: the zero that row_shr fills in becomes phi(column) -- a plain u32 max is exact here, both halves of every H are >= phi */
+				xl_row_shr1_sub_keep(fin, Fout, gEv);              /* the last row's "- gapE" happens here (Fout is OPEN); lane 0 keeps its zero */
+				f = fin;
+			} else { hin = xl_row_shr1_zero(Hlast); f = xl_row_shr1_zero(Fout); }
 			u32 cm = xl_row_shr1_zero(cmout);      /* this column's maximum of the rows above */
 			chain_rows<R, true, FORM>(sc, H, E, hsave, f, cm, ck, gO, gE, fl);
 			hsave = hin; Hlast = H[R - 1]; Fout = f; cmout = cm;
@@ -361,7 +347,8 @@ SSW_DEV void db_rows(const unsigned char* lds, u32 pa_next, u32x4 (&sc)[(R + 3) 
 				h = pk_max3_fr(d + sc[r >> 2][r & 3], E[r], f);
 				const u32 t = h - gO;
 				E[r] = pk_max3_fr(E[r], t, fl);
-				f = pk_max(f, t) - gE;
+				f = pk_max(f, t);
+				if (r != R - 1) f -= gE;      /* the last row leaves f OPEN: the lane below subtracts while it takes it over (k_fill) */
 			} else {
 				const u32 h0 = pk_max(pk_adds(d, sc[r >> 2][r & 3]), E[r]);
 				h = pk_max(h0, f);
@@ -464,12 +451,14 @@ SSW_DEV void filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 	u32 H[R], E[R], snap[R];                        /* snap: per query half, the lane's H column at its last record (db_record) */
 #pragma unroll
 	for (int r = 0; r < R; ++r) { H[r] = zero0; E[r] = FR ? fl : 0u; snap[r] = 0; }
-	u32 Hlast = zero0, Fout = zero0, cmout = zero0, ck = 0, hsave = zero0;
+	u32 Hlast = zero0, Fout = FR ? zero0 + a.gapE2 : zero0, cmout = zero0, ck = 0, hsave = zero0;      /* (frame form: Fout is OPEN) */
 	u32 best = zero0;                               /* packed: highest running column maximum this lane has seen */
 	u32 btc2 = 0xffffffffu;                         /* packed: column of the last record per half (the host keeps targets below 65000 residues here) */
 	const u32 lane_prof = (u32)l16 * 16u;
 	const u32 gO = FR ? a.gapO2 - a.gapE2 : a.gapO2;
 	const u32 gE = a.gapE2;
+	const u32 gEv = opaque(gE);
+	u32 fin = 0;                                    /* frame form: the F a lane takes over; lane 0 keeps this zero */
 
 	/* software pipeline of the LDS reads (three or four wavefronts per SIMD do not hide a ring entry -> address -> scores round
 	   trip per step): the ring entry of step s+2 is requested before the rows of step s run, the score chunks of step s+1 while
@@ -528,9 +517,12 @@ SSW_DEV void filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 		for (int j = 0; j < 16; ++j) {
 			const int tc = s0 + j - l16;
 			const u32 pa_next = lds_ld16(lds, rp + 2u * (j + 2));      /* the ring entry of step s + 2 */
-			u32 hin = xl_row_shr1_zero(Hlast);
-			if (FR) { hin = umax32(hin, fl); fl += gE; best += gE; }      /* lane 0: the zero row_shr fills in becomes phi(column); the record follows the lane's frame */
-			u32 f = xl_row_shr1_zero(Fout);
+			u32 hin, f;
+			if (FR) {   /* two hand-offs fused with the arithmetic behind them (k_fill) */
+				hin = xl_row_shr1_umax(Hlast, fl); fl += gE; best += gE;      /* lane 0: the zero row_shr fills in becomes phi(column); the record follows the lane's frame */
+				xl_row_shr1_sub_keep(fin, Fout, gEv);
+				f = fin;
+			} else { hin = xl_row_shr1_zero(Hlast); f = xl_row_shr1_zero(Fout); }
 			u32 cm = xl_row_shr1_zero(cmout);      /* this column's maximum of the rows above (lane 0 starts a new column with 0) */
 			/* best cell: `pre` = the lane's running record and the rows above in this column; only the lane whose OWN rows
 			   beat it -- the lane holding the new record cell, not every lane below -- takes the branch further down */

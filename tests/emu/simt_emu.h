@@ -101,6 +101,17 @@ SSW_DEV u32 xl_row_shr1_keep(u32 keep, u32 v)
 	int l = emu::cur->lane;
 	return emu::exchange(v, l - 1, (l & 15) != 0, keep);
 }
+SSW_DEV u32 xl_row_shr1_umax(u32 v, u32 b)
+{
+	const u32 t = xl_row_shr1_zero(v);
+	return t > b ? t : b;
+}
+SSW_DEV void xl_row_shr1_sub_keep(u32& dst, u32 v, u32 b)
+{
+	int l = emu::cur->lane;
+	const u32 t = emu::exchange(v, l - 1, (l & 15) != 0, 0u);
+	if ((l & 15) != 0) dst = t - b;
+}
 SSW_DEV u32 xl_wave_shr1_keep(u32 keep, u32 v)
 {
 	int l = emu::cur->lane;
