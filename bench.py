@@ -18,16 +18,18 @@ readLen x refLen of the forward matrix only.
 process per GPU -- what the driver's command line does); under a launcher the ranks are used as they are.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields:
-  also            (default run of the metric's config on one GPU) BASELINE configs 3, 4 and 5 run for a few steps each AFTER the
-                  timed region: rate, roofline fraction of their fill kernel, parity against tests/golden/full
-  roofline        HBM view of the dominant fill kernel: algorithmic bytes per launch / mean launch time (HIP events on the
-                  library's stream), `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes of THIS kernel
-                  source (profiles/round3_traffic.json; null when the source changed since)
-  roofline_valu   the binding roofline of this integer max-plus recurrence: packed 16-bit VALU issue rate
+  also            (default run of the metric's config on one GPU) config 2 under pure 8-bit scoring (1/-3/5/2), BASELINE configs 3, 4, 5 and
+                  the README's benchmark shape (6) run for a few steps each AFTER the timed region: rate, roofline fraction of their fill
+                  kernel, parity against tests/golden/full
+  roofline        the BINDING roofline of this integer max-plus recurrence: VALU issue of the dominant fill kernel's recurrence
+                  (`frac` on readLen x refLen cells; `peak_note` states the 4-cycle peak and the ISA ideal)
+  roofline_hbm    HBM view of the same kernel: algorithmic bytes per launch / mean launch time (HIP events on the library's stream),
+                  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes of THIS kernel source (null when it changed since)
   value_with_h2d  the same batch with the queries uploaded inside the step (PCIe-inclusive; `value` is the resident rate)
-  cpu_baseline    the unmodified reference (oracle/_ref, its SSE2 path) on this host's usable cores, bounded sample
-  parity          the GPU results of the timed batch against the reference: the committed full-size fixtures
-                  (tests/golden/full, made by scripts/make_expected.py) when the workload is a preset, else the CPU sample
+  cpu_baseline    the unmodified reference (oracle/_ref, its SSE2 path) on rank 0's usable cores, bounded sample (also on N > 1 lines)
+  parity          the GPU results of the timed batch against the reference, EVERY rank on its own read block: the committed full-size
+                  fixtures (tests/golden/full, made by scripts/make_expected.py) when the workload is a preset -- all reads of block 0 on
+                  one GPU, a seeded 2 000-read sample of block r on rank r of an N-GPU line (`parity.per_rank`) -- else a CPU sample
 """
 import argparse
 import hashlib
@@ -46,7 +48,13 @@ HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: 8 TB/s spec
 VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9    # packed 16-bit (VOP3P) instructions issue over 4 cycles per wave64: 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
                                             # = 39.3e12 packed lane-instr/s (profiles/round1_valu_rate_probe.txt measures 38.3e12)
 FULL = os.path.join(ROOT, "tests", "golden", "full")
-KERNEL_SRC = os.path.join(ROOT, "complete-striped-smith-waterman-library_amd", "csrc", "ssw_kernels.hip")
+CSRC = os.path.join(ROOT, "complete-striped-smith-waterman-library_amd", "csrc")
+KERNEL_SRCS = [os.path.join(CSRC, f) for f in ("ssw_kernels.hip", "lanes.h", "ssw_dev.h")]      # everything the device code is made of
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round4_traffic.json")                         # written by scripts/gpu_profile.sh
+# VALU issue, two yardsticks: every instruction of the recurrence charged a 4-cycle slot -- what the kernels' mix actually costs
+# (profiles/round3_mix_issue_probe.txt) -- and the ISA ideal in which the three 32-bit adds of a row issue in 2.2 cycles as in a pure stream
+CYCLES_PER_PAIR_ROW_4CYCLE = 6.5 * 4.0
+CYCLES_PER_PAIR_ROW_ISA_IDEAL = 3.5 * 4.0 + 3.0 * 2.2      # = 20.6
 
 
 def usable_cores():
@@ -72,14 +80,17 @@ def usable_cores():
 
 
 def kernel_source_id():
-    with open(KERNEL_SRC, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for path in KERNEL_SRCS:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def measured_issue(key):
     """SQ_INSTS_VALU / GRBM_GUI_ACTIVE statistics of the dominant fill kernel from the committed PMC passes, for this kernel source only"""
     try:
-        with open(os.path.join(ROOT, "profiles", "round3_traffic.json")) as f:
+        with open(TRAFFIC_JSON) as f:
             tj = json.load(f)
         if tj.get("kernel_source_sha16") == kernel_source_id():
             return (tj.get("valu_issue") or {}).get(key)
@@ -92,7 +103,7 @@ def measured_traffic(key):
     """HBM bytes per alignment of the dominant kernel from the rocprofv3 PMC passes (scripts/gpu_profile_round3.sh ->
     profiles/round3_traffic.json), only if they were taken on this very kernel source"""
     try:
-        with open(os.path.join(ROOT, "profiles", "round3_traffic.json")) as f:
+        with open(TRAFFIC_JSON) as f:
             tj = json.load(f)
         ent = tj.get(key)
         if ent and tj.get("kernel_source_sha16") == kernel_source_id():
@@ -104,7 +115,10 @@ def measured_traffic(key):
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json workload (default 2: the metric's config)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5, 6],
+                    help="BASELINE.json workload (default 2: the metric's config); 6 = the README's own benchmark shape (mixed read lengths vs 4.94 Mb)")
+    ap.add_argument("--shared-device", action="store_true",
+                    help="other processes use these GPUs too: keep the library's conservative scratch budget (default: a rank that has a GPU of its own sizes for the whole HBM)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
@@ -133,15 +147,16 @@ def parse_args(argv=None):
     a.quiet = False
     a.custom = any(getattr(a, k) is not None for k in ("read_len", "ref_len", "sub", "indel")) or (a.match, a.mismatch, a.gap_open, a.gap_extend) != (2, 2, 3, 1)
     if a.steps is None:
-        a.steps = {2: 2, 3: 2, 4: 1, 5: 1}[a.config]
+        a.steps = {2: 2, 3: 2, 4: 1, 5: 1, 6: 5}[a.config]
     if a.warmup is None:
         a.warmup = 1
     return a
 
 
-def own_device(world, lib):
-    """every rank of this run has a GPU of its own (N <= visible devices): the contexts may size their scratch for the whole HBM"""
-    return world <= max(1, lib.ssw_gpu_device_count()) and os.environ.get("SSW_BENCH_SHARED_DEVICE", "0") != "1"
+def own_device(args, world, lib):
+    """every rank of this run has a GPU of its own (N <= visible devices) and nobody said otherwise (--shared-device: other processes use
+    these GPUs too): the contexts may size their scratch for the whole HBM (ssw_gpu_set_budget_exclusive)"""
+    return world <= max(1, lib.ssw_gpu_device_count()) and not args.shared_device and os.environ.get("SSW_BENCH_SHARED_DEVICE", "0") != "1"
 
 
 def init_dist():
@@ -187,6 +202,33 @@ def cigar_hashes(res_col, cig):
 
 
 # ====================================================================================================== DNA configs
+def result_fields(g):
+    return np.stack([g["score1"], g["score2"], g["ref_begin1"], g["ref_end1"], g["read_begin1"], g["read_end1"], g["ref_end2"],
+                     g["cigarLen"], g["flag"]], axis=1).astype(np.int32)
+
+
+def compare_with_reference_records(g, cig, exp, exp_hash, flag):
+    """GPU records `g` (one per read) against reference records made with flag 2 -> (mismatching alignments, what was compared)"""
+    got = result_fields(g)
+    if flag == 2:
+        mism = (got != exp).any(axis=1) | (cigar_hashes(g, cig) != exp_hash)
+        return int(mism.sum()), "all s_align fields + FNV-1a of every CIGAR word"
+    if flag == 0:   # score-only run against flag-2 records: the five fields the flag does not change; begins must be -1, no CIGAR
+        cols = [0, 1, 3, 5, 6]
+        mism = (got[:, cols] != exp[:, cols]).any(axis=1) | (got[:, 2] != -1) | (got[:, 4] != -1) | (got[:, 7] != 0) | (got[:, 8] != 0)
+        return int(mism.sum()), "score1 score2 ref_end1 read_end1 ref_end2 (+ begins -1, no CIGAR) vs the flag-2 reference records"
+    cols = [0, 1, 3, 5, 6]
+    return int((got[:, cols] != exp[:, cols]).any(axis=1).sum()), "score1 score2 ref_end1 read_end1 ref_end2"
+
+
+def gather_objects(dist, world, obj):
+    if dist is None:
+        return [obj]
+    lst = [None] * world
+    dist.all_gather_object(lst, obj)
+    return lst
+
+
 def bench_dna(args, world, rank, local_rank, dist):
     import ctypes as C
     import ssw_amd
@@ -196,23 +238,37 @@ def bench_dna(args, world, rank, local_rank, dist):
     if lib.ssw_gpu_device_count() < 1:
         raise RuntimeError("bench.py: no HIP device visible; libssw.so has no CPU path")
     ndev = lib.ssw_gpu_device_count()
+    scoring = (args.match, args.mismatch, args.gap_open, args.gap_extend)
 
-    preset = dict(W.DNA_CONFIGS[args.config])
-    p = dict(preset)
-    for k, a in (("reads", args.reads), ("read_len", args.read_len), ("ref_len", args.ref_len), ("flag", args.flag), ("sub", args.sub),
-                 ("indel", args.indel), ("mask_len", args.mask_len)):
-        if a is not None:
-            p[k] = a
-    is_preset = not args.custom and all(p[k] == preset[k] for k in ("read_len", "ref_len", "sub", "indel", "mask_len"))
-    fixture_ok = is_preset and p["reads"] == preset["reads"]      # (the generator's stream depends on the read count: the fixtures cover the preset batch only)
+    if args.config == 6:       # the README's benchmark shape: mixed read lengths
+        preset = dict(W.MIXED_CONFIG)
+        p = dict(preset)
+        for k, a in (("reads", args.reads), ("ref_len", args.ref_len), ("flag", args.flag), ("mask_len", args.mask_len)):
+            if a is not None:
+                p[k] = a
+        shape_preset = all(getattr(args, k) is None for k in ("read_len", "sub", "indel")) and all(p[k] == preset[k] for k in ("ref_len", "mask_len"))
+        ref, rlist, _ = W.mixed_config(rank, reads=p["reads"], ref_len=p["ref_len"])
+        qcodes, off = W.pack(rlist)
+        rlen = int(round(float(off[-1]) / len(rlist)))
+    else:
+        preset = dict(W.DNA_CONFIGS[args.config])
+        p = dict(preset)
+        for k, a in (("reads", args.reads), ("read_len", args.read_len), ("ref_len", args.ref_len), ("flag", args.flag), ("sub", args.sub),
+                     ("indel", args.indel), ("mask_len", args.mask_len)):
+            if a is not None:
+                p[k] = a
+        shape_preset = all(p[k] == preset[k] for k in ("read_len", "ref_len", "sub", "indel", "mask_len"))
+        ref = random_ref(p["ref_len"], p["seed_ref"], 4)
+        reads2d = W.make_reads_fast(ref, p["reads"], p["read_len"], seed=p["seed_reads"] + rank, sub=p["sub"], ins=p["indel"], dele=p["indel"])
+        rlen = p["read_len"]
+        qcodes = np.ascontiguousarray(reads2d.reshape(-1))
+        off = np.arange(p["reads"] + 1, dtype=np.int64) * rlen
+    fixture_ok = shape_preset and p["reads"] == preset["reads"]      # (the generator's stream depends on the read count: the fixtures cover the preset batch only)
     mat = dna_matrix(args.match, args.mismatch)
-    ref = random_ref(p["ref_len"], p["seed_ref"], 4)
-    reads = W.make_reads_fast(ref, p["reads"], p["read_len"], seed=p["seed_reads"] + rank, sub=p["sub"], ins=p["indel"], dele=p["indel"])
-    nreads, rlen, flag = p["reads"], p["read_len"], p["flag"]
-    off = np.arange(nreads + 1, dtype=np.int64) * rlen
+    nreads, flag = p["reads"], p["flag"]
     want_cigar = (flag & 7) != 0
-    name = preset["name"] if is_preset and nreads == preset["reads"] else "%d x %d bp DNA reads vs %.2f Mb target (config %d generator)" % (
-        nreads, rlen, p["ref_len"] / 1e6, args.config)
+    name = preset["name"] if fixture_ok else "%d DNA reads of %s bp vs %.2f Mb target (config %d generator)" % (
+        nreads, "%d..%d" % (int(np.diff(off).min()), int(np.diff(off).max())) if args.config == 6 else str(rlen), p["ref_len"] / 1e6, args.config)
 
     pool = None
     if args.pool > 0:
@@ -221,13 +277,13 @@ def bench_dna(args, world, rank, local_rank, dist):
         ctx = None
 
         def step():
-            return pool.align(None, mat, 5, args.gap_open, args.gap_extend, flag, 0, 0, p["mask_len"], 2, want_cigar=want_cigar, packed=(reads.reshape(-1), off))
+            return pool.align(None, mat, 5, args.gap_open, args.gap_extend, flag, 0, 0, p["mask_len"], 2, want_cigar=want_cigar, packed=(qcodes, off))
     else:
         ctx = ssw_amd.Context(local_rank % ndev, lib)
-        budget = ctx.set_exclusive() if own_device(world, lib) else int(lib.ssw_gpu_get_budget(ctx.h))
+        budget = ctx.set_exclusive() if own_device(args, world, lib) else int(lib.ssw_gpu_get_budget(ctx.h))
 
         def upload_reads():
-            qh = lib.ssw_gpu_seqs_upload(ctx.h, reads.ctypes.data_as(C.POINTER(C.c_int8)), off.ctypes.data_as(C.POINTER(C.c_int64)), nreads)
+            qh = lib.ssw_gpu_seqs_upload(ctx.h, qcodes.ctypes.data_as(C.POINTER(C.c_int8)), off.ctypes.data_as(C.POINTER(C.c_int64)), nreads)
             if not qh:
                 raise RuntimeError(ctx.error())
             Q = ssw_amd.Seqs.__new__(ssw_amd.Seqs); Q.ctx = ctx; Q.count = nreads; Q.h = qh
@@ -270,8 +326,87 @@ def bench_dna(args, world, rank, local_rank, dist):
     barrier()
     dt = max_over_ranks(dist, time.perf_counter() - t0)
 
-    cells_per_step = float(nreads) * rlen * p["ref_len"]
-    value = cells_per_step * args.steps * world / dt / 1e9
+    cells_per_step = float(off[-1]) * p["ref_len"]
+    # every rank's block has (nearly, config 6: the same distribution of) the same number of cells: whole-job cells = sum over the ranks
+    cells_all = sum(gather_objects(dist, world, cells_per_step))
+    value = cells_all * args.steps / dt / 1e9
+
+    # ---- parity of the timed batch, EVERY rank against the reference's records of ITS read block (tests/golden/full), gathered on rank 0
+    from sswutil import ref_lib, oracle_align, _ptr, i8p, i32p, i64p
+    R = ref_lib()
+    g_all = res[:, 0]
+    par = None
+    tag = {(2, 2, 3, 1): "", (1, 3, 5, 2): "_u8"}.get(scoring)
+    fix = os.path.join(FULL, "config%d%s_block0.npz" % (args.config, tag)) if tag is not None else None
+    if fixture_ok and args.config == 6 and scoring in ((2, 2, 3, 1), (1, 3, 5, 2)) and rank == 0 and os.path.exists(os.path.join(FULL, "config6_block0.npz")):
+        z = np.load(os.path.join(FULL, "config6_block0.npz"))
+        key = "default" if scoring == (2, 2, 3, 1) else "m1x3o5e2"
+        bad, what = compare_with_reference_records(g_all, cig, z["fields_" + key], z["cigar_fnv_" + key], flag)
+        par = {"sample": int(nreads), "mismatching_alignments": bad, "fields": what,
+               "against": "tests/golden/full/config6_block0.npz (%s): unmodified reference (oracle/_ref) on the same seeded reads" % key}
+    elif fixture_ok and args.config != 6 and rank == 0 and fix is not None and os.path.exists(fix):
+        z = np.load(fix)
+        k = min(nreads, len(z["fields"]))
+        bad, what = compare_with_reference_records(g_all[:k], cig, z["fields"][:k], z["cigar_fnv"][:k], flag)
+        par = {"sample": int(k), "mismatching_alignments": bad, "fields": what,
+               "against": "tests/golden/full/%s: unmodified reference (oracle/_ref) on the same seeded reads" % os.path.basename(fix)}
+    elif fixture_ok and args.config in (2, 3) and scoring == (2, 2, 3, 1) and os.path.exists(os.path.join(FULL, "config%d_blocks_sample.npz" % args.config)):
+        z = np.load(os.path.join(FULL, "config%d_blocks_sample.npz" % args.config))
+        if rank < len(z["idx"]):
+            idx = z["idx"][rank]
+            bad, what = compare_with_reference_records(g_all[idx], cig, z["fields"][rank], z["cigar_fnv"][rank], flag)
+            par = {"sample": int(len(idx)), "mismatching_alignments": bad, "fields": what,
+                   "against": "tests/golden/full/config%d_blocks_sample.npz[block %d]: unmodified reference on a seeded sample of this rank's read block" % (args.config, rank)}
+    cpu = None
+    cores = usable_cores()
+
+    def cpu_run(k, threads):
+        cres = np.zeros((k, 10), dtype=np.int32)
+        secs = R.refwrap_bench(_ptr(qcodes, i8p), _ptr(off, i64p), k, _ptr(ref, i8p), len(ref), _ptr(mat, i8p), 5, args.gap_open, args.gap_extend,
+                               flag, 0, 0, p["mask_len"], threads, _ptr(cres, i32p))
+        return secs, cres
+    if rank == 0 and args.cpu_sample != 0 and R is not None:
+        # the CPU baseline: the unmodified reference on this host's usable cores, a bounded sample of rank 0's batch (also on N > 1 lines:
+        # it runs after the timed region while the other ranks wait at the last barrier)
+        if args.cpu_sample > 0:
+            ns = min(args.cpu_sample, nreads)
+        else:   # pilot of one read per core, then a sample sized for ~15 s of wall-clock on all cores
+            pilot = min(nreads, cores)
+            s0, _ = cpu_run(pilot, cores)
+            ns = int(min(nreads, max(pilot, pilot / max(s0, 1e-3) * 15.0)))
+        secs, cres = cpu_run(ns, cores)
+        cpu_gcups = float(off[ns]) * p["ref_len"] / secs / 1e9
+        cpu = {"value": round(cpu_gcups, 2), "unit": "GCUPS", "cores": cores, "kind": "reference",
+               "per_core": round(cpu_gcups / cores, 2), "host_logical_cpus": os.cpu_count(),
+               "cores_note": "threads = CPUs this container may use (affinity capped by the cgroup cpu.max quota)",
+               "sample": "first %d reads of rank 0's batch vs the same target, ssw_init(...,2)+ssw_align through the C API, "
+                         "reference ssw.c built -O2 (oracle/_ref), one thread per core, %.1f s" % (ns, secs)}
+        if par is None:
+            par = {"sample": ns, "mismatching_alignments": int((result_fields(g_all[:ns]) != cres[:, :9]).any(axis=1).sum()),
+                   "fields": "score1 score2 ref/read begin/end ref_end2 cigarLen flag", "against": "the CPU-baseline run of this process"}
+    if par is None and R is not None and args.cpu_sample != 0:      # a rank without a fixture for its block: a small sample through the reference
+        ns = min(nreads, 32)
+        _, cres = cpu_run(ns, 2)
+        par = {"sample": ns, "mismatching_alignments": int((result_fields(g_all[:ns]) != cres[:, :9]).any(axis=1).sum()),
+               "fields": "score1 score2 ref/read begin/end ref_end2 cigarLen flag", "against": "the unmodified reference (oracle/_ref) run by this rank on its first reads"}
+    if par is None and args.cpu_sample != 0:                      # no reference build on this host: the scalar port (oracle/), a couple of reads
+        ns = min(nreads, args.cpu_sample if args.cpu_sample > 0 else 2)
+        t1 = time.perf_counter()
+        mism = 0
+        for i in range(ns):
+            rd = qcodes[off[i]:off[i + 1]]
+            d, _ = oracle_align(rd, mat, 5, ref, args.gap_open, args.gap_extend, flag, 0, 0, p["mask_len"] if p["mask_len"] >= 0 else len(rd) // 2, 2, 0)
+            g = res[i, 0]
+            mism += any(int(g[k]) != d[k] for k in ("score1", "score2", "ref_end1", "read_end1", "ref_end2"))
+        secs = time.perf_counter() - t1
+        if rank == 0:
+            cpu = {"value": round(float(off[ns]) * p["ref_len"] / secs / 1e9, 3), "unit": "GCUPS", "cores": 1,
+                   "kind": "port", "sample": "%d reads, scalar lane-model oracle (oracle/_ref not shipped)" % ns}
+        par = {"sample": ns, "mismatching_alignments": mism, "fields": "score1 score2 ref_end1 read_end1 ref_end2", "against": "the scalar port (oracle/)"}
+    if par is not None:
+        par["rank"] = rank
+    per_rank = gather_objects(dist, world, par)
+
     out = None
     if rank == 0:
         out = {"metric": "GCUPS", "value": round(value, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -279,7 +414,12 @@ def bench_dna(args, world, rank, local_rank, dist):
                "dtype": "int16x2 (packed; reference u8/int16 semantics)", "data": "synthetic",
                "config": {"workload": "%s; %d/-%d/%d/%d, score_size 2, flag %d" % (name, args.match, args.mismatch, args.gap_open, args.gap_extend, flag),
                           "baseline_config": args.config, "reads_per_gpu": nreads, "read_len": rlen, "ref_len": p["ref_len"],
-                          "sharding": "read block r on rank r, target replicated, no collective"}}
+                          "sharding": "read block r on rank r, target replicated, no collective"},
+               "value_note": "whole-job rate with the sequences resident in HBM when the timed region starts (the bench contract); "
+                             "value_with_h2d re-uploads the queries inside the step (SURVEY 8d's definition)"}
+        if args.config == 6:
+            out["config"]["readme_context"] = ("the reference's README.md:62-74 quotes ~880 s (defaults) / ~460 s (-m1 -x3 -o5 -e2) of CPU time, one thread, for its "
+                                               "1000 Ion Torrent reads vs E. coli 536 (~1.1 / ~2.1 GCUPS): same shape, other data and hardware -- context, not vs_baseline")
         if pool is None:
             out["config"]["scratch_budget_gib"] = round(budget / 2.0 ** 30, 1)
         if pool is not None:
@@ -287,45 +427,50 @@ def bench_dna(args, world, rank, local_rank, dist):
             out["config"]["note"] = "in-library per-GPU work queues (ssw_gpu_pool): reads on the host, blocks uploaded by the workers inside the step"
             out["pool_stats"] = pool.stats()
         if tm is not None:
-            if tm["fill_ops_per_row"] == 7.5:
-                out["dtype"] = "f16x2 holding exact integers (scores/2048); reference u8/int16 semantics"
-            elif tm["fill_ops_per_row"] == 6.5:
+            if tm["fill_ops_per_row"] == 6.5:
                 out["dtype"] = "int16x2 in a column frame (value + phi(column); 32-bit adds on the packed pair, three-input maxima on the bit patterns); reference u8/int16 semantics"
             out["mix"] = {"word_rules": int(tm["n_word"]), "byte_rules": int(tm["n_byte"])}
             out["phases_ms_per_step"] = {"fill": round(acc["fill_ms"] / args.steps, 3), "locate": round(acc["locate_ms"] / args.steps, 3),
                                          "trace": round(acc["trace_ms"] / args.steps, 3), "reduce_and_copies": round(acc["reduce_ms"] / args.steps, 3)}
             launch_ms = acc["fill_ms"] / max(1, acc["fill_launches"])
-            # algorithmic HBM bytes of one fill launch (SURVEY 8d / DESIGN.md): per alignment refLen target codes read, readLen + n^2
-            # query/matrix bytes, 4*refLen column-maximum bytes written (2 rule sets x u16), 40 B result; long queries add the
+            # ---- the binding roofline: VALU issue of the fill kernel's recurrence
+            ops = tm["fill_ops_per_row"]
+            fill_s = acc["fill_ms"] * 1e-3
+            achieved_valu = acc["fill_cells"] * ops / 2.0 / fill_s if fill_s > 0 else 0.0        # every evaluated cell: padding rows, halo columns
+            real = cells_per_step * args.steps * ops / 2.0 / fill_s if fill_s > 0 else 0.0       # readLen x refLen only
+            probe = ctx.valu_probe(8192, 4000) if args.lib is None else 0.0      # (skipped on the test emulator)
+            ideal = (CYCLES_PER_PAIR_ROW_ISA_IDEAL / CYCLES_PER_PAIR_ROW_4CYCLE) if ops == 6.5 else 1.0
+            out["roofline"] = {"bound": "valu-issue", "kernel": tm["fill_kernel"], "achieved": round(real / 1e12, 3), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
+                               "unit": "T lane-op/s", "frac": round(real / VALU_PEAK_LANEOPS, 4),
+                               "frac_with_padding_and_halo": round(achieved_valu / VALU_PEAK_LANEOPS, 4),
+                               "frac_of_isa_ideal": round(real / VALU_PEAK_LANEOPS * ideal, 4),
+                               "measured_peak_probe": round(probe / 1e12, 2), "ops_per_pair_row": ops,
+                               "launch_ms": round(launch_ms, 3), "launches": int(acc["fill_launches"]),
+                               "fill_gcups_padded": round(acc["fill_cells"] / fill_s / 1e9, 1) if fill_s > 0 else 0.0,
+                               "peak_note": "integer max-plus recurrence: neither MFMA nor HBM binds, the issue of vector instructions does.  `achieved` = readLen x refLen cells "
+                                            "x %.1f recurrence instructions per row of a query pair / 2 / fill time; `peak` = one wave64 instruction per 4 cycles and SIMD = 256 CU x 4 SIMD "
+                                            "x 16 lanes x 2.4 GHz = 39.3 T (every VOP3P, and every other vector instruction in this mix: profiles/round3_mix_issue_probe.txt).  "
+                                            "`frac_of_isa_ideal`: against the ISA ideal of %.1f cycles per pair-row (the three 32-bit adds at the 2.2 cycles they take in a pure "
+                                            "stream) instead of 26 -- not reachable by reordering (DESIGN.md 8b), stated for completeness" % (ops, CYCLES_PER_PAIR_ROW_ISA_IDEAL),
+                               "counters": measured_issue("config%d" % args.config) if fixture_ok else None}
+            # ---- the HBM view (not binding): algorithmic bytes of one fill launch (SURVEY 8d / DESIGN.md): per alignment refLen target codes read,
+            # readLen + n^2 query/matrix bytes, 4*refLen column-maximum bytes written (2 rule sets x u16), 40 B result; long queries add the
             # boundary records between strips (16 B per column and pair, written once and read once)
             aln_per_launch = nreads * args.steps / max(1, acc["fill_launches"])
             bytes_per_aln = p["ref_len"] + rlen + 25 + 40 + 4 * p["ref_len"]
             if tm["fill_strips"] > 1:
                 bytes_per_aln += 16 * p["ref_len"] * (tm["fill_strips"] - 1)
             achieved = aln_per_launch * bytes_per_aln / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-            tr = measured_traffic("config%d" % args.config) if is_preset else None
+            tr = measured_traffic("config%d" % args.config) if fixture_ok else None
             traffic = round(tr["hbm_bytes_per_alignment"] * aln_per_launch / (launch_ms * 1e-3) / 1e9, 2) if tr and launch_ms > 0 else None
-            out["roofline"] = {"bound": "hbm", "kernel": tm["fill_kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                               "traffic_note": ("GB/s from rocprofv3 FETCH_SIZE + WRITE_SIZE of this kernel, PMC passes of this kernel source "
-                                                "(profiles/round3_traffic.json, source %s)" % kernel_source_id()) if traffic is not None else
-                                               "no PMC pass of this kernel source committed (scripts/gpu_profile_round3.sh writes profiles/round3_traffic.json)",
-                               "launch_ms": round(launch_ms, 3), "launches": int(acc["fill_launches"]),
-                               "algorithmic_bytes_per_alignment": int(bytes_per_aln),
-                               "note": "integer max-plus recurrence: HBM is not the binding resource, see roofline_valu"}
-            valu_ops = acc["fill_cells"] * tm["fill_ops_per_row"] / 2.0
-            achieved_valu = valu_ops / (acc["fill_ms"] * 1e-3) if acc["fill_ms"] > 0 else 0.0
-            probe = ctx.valu_probe(8192, 4000) if args.lib is None else 0.0      # (skipped on the test emulator)
-            real = cells_per_step * args.steps * tm["fill_ops_per_row"] / 2.0 / (acc["fill_ms"] * 1e-3) if acc["fill_ms"] > 0 else 0.0
-            out["roofline_valu"] = {"bound": "valu-packed16", "achieved": round(achieved_valu / 1e12, 3), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
-                                    "unit": "T lane-op/s", "frac": round(achieved_valu / VALU_PEAK_LANEOPS, 4),
-                                    "frac_on_real_cells": round(real / VALU_PEAK_LANEOPS, 4), "measured_peak_probe": round(probe / 1e12, 2),
-                                    "ops_per_pair_row": tm["fill_ops_per_row"],
-                                    "note": "VALU issue slots of the fill kernel's recurrence: 4 cycles per wave64 instruction (VOP3P always; the 2-cycle 32-bit adds of "
-                                            "the column-frame form too when they alternate with VOP3P: profiles/round3_mix_issue_probe.txt), peak = 256 CU x 4 SIMD x 16 x 2.4 GHz; "
-                                            "`frac` counts every evaluated cell (padding rows, halo columns), `frac_on_real_cells` only readLen x refLen",
-                                    "fill_gcups_padded": round(acc["fill_cells"] / (acc["fill_ms"] * 1e-3) / 1e9, 1) if acc["fill_ms"] > 0 else 0.0,
-                                    "counters": measured_issue("config%d" % args.config) if is_preset else None}
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": tm["fill_kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                                   "traffic_note": ("GB/s from rocprofv3 FETCH_SIZE + WRITE_SIZE of this kernel, PMC passes of this kernel source "
+                                                    "(%s, source %s)" % (os.path.relpath(TRAFFIC_JSON, ROOT), kernel_source_id())) if traffic is not None else
+                                                   "no PMC pass of this kernel source committed (scripts/gpu_profile.sh writes %s)" % os.path.relpath(TRAFFIC_JSON, ROOT),
+                                   "launch_ms": round(launch_ms, 3), "launches": int(acc["fill_launches"]),
+                                   "algorithmic_bytes_per_alignment": int(bytes_per_aln),
+                                   "note": "HBM is not the binding resource of this path (see roofline)"}
             # PCIe-inclusive rate: one more step with the reads uploaded (and freed) inside it
             if world == 1 and not args.quiet:
                 t1 = time.perf_counter()
@@ -333,70 +478,15 @@ def bench_dna(args, world, rank, local_rank, dist):
                 step(Q2)
                 Q2.free()
                 out["value_with_h2d"] = round(cells_per_step / (time.perf_counter() - t1) / 1e9, 2)
-
-        # ---- parity of the timed batch + CPU baseline (rank 0, N = 1 only)
-        if world == 1:
-            from sswutil import ref_lib, oracle_align, _ptr, i8p, i32p, i64p
-            fix = os.path.join(FULL, "config%d_block0.npz" % args.config)
-            default_scoring = (args.match, args.mismatch, args.gap_open, args.gap_extend) == (2, 2, 3, 1)
-            if fixture_ok and default_scoring and os.path.exists(fix):
-                z = np.load(fix)
-                k = min(nreads, len(z["fields"]))
-                g = res[:k, 0]
-                got = np.stack([g["score1"], g["score2"], g["ref_begin1"], g["ref_end1"], g["read_begin1"], g["read_end1"], g["ref_end2"],
-                                g["cigarLen"], g["flag"]], axis=1).astype(np.int32)
-                exp = z["fields"][:k]
-                if flag == 2:
-                    mism = (got != exp).any(axis=1) | (cigar_hashes(g, cig) != z["cigar_fnv"][:k])
-                    what = "all s_align fields + FNV-1a of every CIGAR word"
-                else:   # score-only run against flag-2 fixtures: the five fields the flag does not change; begins must be -1, no CIGAR
-                    cols = [0, 1, 3, 5, 6]
-                    mism = (got[:, cols] != exp[:, cols]).any(axis=1) | (got[:, 2] != -1) | (got[:, 4] != -1) | (got[:, 7] != 0) | (got[:, 8] != 0)
-                    what = "score1 score2 ref_end1 read_end1 ref_end2 (+ begins -1, no CIGAR) vs the flag-2 reference records"
-                out["parity"] = {"sample": int(k), "mismatching_alignments": int(mism.sum()), "fields": what,
-                                 "against": "tests/golden/full/config%d_block0.npz: unmodified reference (oracle/_ref) on the same seeded reads" % args.config}
-            R = ref_lib()
-            if args.cpu_sample != 0 and R is not None:
-                cores = usable_cores()
-
-                def cpu_run(k):
-                    sample = np.ascontiguousarray(reads[:k])
-                    soff = np.arange(k + 1, dtype=np.int64) * rlen
-                    cres = np.zeros((k, 10), dtype=np.int32)
-                    secs = R.refwrap_bench(_ptr(sample, i8p), _ptr(soff, i64p), k, _ptr(ref, i8p), len(ref), _ptr(mat, i8p), 5, args.gap_open, args.gap_extend,
-                                           flag, 0, 0, p["mask_len"], cores, _ptr(cres, i32p))
-                    return secs, cres
-                if args.cpu_sample > 0:
-                    ns = min(args.cpu_sample, nreads)
-                else:   # pilot of one read per core, then a sample sized for ~15 s of wall-clock on all cores
-                    pilot = min(nreads, cores)
-                    s0, _ = cpu_run(pilot)
-                    ns = int(min(nreads, max(pilot, pilot / max(s0, 1e-3) * 15.0)))
-                secs, cres = cpu_run(ns)
-                cpu_gcups = ns * rlen * p["ref_len"] / secs / 1e9
-                out["cpu_baseline"] = {"value": round(cpu_gcups, 2), "unit": "GCUPS", "cores": cores, "kind": "reference",
-                                       "per_core": round(cpu_gcups / cores, 2), "host_logical_cpus": os.cpu_count(),
-                                       "cores_note": "threads = CPUs this container may use (affinity capped by the cgroup cpu.max quota)",
-                                       "sample": "first %d reads of the batch vs the same target, ssw_init(...,2)+ssw_align through the C API, "
-                                                 "reference ssw.c built -O2 (oracle/_ref), one thread per core, %.1f s" % (ns, secs)}
-                if "parity" not in out:
-                    g = res[:ns, 0]
-                    got = np.stack([g["score1"], g["score2"], g["ref_begin1"], g["ref_end1"], g["read_begin1"], g["read_end1"], g["ref_end2"],
-                                    g["cigarLen"], g["flag"]], axis=1).astype(np.int32)
-                    out["parity"] = {"sample": ns, "mismatching_alignments": int((got != cres[:, :9]).any(axis=1).sum()),
-                                     "fields": "score1 score2 ref/read begin/end ref_end2 cigarLen flag", "against": "the CPU-baseline run of this process"}
-            elif args.cpu_sample != 0:
-                ns = args.cpu_sample if args.cpu_sample > 0 else 2
-                t1 = time.perf_counter()
-                mism = 0
-                for i in range(ns):
-                    d, _ = oracle_align(reads[i], mat, 5, ref, args.gap_open, args.gap_extend, flag, 0, 0, rlen // 2, 2, 0)
-                    g = res[i, 0]
-                    mism += any(int(g[k]) != d[k] for k in ("score1", "score2", "ref_end1", "read_end1", "ref_end2"))
-                secs = time.perf_counter() - t1
-                out["cpu_baseline"] = {"value": round(ns * rlen * p["ref_len"] / secs / 1e9, 3), "unit": "GCUPS", "cores": 1,
-                                       "kind": "port", "sample": "%d reads, scalar lane-model oracle (oracle/_ref not shipped)" % ns}
-                out.setdefault("parity", {"sample": ns, "mismatching_alignments": mism})
+        got_par = [x for x in per_rank if x]
+        if got_par:
+            out["parity"] = dict(got_par[0])
+            out["parity"].pop("rank", None)
+            if world > 1:
+                out["parity"] = {"sample": int(sum(x["sample"] for x in got_par)), "mismatching_alignments": int(sum(x["mismatching_alignments"] for x in got_par)),
+                                 "ranks_checked": len(got_par), "per_rank": got_par}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         if not args.quiet:
             cleanup()        # this config's device buffers go first: the `also` runs get the whole device, like a run of their own
             attach_also(args, out, world)
@@ -404,7 +494,7 @@ def bench_dna(args, world, rank, local_rank, dist):
             sys.stdout.flush()
     dump = os.environ.get("SSW_BENCH_DUMP")
     if dump:   # tests: keep every rank's shard and results for an independent check
-        np.savez(os.path.join(dump, "rank%d.npz" % rank), reads=reads, ref=ref, res=res)
+        np.savez(os.path.join(dump, "rank%d.npz" % rank), reads=qcodes.reshape(nreads, -1) if args.config != 6 else qcodes, ref=ref, res=res)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -423,7 +513,7 @@ def bench_db(args, world, rank, local_rank, dist):
     if lib.ssw_gpu_device_count() < 1:
         raise RuntimeError("bench.py: no HIP device visible; libssw.so has no CPU path")
     ctx = ssw_amd.Context(local_rank % max(1, lib.ssw_gpu_device_count()), lib)
-    if own_device(world, lib):
+    if own_device(args, world, lib):
         ctx.set_exclusive()
     nq = args.reads if args.reads is not None else 50_000
     nt = args.db_targets if args.db_targets is not None else 10_000
@@ -457,6 +547,11 @@ def bench_db(args, world, rank, local_rank, dist):
         fresh()
         ctx.search_db(Q, T, mat, 24, args.gap_open, args.gap_extend, -1, 2, args.db_chunk, cb)
 
+    # allocation warm-up, outside every timer: the library page-locks its two host buffers for nq x chunk records on the first search of a
+    # context (of the order of a second) and keeps them -- one chunk of DB entries makes that happen before the first measured step
+    Tw = ctx.upload(db[:min(nt, args.db_chunk)])
+    ctx.search_db(Q, Tw, mat, 24, args.gap_open, args.gap_extend, -1, 2, args.db_chunk, lambda tfirst, hits: 0)
+    Tw.free()
     for _ in range(args.warmup):
         step()
     if dist is not None:
@@ -475,6 +570,20 @@ def bench_db(args, world, rank, local_rank, dist):
     out = None
     if rank == 0 and world == 1:
         step(on_chunk_verify)          # untimed: the same search once more, every record folded into the parity checksums
+    # ranks other than 0 have no committed fixture for their query block: their first queries x all entries through the unmodified reference
+    rank_par = None
+    if rank > 0 and args.cpu_sample != 0:
+        Rr = ref_lib()
+        if Rr is not None and hasattr(Rr, "refwrap_bench_db"):
+            kq = min(nq, keep, 4)
+            tc_, to_ = W.pack(db); qc_, qo_ = W.pack(qs[:kq])
+            r5 = np.zeros((kq, nt, 5), dtype=np.int32)
+            Rr.refwrap_bench_db(_ptr(qc_, i8p), _ptr(qo_, i64p), kq, _ptr(tc_, i8p), _ptr(to_, i64p), nt, _ptr(mat, i8p), 24, args.gap_open, args.gap_extend, -1, 2, _ptr(r5, i32p))
+            kept = state["kept"][:kq]
+            got = np.stack([kept["score1"], kept["score2"], kept["ref_end1"], kept["read_end1"], kept["ref_end2"]], axis=2).astype(np.int32)
+            rank_par = {"rank": rank, "sample": kq * nt, "mismatching_alignments": int((got != r5).any(axis=2).sum()),
+                        "against": "the unmodified reference (oracle/_ref) run by this rank on its first %d queries x all %d entries" % (kq, nt)}
+    per_rank = gather_objects(dist, world, rank_par)
     if rank == 0:
         qsum = float(sum(len(x) for x in qs)); tsum = float(sum(len(x) for x in db))
         out = {"metric": "GCUPS", "value": round(cells * args.steps * world / dt / 1e9, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
@@ -495,25 +604,28 @@ def bench_db(args, world, rank, local_rank, dist):
         achieved = aln_per_launch * bytes_per_aln / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         tr = measured_traffic("config5") if is_preset else None
         traffic = round(tr["hbm_bytes_per_alignment"] * aln_per_launch / (launch_ms * 1e-3) / 1e9, 2) if tr and launch_ms > 0 else None
-        out["roofline"] = {"bound": "hbm", "kernel": tm["fill_kernel"] + " (largest size class; a launch = all size classes of one chunk of DB entries, side by side on 4 streams)",
-                           "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                           "launch_ms": round(launch_ms, 3), "launches": int(launches), "algorithmic_bytes_per_alignment": round(bytes_per_aln, 1),
-                           "note": "integer max-plus recurrence: HBM is not the binding resource, see roofline_valu"}
+        out["roofline_hbm"] = {"bound": "hbm", "kernel": tm["fill_kernel"] + " (largest size class; a launch = all size classes of one chunk of DB entries, side by side on 4 streams)",
+                               "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                               "launch_ms": round(launch_ms, 3), "launches": int(launches), "algorithmic_bytes_per_alignment": round(bytes_per_aln, 1),
+                               "note": "HBM is not the binding resource of this path (see roofline)"}
         ops = tm["fill_ops_per_row"]
         achieved_valu = fill_cells * ops / 2.0 / (fill_ms * 1e-3) if fill_ms > 0 else 0.0
         real = cells * args.steps * ops / 2.0 / (fill_ms * 1e-3) if fill_ms > 0 else 0.0
         probe = ctx.valu_probe(8192, 4000) if args.lib is None else 0.0
-        out["roofline_valu"] = {"bound": "valu-packed16", "achieved": round(achieved_valu / 1e12, 3), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
-                                "unit": "T lane-op/s", "frac": round(achieved_valu / VALU_PEAK_LANEOPS, 4), "frac_on_real_cells": round(real / VALU_PEAK_LANEOPS, 4),
-                                "measured_peak_probe": round(probe / 1e12, 2), "ops_per_pair_row": ops,
-                                "note": "recurrence instructions only (%.1f per row of a query pair, each a 4-cycle issue slot in this mix: profiles/round3_mix_issue_probe.txt); "
-                                        "best-cell tracking and the fused reduction are overhead on top" % ops,
-                                "fill_gcups_padded": round(fill_cells / (fill_ms * 1e-3) / 1e9, 1) if fill_ms > 0 else 0.0,
-                                "counters": measured_issue("config5") if is_preset else None}
-        if world == 1:
+        ideal = (CYCLES_PER_PAIR_ROW_ISA_IDEAL / CYCLES_PER_PAIR_ROW_4CYCLE) if ops == 6.5 else 1.0
+        out["roofline"] = {"bound": "valu-issue", "kernel": tm["fill_kernel"] + " (largest size class)", "achieved": round(real / 1e12, 3), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
+                           "unit": "T lane-op/s", "frac": round(real / VALU_PEAK_LANEOPS, 4), "frac_with_padding_and_halo": round(achieved_valu / VALU_PEAK_LANEOPS, 4),
+                           "frac_of_isa_ideal": round(real / VALU_PEAK_LANEOPS * ideal, 4),
+                           "measured_peak_probe": round(probe / 1e12, 2), "ops_per_pair_row": ops,
+                           "peak_note": "recurrence instructions only (%.1f per row of a query pair, each a 4-cycle issue slot in this mix: profiles/round3_mix_issue_probe.txt; "
+                                        "ISA ideal %.1f cycles per pair-row); best-cell tracking and the fused reduction are overhead on top; `achieved` counts readLen x refLen cells, "
+                                        "`frac_with_padding_and_halo` every evaluated cell" % (ops, CYCLES_PER_PAIR_ROW_ISA_IDEAL),
+                           "fill_gcups_padded": round(fill_cells / (fill_ms * 1e-3) / 1e9, 1) if fill_ms > 0 else 0.0,
+                           "counters": measured_issue("config5") if is_preset else None}
+        if True:
             par = {}
             fix = os.path.join(FULL, "config5_block0.npz")
-            if is_preset and os.path.exists(fix):
+            if is_preset and os.path.exists(fix):      # (the rows of the first queries are kept in the timed steps too: rank 0 of any N)
                 z = np.load(fix)
                 k = min(keep, int(z["nq"]))
                 kept = state["kept"][:k]
@@ -525,7 +637,7 @@ def bench_db(args, world, rank, local_rank, dist):
                        "against": "tests/golden/full/config5_block0.npz: unmodified reference on the first %d queries x all %d entries "
                                   "(one checksum per query, full records of the first 16)" % (k, nt)}
             fixf = os.path.join(FULL, "config5_full_block0.npz")
-            if is_preset and os.path.exists(fixf):
+            if is_preset and world == 1 and os.path.exists(fixf):      # (needs the extra verification search: N = 1 only)
                 z = np.load(fixf)
                 nb = min(nblk, int(z["done"]) // int(z["block"]))
                 if nb > 0:
@@ -560,6 +672,11 @@ def bench_db(args, world, rank, local_rank, dist):
                 par.setdefault("sample", kq * nt)
                 par["cpu_sample"] = {"alignments": kq * nt, "mismatching_alignments": int((got != r5).any(axis=2).sum())}
                 par.setdefault("mismatching_alignments", par["cpu_sample"]["mismatching_alignments"])
+            if world > 1 and par:
+                par["rank"] = 0
+                got_par = [par] + [x for x in per_rank if x]
+                par = {"sample": int(sum(x["sample"] for x in got_par)), "mismatching_alignments": int(sum(x["mismatching_alignments"] for x in got_par)),
+                       "ranks_checked": len(got_par), "per_rank": got_par}
             if par:
                 out["parity"] = par
         if not args.quiet:
@@ -578,31 +695,35 @@ def attach_also(args, out, world):
     roofline fraction and parity against the committed full-size fixtures go into `also`."""
     which = args.also
     if which is None:
-        which = "3,4,5" if (args.config == 2 and world == 1 and not args.custom and args.pool == 0 and args.lib is None and
+        which = "2u8,3,4,5,6" if (args.config == 2 and world == 1 and not args.custom and args.pool == 0 and args.lib is None and
                             all(getattr(args, k) is None for k in ("reads", "flag", "mask_len"))) else "none"
     if which in ("none", ""):
         return
     also = {}
     t0 = time.perf_counter()
-    for c in [int(x) for x in which.split(",")]:
-        sub = parse_args(["--config", str(c), "--steps", "1" if c == 5 else "2", "--warmup", "0" if c == 5 else "1", "--cpu-sample", "0"] +
+    for tok in which.split(","):
+        u8 = tok.endswith("u8")        # "2u8": config 2 under the pure 8-bit scoring of SURVEY 8d (ii), 1/-3/5/2
+        c = int(tok[:-2] if u8 else tok)
+        scoring = ["--match", "1", "--mismatch", "3", "--gap-open", "5", "--gap-extend", "2"] if u8 else []
+        sub = parse_args(["--config", str(c), "--steps", "1" if c == 5 else "5" if c == 6 else "2", "--warmup", "0" if c == 5 else "1", "--cpu-sample", "0"] + scoring +
                          (["--lib", args.lib] if args.lib else []))
         if args.lib:        # (tests on the emulator: small shapes)
-            sub = parse_args(["--config", str(c), "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--lib", args.lib] +
+            sub = parse_args(["--config", str(c), "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--lib", args.lib] + scoring +
                              (["--reads", "24", "--db-targets", "9", "--db-chunk", "4"] if c == 5 else
+                              ["--reads", "6", "--ref-len", "3000"] if c == 6 else
                               ["--reads", "4", "--ref-len", "3000", "--read-len", "700" if c == 4 else "90"]))
         sub.quiet = True
         try:
             o, _ = bench_db(sub, 1, 0, 0, None) if c == 5 else bench_dna(sub, 1, 0, 0, None)
-            also["config%d" % c] = {"value": o["value"], "unit": "GCUPS", "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
+            also["config" + tok] = {"value": o["value"], "unit": "GCUPS", "ms_per_step": o["ms_per_step"], "steps": o["steps"], "warmup": o["warmup"],
                                     "workload": o["config"]["workload"], "dtype": o["dtype"],
                                     "fill_kernel": o.get("roofline", {}).get("kernel"),
-                                    "roofline_valu_frac": o.get("roofline_valu", {}).get("frac"),
-                                    "roofline_valu_frac_on_real_cells": o.get("roofline_valu", {}).get("frac_on_real_cells"),
-                                    "roofline_hbm_frac": o.get("roofline", {}).get("frac"),
+                                    "roofline_frac": o.get("roofline", {}).get("frac"),
+                                    "roofline_frac_with_padding_and_halo": o.get("roofline", {}).get("frac_with_padding_and_halo"),
+                                    "roofline_hbm_frac": o.get("roofline_hbm", {}).get("frac"), "mix": o.get("mix"),
                                     "phases_ms_per_step": o.get("phases_ms_per_step"), "parity": o.get("parity")}
         except Exception as e:      # the metric's line must survive a failure here
-            also["config%d" % c] = {"error": "%s: %s" % (type(e).__name__, e)}
+            also["config" + tok] = {"error": "%s: %s" % (type(e).__name__, e)}
     also["seconds"] = round(time.perf_counter() - t0, 1)
     also["note"] = "run after the timed region of the metric's config, same process and device; parity = the GPU results of these runs against tests/golden/full"
     out["also"] = also

@@ -39,6 +39,17 @@ typedef struct {
 	int64_t cigar_off;   /* word offset of this alignment's CIGAR in the device CIGAR pool */
 } ssw_dres;
 
+/* Jobs that are (query, target) PAIRS instead of queries against the launch's one target (database search with begin positions /
+   CIGARs: the survivors of the score filter, reference src/main.c:493-506 with flag != 0): the "query index" of a job is then a
+   virtual id -- the position of the pair in a compact survivor list.  Records, CIGAR slots and resume state are indexed by the
+   virtual id, the sequences are reached through the two maps.  vq == NULL: plain query indices, the args' own `tgt`. */
+typedef struct {
+	const int32_t* vq;       /* virtual id -> query index */
+	const int32_t* vt;       /* virtual id -> target index */
+	const int8_t* tcodes;    /* all target codes */
+	const int64_t* toff;     /* target offsets */
+} ssw_vmap;
+
 /* forward fill: column maxima of every (pair, tile) of one target */
 typedef struct {
 	const int8_t* tgt;       /* codes of the target */
@@ -110,7 +121,30 @@ typedef struct {
 	int32_t* counters;       /* optional: [0] alignments decided under 16-bit rules, [1] under 8-bit rules, [2] workgroups repeated in the int16 form */
 	int32_t form;            /* 1: column-frame form of the recurrence (fr_base / fr_kmask as in ssw_fill_args), 0: plain int16 with the two-row maximum */
 	int32_t fr_base, fr_kmask;
+	int32_t mark_word;       /* `out` records carry SSW_OUT_WORD in their status when the pair was decided under 16-bit rules (k_select reads and clears it) */
 } ssw_filldb_args;
+#define SSW_OUT_WORD 0x100
+
+/* Flagged database search: which (query, target) pairs of a chunk go on to the reverse pass / traceback (reference src/ssw.c:916: not
+   when flag == 0 or (flag == 2 and score1 < filters)), compacted in (bucket-ordered query, target) order -- deterministic, and grouped
+   by the geometry bucket whose window kernel they need.  pass 0: survivors per block of 256 pairs; pass 1 (one workgroup): exclusive
+   scan of the block counts, total to total[0]; pass 2: survivor records + maps, SSW_OUT_WORD cleared in every record. */
+typedef struct {
+	struct ssw_out_rec* out; /* [query][nt] */
+	const int32_t* order;    /* nk queries in bucket order */
+	int32_t nk, nt;
+	int32_t tbase;           /* target index of column 0 of `out` */
+	int32_t flag, filters;
+	int32_t pass;
+	int32_t* blk;            /* nblk + 1 ints: counts, then exclusive offsets */
+	int32_t nblk;
+	const int64_t* bucket_lin; /* nbk + 1 linear indices k * nt at which the buckets start (last = nk * nt) */
+	int32_t nbk;
+	int32_t* bucket_first;   /* nbk + 1: first survivor of every bucket (last = total) */
+	ssw_dres* sres;          /* survivors */
+	int32_t* svq; int32_t* svt; int32_t* vlist;   /* maps + the identity list the window / traceback launches take as their job list */
+	int32_t cap;             /* survivors the three arrays hold (pass 2 writes no further) */
+} ssw_select_args;
 
 /* reduction of the column maxima into score1 / ref_end1 / score2 / ref_end2 */
 typedef struct {
@@ -149,6 +183,7 @@ typedef struct {
 	int32_t reverse;         /* 0: locate read_end1; 1: reverse pass */
 	int32_t flag, filters, filterd;
 	ssw_dres* res;
+	ssw_vmap vm;
 } ssw_capture_args;
 
 /*
@@ -188,12 +223,13 @@ typedef struct {
 	int32_t* cand;           /* fill mode, optional: best cell of every job, [job][half][4] = value, column, row, - */
 	/* work-queue form (k_chainq): njobs x strips items drawn from a ticket counter */
 	int32_t strips;          /* strips per job of this launch (jobs with fewer strips leave the rest of their items empty) */
-	int32_t* queue;          /* [0] ticket counter, [1 + job * strips + strip] completion flags, [1 + items] error word (a wait
-	                            that timed out); zeroed before the launch */
+	int32_t* queue;          /* [0] ticket counter, [1 + job * strips + strip] completion flags; zeroed before the launch */
+	int32_t* err;            /* error word of the call: raised by a wait that timed out, checked by the host before results are handed out */
 	int32_t* cand_strip;     /* [job * strips + strip][half][4]: best cell of the job up to and including that strip */
 	int32_t form;            /* fill mode: 3 = column frame (fr_base / fr_kmask as in ssw_fill_args), 0 = plain int16 */
 	int32_t fr_base, fr_kmask;
 	int32_t whole_jobs;      /* 1: a ticket is a whole job (its strips in sequence on one wavefront); 0: a ticket is one strip */
+	ssw_vmap vm;             /* capture mode only */
 } ssw_chainx_args;
 
 /*
@@ -246,6 +282,7 @@ typedef struct {
 	int32_t lds_bytes;       /* k_trace_wave: dynamic LDS per workgroup; bands that fit keep their rows on chip */
 	int32_t waves;           /* k_trace_wave: wavefronts working on one alignment (1, 4 or 16): wide bands need the lanes */
 	int32_t unblocked;       /* k_trace_wave teams: 1 = one cell per thread and two barriers per 64 x waves cells (the first form; experiments / tests) */
+	ssw_vmap vm;
 } ssw_trace_args;
 
 /* device-side mark_mismatch: M -> '=' / 'X' runs, soft clips, edit distance */
@@ -258,6 +295,7 @@ typedef struct {
 	const uint32_t* cigar;   /* slots written by the traceback (res[q].cigar_off) */
 	uint32_t* out;           /* nq slots of out_stride words */
 	int64_t out_stride;
+	ssw_vmap vm;
 } ssw_mark_args;
 
 /* compaction of the per-query CIGAR slots into one pool */
@@ -304,6 +342,7 @@ int   ssw_shim_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int   ssw_shim_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int   ssw_shim_memset(void* dst, int value, size_t bytes, void* stream);
 size_t ssw_shim_mem_free_bytes(void);
+int   ssw_shim_device_props(int* compute_units, int* waves_per_cu);   /* of the current device */
 void* ssw_shim_event_create(void);
 void  ssw_shim_event_destroy(void* ev);
 int   ssw_shim_event_record(void* ev, void* stream);
@@ -324,6 +363,7 @@ int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);
 int ssw_shim_launch_trace_wave(const ssw_trace_args* a, void* stream);
 int64_t ssw_shim_trace_lds_need(int band_width, int waves);   /* LDS that keeps a band of this width on chip */   /* one wavefront per alignment (long reads) */
 int ssw_shim_launch_gather(const ssw_gather_args* a, void* stream);
+int ssw_shim_launch_select(const ssw_select_args* a, void* stream);   /* the pass in a->pass */
 int ssw_shim_launch_mark(const ssw_mark_args* a, void* stream);
 int ssw_shim_launch_prep(const ssw_prep_args* a, void* stream);
 int ssw_shim_launch_selftest(const ssw_selftest_args* a, int blocks, void* stream);

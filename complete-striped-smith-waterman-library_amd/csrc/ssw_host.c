@@ -35,6 +35,33 @@ struct _profile {
 
 typedef struct { void* p; size_t cap; } dbuf;
 
+/* Test / experiment hooks (SSW_GPU_* environment variables).  They are read ONCE at the entry of a batch call (knobs_load) into this
+   record -- never inside the launch loops -- so that a test can flip one between two calls on the same context. */
+typedef struct {
+	int debug;              /* SSW_GPU_DEBUG: progress lines on stderr (and a stream sync after the queue launches) */
+	int frame_k;            /* SSW_GPU_FRAME_K >= 16: renormalisation period of the column frame (tests: renormalise often); 0: default */
+	int queue_mode;         /* SSW_GPU_QUEUE=jobs -> 1, strips -> 2, else 0: by the number of jobs */
+	int queue_waves;        /* SSW_GPU_QUEUE_WAVES: wavefronts of a persistent launch; 0: what the device holds */
+	int db_plain;           /* SSW_GPU_DB_FORM=0: k_filldb in the plain int16 form */
+	int db_chain_best;      /* SSW_GPU_DB_CHAIN_BEST=0 switches the chain-best filter off */
+	int xlanes16;           /* SSW_GPU_XLANES=16: long queries on 16-lane chains (k_chainx) */
+	int xr, xr_window;      /* SSW_GPU_XR / SSW_GPU_XR_WINDOW: rows per lane of the strip kernel / of its window passes; 0: default */
+	int fill_plain;         /* SSW_GPU_FILL_FORM=0 (or the older SSW_GPU_FILL_F16=0): plain int16 form everywhere */
+	int no_db;              /* SSW_GPU_NO_DB=1: never take the fused database-search path */
+	int overlap;            /* SSW_GPU_OVERLAP=1: reductions on a second stream beside the next fill (measured slower) */
+	int no_track;           /* SSW_GPU_NO_TRACK=1: always run the locate pass */
+	int no_seg_reduce;      /* SSW_GPU_SEG_REDUCE=0: k_reduce over the columns instead of k_reduce_seg over group maxima */
+	int window_int16;       /* SSW_GPU_WINDOW_INT16: window passes of the strip kernel in the plain form */
+	int trace_wave;         /* SSW_GPU_TRACE_WAVE=0/1: force the thread / team traceback; -1: by read length */
+	int trace_no_lds;       /* SSW_GPU_TRACE_LDS=0: band rows in HBM scratch */
+	int trace_waves;        /* SSW_GPU_TRACE_WAVES=1/4/16: team size; 0: by band width */
+	int trace_unblocked;    /* SSW_GPU_TRACE_BLOCKED=0: teams with one cell per thread */
+	int serial_buckets;     /* SSW_GPU_SERIAL_BUCKETS=1: geometry buckets one after the other on the main stream (the form before round 4) */
+	int no_dbx;             /* SSW_GPU_NO_DBX=1: flagged batches against many targets take the per-target loop (the form before round 4) */
+	int db_tsub, dbx_slab;  /* SSW_GPU_DB_TSUB / SSW_GPU_DBX_SLAB: targets per chunk of the database search / survivors per traceback slab (tests: force
+	                           several chunks and slabs on toy batches); 0: from the budget */
+} ssw_knobs;
+
 #define SSW_TSTREAMS 6
 #define DB_STREAMS 4                   /* side streams the size classes of a database-search chunk are spread over */
 
@@ -46,13 +73,16 @@ struct ssw_gpu_ctx {
 	void *ev_fill[2], *ev_red[2];
 	char err[512];
 	ssw_gpu_timing tm;
-	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, cigar2, need, goff, gpool, bnd, tlist, cand, tresume, queue, cands, sg16, sg8;
+	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, cigar2, need, goff, gpool, bnd, tlist, cand, tresume, queue, cands, sg16, sg8, qerr;
+	dbuf sres, svq, svt, scnt;          /* flagged database search: survivor records, their (query, target) maps, counters */
 	void** ev; int nev, capev;          /* event pairs around fill launches */
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d, *ev_db;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
 	int busy;                           /* a batch call is running on this context (one call at a time per context) */
 	int budget_shrunk;                  /* an allocation failed once: the device is shared, the budget was cut (SSW_ALLOC_RETRY) */
-	const int32_t* queue_err;           /* device error word of the last work-queue launch, not yet checked */
+	ssw_knobs kn;                       /* environment hooks of the running call (knobs_load) */
+	int dev_cus, dev_wave_slots;        /* compute units and resident wavefront slots of the device (hipGetDeviceProperties) */
+	int queue_used;                     /* a work-queue launch of this call may have raised the error word (c->qerr): checked before results are handed out */
 	void* hits_d[2]; void* hits_h[2]; size_t hits_cap;     /* streamed database search: two device + two page-locked host buffers, kept between calls */
 };
 
@@ -66,6 +96,36 @@ struct ssw_gpu_seqs {
 };
 
 static __thread char g_open_err[512];   /* error of the last failed ssw_gpu_open of this thread */
+
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e && e[0] ? atoi(e) : dflt; }
+static int env_is(const char* name, char ch) { const char* e = getenv(name); return e && e[0] == ch; }
+static void knobs_load(ssw_knobs* k)
+{
+	memset(k, 0, sizeof *k);
+	k->debug = getenv("SSW_GPU_DEBUG") != 0;
+	{ const int v = env_int("SSW_GPU_FRAME_K", 0); k->frame_k = v >= 16 ? v : 0; }
+	k->queue_mode = env_is("SSW_GPU_QUEUE", 'j') ? 1 : env_is("SSW_GPU_QUEUE", 's') ? 2 : 0;
+	{ const int v = env_int("SSW_GPU_QUEUE_WAVES", 0); k->queue_waves = v > 0 ? v : 0; }
+	k->db_plain = env_is("SSW_GPU_DB_FORM", '0');
+	k->db_chain_best = !env_is("SSW_GPU_DB_CHAIN_BEST", '0');
+	k->xlanes16 = env_int("SSW_GPU_XLANES", 0) == 16;
+	{ const int v = env_int("SSW_GPU_XR", 0); k->xr = v >= 1 && v <= 16 ? v : 0; }
+	{ const int v = env_int("SSW_GPU_XR_WINDOW", 0); k->xr_window = v >= 1 && v <= 16 ? v : 0; }
+	k->fill_plain = env_is("SSW_GPU_FILL_FORM", '0') || env_is("SSW_GPU_FILL_F16", '0');
+	k->no_db = env_is("SSW_GPU_NO_DB", '1');
+	k->overlap = env_is("SSW_GPU_OVERLAP", '1');
+	k->no_track = env_is("SSW_GPU_NO_TRACK", '1');
+	k->no_seg_reduce = env_is("SSW_GPU_SEG_REDUCE", '0');
+	k->window_int16 = getenv("SSW_GPU_WINDOW_INT16") != 0;
+	k->trace_wave = getenv("SSW_GPU_TRACE_WAVE") ? env_is("SSW_GPU_TRACE_WAVE", '1') : -1;
+	k->trace_no_lds = env_is("SSW_GPU_TRACE_LDS", '0');
+	{ const int v = env_int("SSW_GPU_TRACE_WAVES", 0); k->trace_waves = v == 1 || v == 4 || v == 16 ? v : 0; }
+	k->trace_unblocked = env_is("SSW_GPU_TRACE_BLOCKED", '0');
+	k->serial_buckets = env_is("SSW_GPU_SERIAL_BUCKETS", '1');
+	k->no_dbx = env_is("SSW_GPU_NO_DBX", '1');
+	{ const int v = env_int("SSW_GPU_DB_TSUB", 0); k->db_tsub = v > 0 ? v : 0; }
+	{ const int v = env_int("SSW_GPU_DBX_SLAB", 0); k->dbx_slab = v > 0 ? v : 0; }
+}
 
 #include <time.h>
 static double dbg_ms(void)      /* wall clock for the SSW_GPU_DEBUG progress lines */
@@ -119,6 +179,11 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
 		ssw_gpu_close(c);      /* destroys whatever was created (NULL handles are skipped) */
 		return 0;
 	}
+	knobs_load(&c->kn);
+	/* geometry of the device the launches are sized for: a partitioned (CPX / DPX) MI355X reports fewer compute units than the 256 of
+	   the whole chip, and launches sized for 256 would leave its last round of workgroups half empty */
+	c->dev_cus = 256; c->dev_wave_slots = 2048;
+	{ int cus = 0, wpc = 0; if (ssw_shim_device_props(&cus, &wpc) == 0 && cus > 0) { c->dev_cus = cus; c->dev_wave_slots = cus * 8; } }
 	const char* e = getenv("SSW_GPU_CM_BUDGET_MB");
 	/* scratch budget (column maxima, boundary records, traceback scratch).  The DEFAULT assumes nothing about who else uses the device: half
 	   of what is free now, at most 64 GiB -- several processes per GPU (ranks, single-pair callers) then still fit, and HIP does not refuse
@@ -154,6 +219,7 @@ int ssw_gpu_set_budget(ssw_gpu_ctx* c, size_t bytes)
 	}
 	if (bytes < ((size_t)1 << 20)) bytes = (size_t)1 << 20;
 	c->cm_budget = bytes;
+	c->budget_shrunk = 0;      /* an explicit budget starts the allocation-retry ladder afresh */
 	return 0;
 }
 size_t ssw_gpu_get_budget(const ssw_gpu_ctx* c) { return c ? c->cm_budget : 0; }
@@ -176,7 +242,8 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	if (c->stream) ssw_shim_stream_sync(c->stream);
 	for (int i = 0; i < 2; ++i) { ssw_shim_free(c->hits_d[i]); ssw_shim_host_free(c->hits_h[i]); }
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
-	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->cigar2); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand); dbuf_free(&c->tresume); dbuf_free(&c->queue); dbuf_free(&c->cands); dbuf_free(&c->sg16); dbuf_free(&c->sg8);
+	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->cigar2); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand); dbuf_free(&c->tresume); dbuf_free(&c->queue); dbuf_free(&c->cands); dbuf_free(&c->sg16); dbuf_free(&c->sg8); dbuf_free(&c->qerr);
+	dbuf_free(&c->sres); dbuf_free(&c->svq); dbuf_free(&c->svt); dbuf_free(&c->scnt);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
 	free(c->ev);
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
@@ -289,13 +356,16 @@ int ssw_gpu_last_timing(const ssw_gpu_ctx* c, ssw_gpu_timing* out) { return ssw_
    whose true scores stay <= top, picks the renormalisation period K (a power of two >= 64, K * gapE <= ~4096) and the base offset
    so that every live operand is a non-negative number below 0x7C00; returns 0 when the bucket does not fit (plain int16 form then).
    lanes = lanes per chain (16 or 64). */
-static int ssw_frame_params(int64_t top, int gapO, int gapE, int minmat, int lanes, int32_t* base, int32_t* kmask)
+static int ssw_frame_params(const ssw_knobs* kn, int64_t top, int gapO, int gapE, int minmat, int lanes, int32_t* base, int32_t* kmask)
 {
 	if (gapO <= gapE || gapE < 1) return 0;
 	int K = 1024;
-	{ const char* e = getenv("SSW_GPU_FRAME_K"); if (e && atoi(e) >= 16) { K = 16; while (K * 2 <= atoi(e) && K < 1024) K <<= 1; } }   /* tests: renormalise often */
+	if (kn->frame_k) { K = 16; while (K * 2 <= kn->frame_k && K < 1024) K <<= 1; }   /* tests: renormalise often */
 	while (K > 64 && (int64_t)K * gapE > 4096) K >>= 1;
 	const int b = (minmat < 0 ? -minmat : 0) + gapO + 2 * gapE + 8;     /* diag + score' >= 0, F - gapE >= 0, t >= 0 */
+	/* a bucket near the top of the range still fits with a shorter period (15-kb reads at match 2, proteins with a large max(mat)): halve
+	   K down to 64 before giving the bucket to the 9-instruction plain form */
+	while (K > 64 && top + b + (int64_t)(K + lanes + 2) * gapE >= 31744) K >>= 1;
 	if (top + b + (int64_t)(K + lanes + 2) * gapE >= 31744) return 0;
 	*base = b; *kmask = K - 1;
 	return 1;
@@ -325,6 +395,15 @@ static void* next_event(ssw_gpu_ctx* c)
    longer ones by their padded length P16, cut into `strips` row strips of lanes*R rows (k_chainx; lanes = 64: the
    wavefront is one chain, 16: four chains per wavefront) */
 typedef struct { int32_t R, strips, P16, lanes, use_x; int32_t first_pair, npairs; int32_t first_q, nq; } bucket;
+/* tile geometry and scratch of one bucket against the current target (planned before anything is launched: buckets whose launches all
+   fit the budget together run side by side on the side streams, each in its own slice of the scratch buffers) */
+typedef struct {
+	int active, dbl, seg;
+	int32_t tile, halo, ntiles;
+	int64_t maxcols, chunk;
+	size_t cm_bytes, sg_bytes, bnd_bytes, cand_bytes, q_ints, cs_ints;      /* scratch of one launch */
+	size_t cm_off, sg_off, bnd_off, cand_off, q_off, cs_off;                /* its slice when the buckets run side by side, else 0 */
+} bplan;
 typedef struct { int32_t key, q; } keyed;
 typedef struct { int32_t key, need, q; } tpend;     /* traceback negotiation: key = band (wave kernel) or scratch need */
 static int tpend_cmp(const void* a, const void* b)
@@ -349,59 +428,67 @@ static void note_fill_kernel(ssw_gpu_ctx* c, int64_t cells, int64_t* best_cells,
 	c->tm.fill_ops_per_row = ops; c->tm.fill_rows_per_lane = R; c->tm.fill_strips = strips;
 }
 
-/* the last queue launch's error word: a strip that waited for the one above it for seconds gave up (never seen; it would
-   mean a broken queue) -- checked before the queue is reused and before results are handed out */
+/* the error word of this call's work-queue launches: a strip that waited for the one above it for 30 seconds gave up (never seen; it
+   would mean a broken queue) and raised it -- checked once, before results are handed out.  One word per call, apart from the queue
+   buffers: those are reused (and zeroed) from launch to launch without a host round trip. */
 static int chainq_check(ssw_gpu_ctx* c)
 {
-	if (!c->queue_err) return 0;
+	if (!c->queue_used || !c->qerr.p) return 0;
 	int32_t e = 0;
-	const int32_t* p = c->queue_err;
-	c->queue_err = 0;
-	if (ssw_shim_d2h(&e, p, sizeof e, c->stream) || ssw_shim_stream_sync(c->stream)) return fail(c, "download failed: %s", ssw_shim_last_error());
+	c->queue_used = 0;
+	if (ssw_shim_d2h(&e, c->qerr.p, sizeof e, c->stream) || ssw_shim_stream_sync(c->stream)) return fail(c, "download failed: %s", ssw_shim_last_error());
+	if (ssw_shim_memset(c->qerr.p, 0, sizeof e, c->stream)) return fail(c, "memset failed: %s", ssw_shim_last_error());
 	return e ? fail(c, "internal error: a strip of the work queue timed out waiting for the strip above it%s", "") : 0;
 }
 
-/* work-queue launches of the 64-lane strip kernel (k_chainq): zeroed ticket counter + completion flags, one best-cell
-   record per (job, strip) item */
-static int chainq_prepare(ssw_gpu_ctx* c, ssw_chainx_args* xa, int32_t strips, int64_t jobs, int64_t slots_hint)
+/* work-queue launches of the 64-lane strip kernel (k_chainq): zeroed ticket counter + completion flags (q: items + 2 ints), one best-cell
+   record per (job, strip) item (cs: 8 ints per item); both on `stream` */
+static size_t chainq_queue_ints(int64_t items) { return (size_t)(items + 2 + 3) / 4 * 4; }
+static size_t chainq_cands_ints(int64_t items) { return (size_t)8 * (size_t)(items > 0 ? items : 1); }
+static int chainq_setup(ssw_gpu_ctx* c, ssw_chainx_args* xa, int32_t strips, int64_t jobs, int64_t slots_hint, int32_t* q, int32_t* cs, void* stream)
 {
 	const int64_t items = jobs * strips;
-	if (chainq_check(c)) return -1;        /* error word of the previous queue launch (the buffer is about to be reused) */
-	int32_t* q = (int32_t*)ensure(c, &c->queue, sizeof(int32_t) * (size_t)(items + 2));
-	int32_t* cs = (int32_t*)ensure(c, &c->cands, sizeof(int32_t) * 8 * (size_t)(items > 0 ? items : 1));
-	if (!q || !cs) return -1;
-	if (ssw_shim_memset(q, 0, sizeof(int32_t) * (size_t)(items + 2), c->stream)) return fail(c, "memset failed: %s", ssw_shim_last_error());
-	xa->strips = strips; xa->queue = q; xa->cand_strip = cs;
-	c->queue_err = q + 1 + items;
+	if (!c->qerr.p) {
+		if (!ensure(c, &c->qerr, 16) || ssw_shim_memset(c->qerr.p, 0, 16, c->stream) || ssw_shim_stream_sync(c->stream)) return fail(c, "memset failed: %s", ssw_shim_last_error());
+	}
+	if (ssw_shim_memset(q, 0, sizeof(int32_t) * (size_t)(items + 2), stream)) return fail(c, "memset failed: %s", ssw_shim_last_error());
+	xa->strips = strips; xa->queue = q; xa->cand_strip = cs; xa->err = (int32_t*)c->qerr.p;
+	c->queue_used = 1;
 	/* strip-level tickets pay off when there are more jobs than wavefront slots (the last round of whole jobs would leave slots
 	   idle); with fewer jobs every wavefront keeps its job: SSW_GPU_QUEUE=strips / jobs forces one or the other */
 	{
-		const char* e = getenv("SSW_GPU_QUEUE");
-		const int64_t slots = slots_hint > 0 ? slots_hint : 2048;
-		xa->whole_jobs = e && e[0] == 'j' ? 1 : e && e[0] == 's' ? 0 : jobs <= slots;
+		const int64_t slots = slots_hint > 0 ? slots_hint : (c->dev_wave_slots > 0 ? c->dev_wave_slots : 2048);
+		xa->whole_jobs = c->kn.queue_mode == 1 ? 1 : c->kn.queue_mode == 2 ? 0 : jobs <= slots;
 	}
 	return 0;
 }
+static int chainq_prepare(ssw_gpu_ctx* c, ssw_chainx_args* xa, int32_t strips, int64_t jobs, int64_t slots_hint)
+{
+	const int64_t items = jobs * strips;
+	int32_t* q = (int32_t*)ensure(c, &c->queue, sizeof(int32_t) * chainq_queue_ints(items));
+	int32_t* cs = (int32_t*)ensure(c, &c->cands, sizeof(int32_t) * chainq_cands_ints(items));
+	if (!q || !cs) return -1;
+	return chainq_setup(c, xa, strips, jobs, slots_hint, q, cs, c->stream);
+}
 
 /* wavefronts of the persistent launch: what the device holds at once (a wavefront that finds the queue empty just ends) */
-static int chainq_grid(int R, int capture, int n)
+static int chainq_grid(const ssw_gpu_ctx* c, int R, int capture, int n)
 {
-	const char* e = getenv("SSW_GPU_QUEUE_WAVES");
-	if (e && atoi(e) > 0) return atoi(e);
+	if (c->kn.queue_waves > 0) return c->kn.queue_waves;
 	const int res = ssw_shim_chainq_resident(R, capture, n);
-	if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] k_chainq<%d,%s>: %d wavefronts resident on the device\n", R, capture ? "window" : "fill", res);
+	if (c->kn.debug) fprintf(stderr, "[ssw_gpu] k_chainq<%d,%s>: %d wavefronts resident on the device\n", R, capture ? "window" : "fill", res);
 	return res > 0 ? res : 4096;
 }
 
 static int launch_window_pass(ssw_gpu_ctx* c, int32_t R, int32_t lanes, int32_t strips, ssw_chainx_args* xa, int32_t n)
 {
 	if (lanes != 64) return ssw_shim_launch_chainx(R, 1, xa, c->stream);
-	const int qgrid = chainq_grid(R, 1, n);
+	const int qgrid = chainq_grid(c, R, 1, n);
 	if (chainq_prepare(c, xa, strips, ((int64_t)xa->njobs + 1) / 2, qgrid)) return -1;
-	if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] chainq window pass (reverse %d): R %d, %d queries x %d strips, %d wavefronts, %s tickets, form %d\n",
+	if (c->kn.debug) fprintf(stderr, "[ssw_gpu] chainq window pass (reverse %d): R %d, %d queries x %d strips, %d wavefronts, %s tickets, form %d\n",
 	                                     xa->reverse, R, xa->njobs, strips, qgrid, xa->whole_jobs ? "job" : "strip", xa->form);
 	const int rc = ssw_shim_launch_chainq(R, 1, xa, qgrid, c->stream);
-	if (getenv("SSW_GPU_DEBUG")) { const int src = ssw_shim_stream_sync(c->stream); fprintf(stderr, "[ssw_gpu] chainq window pass done (sync rc %d: %s)\n", src, src ? ssw_shim_last_error() : "ok"); }
+	if (c->kn.debug) { const int src = ssw_shim_stream_sync(c->stream); fprintf(stderr, "[ssw_gpu] chainq window pass done (sync rc %d: %s)\n", src, src ? ssw_shim_last_error() : "ok"); }
 	return rc;
 }
 
@@ -432,9 +519,29 @@ typedef struct {
 #define DB_COUNTERS 4                   /* [0] 16-bit-rule alignments, [1] 8-bit-rule, [2] workgroups of k_filldb that repeated in the int16 form */
 
 
+/* Flagged database search (round 4): begin positions / CIGARs against MANY targets in one batch call -- the reference's loop calls
+   ssw_align with flag 2 and a score filter for every (read, target) pair (src/main.c:493-506; gating src/ssw.c:916, 938).  Scores and end
+   positions of all pairs of a chunk of targets come from k_filldb exactly as in the score-only search; k_select compacts the pairs that
+   pass ssw.c:916 into a survivor list (ordered by geometry bucket, query, target); ONE batched reverse pass per bucket and one
+   traceback negotiation then run over the survivors as (query, target) jobs (ssw_vmap) -- no per-target loop, no per-target sync. */
+typedef struct {
+	const int32_t* order; int32_t nqa;     /* non-empty queries in bucket order (host), and ... */
+	const int32_t* d_order;                /* ... on the device */
+	int32_t maxlen, maxmat, minmat, maxt;
+	int32_t xlanes, xrmax, xrcap;
+	int fill_form;
+	uint32_t** pool; int64_t* pool_words; int64_t* pool_cap;      /* the call's host CIGAR pool */
+	double locate_ms, trace_ms;
+	int64_t survivors;
+	/* survivors of the current chunk, on the host after dbx_chunk */
+	ssw_dres* hs; int32_t* hvq; int32_t* hvt; int64_t* hpo; int32_t ns; size_t hcap;
+} dbx_state;
+static int dbx_chunk(ssw_gpu_ctx* c, dbx_state* dx, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, const ssw_gpu_params* prm, const bucket* bk, int nb,
+                     const int8_t* d_mat, struct ssw_out_rec* d_out, int32_t tbase, int32_t nt);
+
 static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
                     const ssw_gpu_params* prm, ssw_gpu_result* results, const bucket* bk, int nb, const ssw_pair* d_pairs,
-                    const int8_t* d_mat, int32_t bias, int32_t maxtlen, const uint8_t* qdone, db_stream* ds)
+                    const int8_t* d_mat, int32_t bias, int32_t maxtlen, const uint8_t* qdone, db_stream* ds, dbx_state* dx)
 {
 	const int32_t nq = Q->count, n = prm->n;
 	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
@@ -478,7 +585,9 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 	}
 	/* result records of a sub-batch of targets stay in HBM until the sub-batch is done */
 	int64_t tsub = (int64_t)(c->cm_budget / 2) / ((int64_t)nq * (int64_t)sizeof(ssw_dres));
+	if (dx) tsub = (int64_t)(c->cm_budget / 4) / ((int64_t)nq * (int64_t)sizeof(struct ssw_out_rec));
 	if (tsub < 16) tsub = 16;
+	if (c->kn.db_tsub) tsub = c->kn.db_tsub;
 	if (ds) tsub = ds->chunk;
 	if (tsub > tcount) tsub = tcount;
 	int32_t* d_tl_all = (int32_t*)ensure(c, &c->tlist, sizeof(int32_t) * (size_t)tcount);     /* every sub-batch has its own slice (uploads stay in flight) */
@@ -486,8 +595,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 	const int nch = SSW_DB_NCH;
 	/* column-frame form of the recurrence wherever a size class's scores leave room for the frame offsets below 31744 (always, for the
 	   matrices and lengths this path admits with sane gap penalties); SSW_GPU_DB_FORM=0 (tests) keeps the plain int16 form */
-	int use_fr = 1;
-	{ const char* e = getenv("SSW_GPU_DB_FORM"); if (e && e[0] == '0') use_fr = 0; }
+	const int use_fr = !c->kn.db_plain;
 	int32_t db_minmat = 0, db_maxmat = 0;
 	for (int32_t i = 0; i < n * n; ++i) { if (prm->mat[i] < db_minmat) db_minmat = prm->mat[i]; if (prm->mat[i] > db_maxmat) db_maxmat = prm->mat[i]; }
 	int db_form[64]; memset(db_form, 0, sizeof db_form);
@@ -505,6 +613,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		   downloaded straight into the caller's array (no host-side conversion pass over nq x nt records) */
 		int direct = nt == tcount && !ds;
 		for (int32_t q = 0; q < nq && direct; ++q) if (!qdone[q]) direct = 0;
+		if (dx) direct = 1;      /* final-layout records per chunk; rows of queries that are not handled here stay empty records (the per-target path fills them in later) */
 		ssw_dres* d_res = 0; struct ssw_out_rec* d_out = 0; int32_t* d_cnt = 0; struct ssw_hit_rec* d_hits = 0;
 		const int buf = chunk_i & 1;
 		if (ds) {      /* all-zero bytes ARE the empty compact record (score 0, ends 0): empty queries / targets need no patching */
@@ -575,7 +684,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 				uint32_t* d_cm16 = d_cm16_all + (need / 4) * sx;
 				uint32_t* d_cm8 = d_cm8_all + (need / 4) * sx;
 				int32_t fr_base = 0, fr_kmask = 0;
-				const int fr = use_fr && ssw_frame_params((int64_t)B->P16 * db_maxmat, prm->gapO, prm->gapE, db_minmat, 16, &fr_base, &fr_kmask);
+				const int fr = use_fr && ssw_frame_params(&c->kn, (int64_t)B->P16 * db_maxmat, prm->gapO, prm->gapE, db_minmat, 16, &fr_base, &fr_kmask);
 				if (b < 64) db_form[b] = fr;
 				for (int32_t p0 = 0; p0 < B->npairs; p0 += (int32_t)ppl)
 				for (int32_t k0 = 0; k0 < nz; k0 += (int32_t)per) {
@@ -584,8 +693,8 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 					fa.tfirst = tfirst + t0; fa.res_nt = nt; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off; fa.pairs = bpairs + B->first_pair + p0;
 					fa.npairs = B->npairs - p0 < ppl ? B->npairs - p0 : (int32_t)ppl; fa.mat = d_mat; fa.n = n; fa.gapO2 = gapO2; fa.gapE2 = gapE2; fa.cm16 = d_cm16; fa.cm8 = d_cm8;
 					fa.cm_stride = stride; fa.maskLen = prm->maskLen; fa.bias = bias; fa.score_size = prm->score_size; fa.res = d_res; fa.out = d_out; fa.counters = d_cnt;
-					fa.hits = d_hits; fa.form = fr; fa.fr_base = fr_base; fa.fr_kmask = fr_kmask;
-					{ const char* e = getenv("SSW_GPU_DB_CHAIN_BEST"); fa.chain_best = !(e && e[0] == '0'); }
+					fa.hits = d_hits; fa.form = fr; fa.fr_base = fr_base; fa.fr_kmask = fr_kmask; fa.mark_word = dx != 0;
+					fa.chain_best = c->kn.db_chain_best;
 					if (ssw_shim_launch_filldb(B->R, &fa, st)) { fail(c, "filldb launch failed: %s", ssw_shim_last_error()); goto done; }
 					int64_t lc = 0;
 					for (int32_t k = 0; k < fa.ntl; ++k)
@@ -616,20 +725,39 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 		}
 		if (direct) {
 			int32_t cnt[DB_COUNTERS] = { 0, 0, 0, 0 };
-			if (ssw_shim_d2h(results, d_out, sizeof(struct ssw_out_rec) * (size_t)nq * (size_t)nt, c->stream) ||
-			    ssw_shim_d2h(cnt, d_cnt, sizeof cnt, c->stream) || ssw_shim_stream_sync(c->stream)) {
+			if (dx) {      /* survivors of this chunk: reverse pass, traceback, CIGARs in the host pool.  (The counters first: the phases below regrow c->need.) */
+				if (ssw_shim_d2h(cnt, d_cnt, sizeof cnt, c->stream) || ssw_shim_stream_sync(c->stream)) { fail(c, "result download failed: %s", ssw_shim_last_error()); goto done; }
+				if (dbx_chunk(c, dx, Q, T, prm, bk, nb, d_mat, d_out, tfirst + t0, nt)) goto done;
+			}
+			if (nt == tcount) {
+				if (ssw_shim_d2h(results, d_out, sizeof(struct ssw_out_rec) * (size_t)nq * (size_t)nt, c->stream)) { fail(c, "result download failed: %s", ssw_shim_last_error()); goto done; }
+			} else {      /* a chunk of the targets: every query's slice of the chunk goes to its row */
+				for (int32_t q = 0; q < nq; ++q)
+					if (ssw_shim_d2h(&results[(int64_t)q * tcount + t0], d_out + (int64_t)q * nt, sizeof(struct ssw_out_rec) * (size_t)nt, c->stream)) {
+						fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
+					}
+			}
+			if ((!dx && ssw_shim_d2h(cnt, d_cnt, sizeof cnt, c->stream)) || ssw_shim_stream_sync(c->stream)) {
 				fail(c, "result download failed: %s", ssw_shim_last_error()); goto done;
 			}
 			c->tm.n_word += cnt[0]; c->tm.n_byte += cnt[1]; c->tm.db_repeats += cnt[2];
-			int64_t qsum = Q->h_off[nq] - Q->h_off[0];
+			int64_t qsum = 0;
+			for (int32_t q = 0; q < nq; ++q) if (qdone[q]) qsum += Q->h_off[q + 1] - Q->h_off[q];      /* (the per-target path counts the cells of the others) */
 			for (int32_t k = 0; k < nt; ++k) {
-				const int64_t L = T->h_off[tfirst + k + 1] - T->h_off[tfirst + k];
+				const int64_t L = T->h_off[tfirst + t0 + k + 1] - T->h_off[tfirst + t0 + k];
 				c->tm.cells += qsum * L;
-				if (L == 0) for (int32_t q = 0; q < nq; ++q) { ssw_gpu_result* o = &results[(int64_t)q * tcount + k]; o->ref_begin1 = -1; o->read_begin1 = -1; o->cigar_off = -1; }
+				if (L == 0) for (int32_t q = 0; q < nq; ++q) { ssw_gpu_result* o = &results[(int64_t)q * tcount + t0 + k]; o->ref_begin1 = -1; o->read_begin1 = -1; o->cigar_off = -1; }
 			}
 			for (int32_t q = 0; q < nq; ++q)      /* empty queries: no kernel wrote their rows */
 				if (Q->h_off[q + 1] == Q->h_off[q])
-					for (int32_t k = 0; k < nt; ++k) { ssw_gpu_result* o = &results[(int64_t)q * tcount + k]; o->ref_begin1 = -1; o->read_begin1 = -1; o->cigar_off = -1; }
+					for (int32_t k = 0; k < nt; ++k) { ssw_gpu_result* o = &results[(int64_t)q * tcount + t0 + k]; o->ref_begin1 = -1; o->read_begin1 = -1; o->cigar_off = -1; }
+			if (dx)      /* what the reverse pass and the traceback added to the survivors' records */
+				for (int32_t v = 0; v < dx->ns; ++v) {
+					const ssw_dres* r = &dx->hs[v];
+					ssw_gpu_result* o = &results[(int64_t)dx->hvq[v] * tcount + (dx->hvt[v] - tfirst)];
+					o->ref_begin1 = r->ref_begin1; o->read_begin1 = r->read_begin1; o->cigarLen = r->cigarLen; o->flag = (uint16_t)r->flag;
+					o->edit_distance = r->nm; o->cigar_off = r->cigarLen > 0 ? dx->hpo[v] : -1;
+				}
 			continue;
 		}
 		if (!hres) {     /* only the sub-batched path converts records on the host (the direct path downloads final-layout records) */
@@ -675,6 +803,398 @@ done:
 	return rc;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Window passes of one geometry bucket over the jobs in d_list[0 .. cnt): pass 0 locates read_end1 where the fill did not track it
+ * (reference src/ssw.c:342-351), pass 1 is the reverse pass that finds the begin position (ssw_align 919-935).  Used by the
+ * per-target path (jobs = queries against d_tgt) and by the flagged database search (jobs = survivor pairs, vm set).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+	const ssw_gpu_seqs* Q; const ssw_gpu_params* prm;
+	const int8_t* d_tgt; int32_t refLen;      /* the target (vm unset), or the longest target (vm set): bounds the window */
+	ssw_vmap vm;
+	const int8_t* d_mat; int32_t n, maxmat, minmat;
+	int fill_form;
+	ssw_dres* d_res;
+	int32_t xlanes, xrmax, xrcap;
+} win_in;
+
+static int window_pass(ssw_gpu_ctx* c, const win_in* wi, const bucket* B, int pass, const int32_t* d_list, int32_t cnt)
+{
+	const ssw_gpu_seqs* Q = wi->Q; const ssw_gpu_params* prm = wi->prm;
+	const int32_t n = wi->n, maxmat = wi->maxmat, refLen = wi->refLen;
+	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
+	if (cnt <= 0) return 0;
+	/* short-query buckets whose four per-chain profiles would not fit the LDS of a workgroup (alphabets near 32
+	   symbols with many rows per lane) take the strip kernel's window mode: one profile per wavefront */
+	const int cap_x = B->use_x || ssw_shim_capture_lds_need(B->R, n) > SSW_LDS_LIMIT;
+	const int32_t capRmax = wi->xrcap < wi->xrmax ? wi->xrcap : wi->xrmax;
+	const int32_t capR = B->use_x ? (B->lanes == 64 && B->R > capRmax ? capRmax : B->R) : ((B->P16 + 63) / 64 < capRmax ? (B->P16 + 63) / 64 : capRmax),
+	              capL = B->use_x ? B->lanes : wi->xlanes;
+	if (cap_x) {
+		const int32_t hw = halo_for(B->P16, maxmat, prm->gapE);
+		const int64_t wcols = (((int64_t)(hw < refLen ? hw : refLen) + 1) + 31) / 16 * 16;
+		int64_t per = (int64_t)(c->cm_budget / (size_t)(16 * wcols)); if (per < 1) per = 1;
+		for (int32_t q0 = 0; q0 < cnt; q0 += (int32_t)per) {
+			const int32_t cnt_q = cnt - q0 < per ? cnt - q0 : (int32_t)per;
+			uint32_t* d_bnd = (uint32_t*)ensure(c, &c->bnd, (size_t)(16 * wcols * cnt_q));
+			if (!d_bnd) return -1;
+			ssw_chainx_args xa; memset(&xa, 0, sizeof xa);
+			xa.tgt = wi->d_tgt; xa.refLen = refLen; xa.qcodes = Q->d_codes; xa.qoff = Q->d_off; xa.mat = wi->d_mat; xa.n = n;
+			xa.gapO2 = gapO2; xa.gapE2 = gapE2; xa.gapE = prm->gapE; xa.maxmat = maxmat; xa.njobs = cnt_q;
+			xa.qlist = d_list + q0; xa.reverse = pass; xa.flag = prm->flag; xa.filters = prm->filters;
+			xa.filterd = prm->filterd; xa.res = wi->d_res; xa.bnd = d_bnd; xa.bnd_stride = wcols; xa.lanes = capL; xa.vm = wi->vm;
+			/* reverse pass: a window of rows + 25 % almost always contains the whole alignment; the exact
+			   halo bound (3x the rows for DNA defaults) is only paid by the alignments that miss */
+			int32_t* d_retry = (int32_t*)ensure(c, &c->need, 64);
+			if (!d_retry) return -1;
+			int32_t missed = 0;
+			xa.window_extra = pass ? 64 : -1; xa.retry_count = d_retry;
+			/* the window passes of the 64-lane chains in the column-frame form too, when the bucket fits its range */
+			xa.form = 0; xa.fr_base = 0; xa.fr_kmask = 0;
+			if (wi->fill_form != 0 && capL == 64 && !c->kn.window_int16 &&
+			    ssw_frame_params(&c->kn, (int64_t)B->P16 * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, wi->minmat, 64, &xa.fr_base, &xa.fr_kmask)) xa.form = 3;
+			const int32_t capS = (B->P16 + capL * capR - 1) / (capL * capR);
+			if (ssw_shim_memset(d_retry, 0, sizeof(int32_t), c->stream) ||
+			    launch_window_pass(c, capR, capL, capS, &xa, n)) return fail(c, "capture launch failed: %s", ssw_shim_last_error());
+			if (pass) {
+				if (ssw_shim_d2h(&missed, d_retry, sizeof(int32_t), c->stream) || ssw_shim_stream_sync(c->stream)) return fail(c, "download failed: %s", ssw_shim_last_error());
+				if (missed > 0) {
+					xa.window_extra = -1;
+					if (launch_window_pass(c, capR, capL, capS, &xa, n)) return fail(c, "capture launch failed: %s", ssw_shim_last_error());
+				}
+			}
+		}
+		return 0;
+	}
+	ssw_capture_args ca; memset(&ca, 0, sizeof ca);
+	ca.tgt = wi->d_tgt; ca.refLen = refLen; ca.qcodes = Q->d_codes; ca.qoff = Q->d_off; ca.qlist = d_list;
+	ca.nq = cnt; ca.mat = wi->d_mat; ca.n = n; ca.gapO2 = gapO2; ca.gapE2 = gapE2; ca.gapE = prm->gapE; ca.maxmat = maxmat;
+	ca.reverse = pass; ca.flag = prm->flag; ca.filters = prm->filters; ca.filterd = prm->filterd; ca.res = wi->d_res; ca.vm = wi->vm;
+	if (ssw_shim_launch_capture(B->R, &ca, c->stream)) return fail(c, "capture launch failed: %s", ssw_shim_last_error());
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Traceback phase (banded_sw + re-score + band retry, reference src/ssw.c:941-973) over the records d_res[0 .. nslots): the ids in
+ * `ids` are offered to the kernels (which skip records without want_cigar), CIGAR slots / resume state are indexed by id.
+ * Used by the per-target path (ids = queries against d_tgt) and by the flagged database search (ids = survivor pairs, vm set).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+	const ssw_gpu_seqs* Q; const ssw_gpu_params* prm;
+	const int8_t* d_tgt; ssw_vmap vm;
+	const int8_t* d_mat; int32_t n;
+	ssw_dres* d_res; int32_t nslots;
+	const int32_t* ids; int32_t nids;      /* host */
+	int32_t* d_list;                       /* device scratch for job lists: >= nslots ints (contents are overwritten) */
+	int32_t* hneed;                        /* host scratch: nslots ints */
+	int32_t maxlen;                        /* longest query */
+	int64_t ref_span;                      /* what the target side can add to an alignment's span: min(exact halo of maxlen, longest target) */
+} trace_in;
+typedef struct { uint32_t* d_cig; int64_t cig_stride; int did_trace; } trace_out;
+
+static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
+{
+		int64_t cig_stride = 0;
+	uint32_t* d_cig = 0;
+	int did_trace = 0;
+	const ssw_gpu_seqs* Q = ti->Q; const ssw_gpu_params* prm = ti->prm;
+	const int8_t* d_tgt = ti->d_tgt; const int8_t* d_mat = ti->d_mat; ssw_dres* d_res = ti->d_res; int32_t* d_qlist = ti->d_list; int32_t* hneed = ti->hneed;
+	const int32_t n = ti->n, nq = ti->nslots, maxlen = ti->maxlen;
+	to->d_cig = 0; to->cig_stride = 0; to->did_trace = 0;
+	if (ti->nids > 0) {
+		/* one launch over all queries; scratch sized for a band a few doublings wide, grown on demand */
+		int64_t span = (int64_t)maxlen + ti->ref_span + 8;
+		cig_stride = (span + 3) / 4 * 4;
+		d_cig = (uint32_t*)ensure(c, &c->cigar, (size_t)(4 * cig_stride * nq));
+		int32_t* d_need = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * 2 * (size_t)nq);
+		int32_t* d_resume = (int32_t*)ensure(c, &c->tresume, sizeof(int32_t) * 8 * (size_t)nq);
+		if (!d_cig || !d_need || !d_resume) return -1;
+		if (ssw_shim_memset(d_resume, 0, sizeof(int32_t) * 8 * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); return -1; }
+		int64_t sstride = ((int64_t)3 * (2 * 16 + 8) * 4 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;
+		/* long reads: one wavefront per alignment (wide bands, 10^4 rows); short reads: one thread per alignment */
+		const int use_wave = c->kn.trace_wave >= 0 ? c->kn.trace_wave : maxlen > 1024;
+		const int trace_no_lds = c->kn.trace_no_lds;     /* experiment / test: band rows in HBM scratch instead of LDS */
+		const int trace_waves_env = c->kn.trace_waves;   /* experiment / test */
+		const int trace_unblocked = c->kn.trace_unblocked;      /* experiment / test: teams with one cell per thread */
+		/* round 0: every alignment with a small scratch (band <= 16).  Alignments whose band had to grow report what
+		   they needed; later rounds run them in classes of similar need (x4 per class) with 4x headroom. */
+		tpend* pend = (tpend*)malloc(sizeof(tpend) * (size_t)nq);     /* key = band that did not fit, need in 4-KiB units, q = query */
+		int32_t* lst = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
+		int32_t* hband = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
+		if (!pend || !lst || !hband) { free(pend); free(lst); free(hband); fail(c, "out of host memory%s", ""); return -1; }
+		int32_t npend = ti->nids;
+		for (int32_t k = 0; k < ti->nids; ++k) { pend[k].key = 0; pend[k].need = 0; pend[k].q = ti->ids[k]; }
+		const int64_t full = (int64_t)maxlen + ti->ref_span;
+		const int64_t worst = (3 * (2 * full + 8) * 4 + (2 * full + 1) * (int64_t)maxlen * 3 + 64 + 15) / 16 * 16;
+		int trace_ok = 1;
+		for (int round = 0; round < 10 && npend > 0 && trace_ok; ++round) {
+			tpend* nextp = (tpend*)malloc(sizeof(tpend) * (size_t)npend);
+			int32_t nnext = 0;
+			if (!nextp) { fail(c, "out of host memory%s", ""); trace_ok = 0; break; }
+			if (round > 0) qsort(pend, (size_t)npend, sizeof(tpend), tpend_cmp);
+			if (round == 0) {
+				int64_t per_launch = (int64_t)((size_t)32 << 30) / sstride; if (per_launch < 1) per_launch = 1;
+				for (int32_t q0 = 0; q0 < npend && trace_ok; q0 += (int32_t)per_launch) {
+					const int32_t cnt_l = npend - q0 < per_launch ? npend - q0 : (int32_t)per_launch;
+					for (int32_t k = 0; k < cnt_l; ++k) lst[k] = pend[q0 + k].q;
+					uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)(sstride * cnt_l));
+					if (!d_scr) { trace_ok = 0; break; }
+					ssw_trace_args ta;
+					ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n; ta.vm = ti->vm;
+					ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = sstride; ta.soff = 0;
+					ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;     /* CIGAR slots are indexed by query */
+					ta.resume = d_resume; ta.unblocked = trace_unblocked; ta.waves = 1; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)ssw_shim_trace_lds_need(16, 1);
+					if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
+					    (use_wave ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
+					    ssw_shim_d2h(hneed, d_need, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
+					    (use_wave && ssw_shim_d2h(hband, d_need + cnt_l, sizeof(int32_t) * (size_t)cnt_l, c->stream)) ||
+					    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
+					for (int32_t k = 0; k < cnt_l; ++k)
+						if (hneed[k] != 0) {
+							if (hneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
+							nextp[nnext].key = use_wave ? hband[k] : hneed[k]; nextp[nnext].need = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
+						}
+					if (c->kn.debug) fprintf(stderr, "[ssw_gpu] %.1f ms: trace round 0: %d alignments, scratch %lld B each, %d pending so far\n",
+					                                     dbg_ms(), cnt_l, (long long)sstride, nnext);
+				}
+			} else {
+				/* every pending alignment gets a multiple of what it last needed (one or two more band doublings).  The
+				   launches of a round -- one per (LDS size, team size) class, split further by the HBM budget -- work on
+				   different alignments and different scratch: they are issued on separate streams and run side by side
+				   (each is bound by the latency of its longest alignment, not by throughput). */
+				int64_t* hoff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)npend * 2 + 2));
+				int32_t* hall = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)npend);
+				if (!hoff || !hall) { free(hoff); free(hall); free(nextp); fail(c, "out of host memory%s", ""); trace_ok = 0; break; }
+				int64_t budget = (int64_t)c->cm_budget * 2;
+				{   /* ... but not more than the device has left now (the fill's buffers stay with the context) */
+					const int64_t room = (int64_t)c->scratch.cap + (int64_t)(ssw_shim_mem_free_bytes() / 5 * 4);
+					if (room > ((int64_t)1 << 30) && budget > room) budget = room;
+				}
+				for (int32_t k = 0; k < npend; ++k) lst[k] = pend[k].q;
+				int64_t* d_soff = (int64_t*)ensure(c, &c->goff, sizeof(int64_t) * ((size_t)npend * 2 + 2));
+				if (!d_soff || ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)npend, c->stream)) { trace_ok = 0; free(hoff); free(hall); free(nextp); break; }
+				for (int32_t b0 = 0; b0 < npend && trace_ok; ) {       /* one batch = what fits the HBM budget at once */
+					struct { int32_t g0, g1, waves; int64_t lds, base, soff0; } grp[64];
+					int ngrp = 0; int64_t batch_total = 0; int32_t g0 = b0; int64_t soff_at = 0;
+					while (g0 < npend && ngrp < 64) {
+						int32_t g1 = g0; int64_t total = 0, lds_l = 0; int waves_l = 1;
+						hoff[soff_at] = 0;
+						while (g1 < npend) {
+							const int64_t nb_ = (int64_t)pend[g1].need * 4096;
+							int64_t cap_i = (nb_ * (nb_ < ((int64_t)32 << 20) ? 4 : 2) + 65536 + 15) / 16 * 16;
+							if (cap_i > worst) cap_i = worst;
+							if ((g1 > g0 || ngrp > 0) && batch_total + total + cap_i > budget) break;
+							if (use_wave) {
+								/* a band row of 2b+1 cells is walked in chunks of 64 cells per wavefront: wide bands get 4 or 16 wavefronts */
+								const int32_t b2 = pend[g1].key > (1 << 20) ? (1 << 21) : 2 * pend[g1].key;
+								int wv = b2 <= 96 ? 1 : b2 <= 256 ? 4 : 16;
+								if (trace_waves_env > 0) wv = trace_waves_env;
+								/* few LDS classes (16 KiB, 64 KiB, 128 KiB): only a handful of hardware queues run side by side */
+								int64_t l = ssw_shim_trace_lds_need(b2, wv), cls = 16384;
+								while (cls < l && cls < 131072) cls <<= (cls == 16384 ? 2 : 1);
+								if (g1 > g0 && (cls != lds_l || wv != waves_l)) break;     /* pending alignments are sorted by band: classes are contiguous */
+								lds_l = cls; waves_l = wv;
+							}
+							total += cap_i; hoff[soff_at + (g1 - g0) + 1] = total; ++g1;
+						}
+						if (g1 == g0) break;                               /* budget exhausted: next batch */
+						grp[ngrp].g0 = g0; grp[ngrp].g1 = g1; grp[ngrp].waves = waves_l; grp[ngrp].lds = lds_l;
+						grp[ngrp].base = batch_total; grp[ngrp].soff0 = soff_at; ++ngrp;
+						batch_total += total; soff_at += (g1 - g0) + 1; g0 = g1;
+					}
+					uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)batch_total);
+					if (!d_scr) { trace_ok = 0; break; }
+					if (ssw_shim_h2d(d_soff, hoff, sizeof(int64_t) * (size_t)soff_at, c->stream) || ssw_shim_event_record(c->ev_fill[0], c->stream)) {
+						fail(c, "upload failed: %s", ssw_shim_last_error()); trace_ok = 0; break;
+					}
+					/* widest bands first: they take longest, and only a few hardware queues run side by side */
+					for (int gx = 0; gx < ngrp && trace_ok; ++gx) {
+						const int gi = ngrp - 1 - gx;
+						void* st = gx == 0 ? c->stream : c->tstream[(gx - 1) % SSW_TSTREAMS];
+						const int32_t cnt_l = grp[gi].g1 - grp[gi].g0;
+						ssw_trace_args ta;
+						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist + grp[gi].g0; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n; ta.vm = ti->vm;
+						ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr + grp[gi].base; ta.scratch_stride = 0;
+						ta.soff = d_soff + grp[gi].soff0;
+						ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need + 2 * (int64_t)grp[gi].g0;
+						ta.resume = d_resume; ta.unblocked = trace_unblocked; ta.waves = grp[gi].waves; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)grp[gi].lds;
+						if (st != c->stream) ssw_shim_stream_wait_event(st, c->ev_fill[0]);
+						if (use_wave ? ssw_shim_launch_trace_wave(&ta, st) : ssw_shim_launch_trace(&ta, st)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
+						if (c->kn.debug) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, LDS %lld B x %d waves per alignment, scratch at %lld\n",
+						                                     round, cnt_l, (long long)grp[gi].lds, grp[gi].waves, (long long)grp[gi].base);
+					}
+					for (int gi = 1; gi < ngrp && gi <= SSW_TSTREAMS; ++gi)     /* the main stream continues after all of them */
+						if (ssw_shim_event_record(c->tev[gi - 1], c->tstream[gi - 1]) || ssw_shim_stream_wait_event(c->stream, c->tev[gi - 1])) trace_ok = 0;
+					if (!trace_ok) break;
+					if (ssw_shim_d2h(hall + 2 * (int64_t)b0, d_need + 2 * (int64_t)b0, sizeof(int32_t) * 2 * (size_t)(g0 - b0), c->stream) ||
+					    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
+					for (int gi = 0; gi < ngrp && trace_ok; ++gi) {
+						const int32_t cnt_l = grp[gi].g1 - grp[gi].g0;
+						const int32_t* gneed = hall + 2 * (int64_t)grp[gi].g0; const int32_t* gband = gneed + cnt_l;
+						for (int32_t k = 0; k < cnt_l; ++k)
+							if (gneed[k] != 0) {
+								if (gneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
+								nextp[nnext].key = use_wave ? gband[k] : gneed[k]; nextp[nnext].need = gneed[k]; nextp[nnext].q = lst[grp[gi].g0 + k]; ++nnext;
+							}
+					}
+					if (c->kn.debug) fprintf(stderr, "[ssw_gpu] %.1f ms: trace round %d: %d launches side by side, %lld B of scratch, %d pending so far\n",
+					                                     dbg_ms(), round, ngrp, (long long)batch_total, nnext);
+					b0 = g0;
+				}
+				free(hoff); free(hall);
+			}
+			did_trace = 1;
+			free(pend); pend = nextp; npend = nnext;
+		}
+		free(pend); free(lst); free(hband);
+		if (!trace_ok) return -1;
+		if (npend > 0) { fail(c, "internal error: traceback scratch negotiation did not converge%s", ""); return -1; }
+	}
+	if (did_trace && prm->mark_mismatch) {   /* SAM-style CIGARs + edit distance, rewritten on the device */
+		const int64_t m_stride = (cig_stride + maxlen + 8 + 3) / 4 * 4;
+		uint32_t* d_cig2 = (uint32_t*)ensure(c, &c->cigar2, (size_t)(4 * m_stride * nq));
+		if (!d_cig2) return -1;
+		ssw_mark_args ma; ma.tgt = d_tgt; ma.qcodes = Q->d_codes; ma.qoff = Q->d_off; ma.nq = nq; ma.res = d_res; ma.cigar = d_cig; ma.vm = ti->vm;
+		ma.out = d_cig2; ma.out_stride = m_stride;
+		if (ssw_shim_launch_mark(&ma, c->stream)) { fail(c, "mark launch failed: %s", ssw_shim_last_error()); return -1; }
+		d_cig = d_cig2;
+	}
+	to->d_cig = d_cig; to->cig_stride = cig_stride; to->did_trace = did_trace;
+	return 0;
+}
+
+static int dbx_chunk(ssw_gpu_ctx* c, dbx_state* dx, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, const ssw_gpu_params* prm, const bucket* bk, int nb,
+                     const int8_t* d_mat, struct ssw_out_rec* d_out, int32_t tbase, int32_t nt)
+{
+	const int32_t nk = dx->nqa;
+	const int64_t npairs = (int64_t)nk * nt;
+	dx->ns = 0;
+	if (npairs <= 0) return 0;
+	if (npairs > 0x7fffff00) return fail(c, "align_batch: %s", "more than 2^31 (query, target) pairs in one chunk of a flagged database search (lower the scratch budget)");
+	const int32_t nblk = (int32_t)((npairs + 255) / 256);
+	/* counters: [nblk + 1] block counts / offsets, [nb + 1] first survivor of every bucket; then the buckets' linear start indices */
+	const size_t ints = (size_t)nblk + 1 + (size_t)nb + 1;
+	int32_t* d_cnt = (int32_t*)ensure(c, &c->scnt, sizeof(int32_t) * ((ints + 1) / 2 * 2) + sizeof(int64_t) * ((size_t)nb + 1));
+	int64_t* hlin = (int64_t*)malloc(sizeof(int64_t) * ((size_t)nb + 1));
+	int32_t* hfirst = (int32_t*)malloc(sizeof(int32_t) * ((size_t)nb + 2));
+	if (!d_cnt || !hlin || !hfirst) { free(hlin); free(hfirst); return d_cnt ? fail(c, "out of host memory%s", "") : -1; }
+	int32_t* d_first = d_cnt + nblk + 1;
+	int64_t* d_lin = (int64_t*)(d_cnt + (ints + 1) / 2 * 2);
+	for (int b = 0; b < nb; ++b) hlin[b] = (int64_t)bk[b].first_q * nt;
+	hlin[nb] = npairs;
+	int rc = -1;
+	ssw_select_args sa; memset(&sa, 0, sizeof sa);
+	sa.out = d_out; sa.order = dx->d_order; sa.nk = nk; sa.nt = nt; sa.tbase = tbase; sa.flag = prm->flag; sa.filters = prm->filters;
+	sa.blk = d_cnt; sa.nblk = nblk; sa.bucket_lin = d_lin; sa.nbk = nb; sa.bucket_first = d_first;
+	int32_t ns = 0;
+	ssw_shim_event_record(c->ev_a, c->stream);
+	sa.pass = 0;
+	if (ssw_shim_h2d(d_lin, hlin, sizeof(int64_t) * ((size_t)nb + 1), c->stream) || ssw_shim_memset(d_first, 0, sizeof(int32_t) * ((size_t)nb + 1), c->stream) ||
+	    ssw_shim_launch_select(&sa, c->stream)) { fail(c, "select launch failed: %s", ssw_shim_last_error()); goto out; }
+	sa.pass = 1;
+	if (ssw_shim_launch_select(&sa, c->stream) || ssw_shim_d2h(&ns, d_cnt + nblk, sizeof ns, c->stream) || ssw_shim_stream_sync(c->stream)) {
+		fail(c, "select launch failed: %s", ssw_shim_last_error()); goto out;
+	}
+	{
+		ssw_dres* d_sres = (ssw_dres*)ensure(c, &c->sres, sizeof(ssw_dres) * (size_t)(ns > 0 ? ns : 1));
+		int32_t* d_maps = (int32_t*)ensure(c, &c->svq, sizeof(int32_t) * 4 * (size_t)(ns > 0 ? ns : 1));      /* vq, vt, identity list, traceback job lists */
+		if (!d_sres || !d_maps) goto out;
+		int32_t* d_vq = d_maps; int32_t* d_vt = d_maps + ns; int32_t* d_vl = d_maps + 2 * (size_t)ns; int32_t* d_tl = d_maps + 3 * (size_t)ns;
+		sa.pass = 2; sa.sres = d_sres; sa.svq = d_vq; sa.svt = d_vt; sa.vlist = d_vl; sa.cap = ns;
+		if (ssw_shim_launch_select(&sa, c->stream) || ssw_shim_d2h(hfirst, d_first, sizeof(int32_t) * ((size_t)nb + 1), c->stream) || ssw_shim_stream_sync(c->stream)) {
+			fail(c, "select launch failed: %s", ssw_shim_last_error()); goto out;
+		}
+		hfirst[nb] = ns;
+		for (int b = nb - 1; b >= 0; --b) if (hlin[b] >= npairs || bk[b].nq == 0) hfirst[b] = hfirst[b + 1];      /* (a start index past the last pair is never visited) */
+		dx->survivors += ns;
+		if (c->kn.debug) fprintf(stderr, "[ssw_gpu] %.1f ms: flagged database search: targets %d..%d, %d of %lld pairs go on to the reverse pass\n",
+		                         dbg_ms(), tbase, tbase + nt - 1, ns, (long long)npairs);
+		if (ns == 0) { rc = 0; goto out; }
+		if ((size_t)ns > dx->hcap) {
+			free(dx->hs); free(dx->hvq); free(dx->hvt); free(dx->hpo);
+			dx->hcap = (size_t)ns + (size_t)ns / 4 + 64;
+			dx->hs = (ssw_dres*)malloc(sizeof(ssw_dres) * dx->hcap); dx->hvq = (int32_t*)malloc(sizeof(int32_t) * dx->hcap);
+			dx->hvt = (int32_t*)malloc(sizeof(int32_t) * dx->hcap); dx->hpo = (int64_t*)malloc(sizeof(int64_t) * dx->hcap);
+			if (!dx->hs || !dx->hvq || !dx->hvt || !dx->hpo) { dx->hcap = 0; fail(c, "out of host memory%s", ""); goto out; }
+		}
+		ssw_vmap vm; vm.vq = d_vq; vm.vt = d_vt; vm.tcodes = T->d_codes; vm.toff = T->d_off;
+		/* ---- reverse pass (begin positions), one launch per geometry bucket that has survivors; read_end1 came with the search */
+		win_in wi; memset(&wi, 0, sizeof wi);
+		wi.Q = Q; wi.prm = prm; wi.d_tgt = T->d_codes; wi.refLen = dx->maxt; wi.d_mat = d_mat; wi.n = prm->n; wi.maxmat = dx->maxmat; wi.minmat = dx->minmat;
+		wi.fill_form = dx->fill_form; wi.xlanes = dx->xlanes; wi.xrmax = dx->xrmax; wi.xrcap = dx->xrcap;
+		for (int b = 0; b < nb; ++b) {
+			const int32_t f0 = hfirst[b], cntb = hfirst[b + 1] - hfirst[b];
+			if (cntb <= 0) continue;
+			wi.d_res = d_sres + f0; wi.vm = vm; wi.vm.vq = d_vq + f0; wi.vm.vt = d_vt + f0;
+			if (window_pass(c, &wi, &bk[b], 1, d_vl, cntb)) goto out;
+		}
+		ssw_shim_event_record(c->ev_b, c->stream);
+		/* ---- traceback over slabs of survivors (a slab = the CIGAR slots that fit half the budget), CIGARs into the host pool */
+		if (ssw_shim_d2h(dx->hvq, d_vq, sizeof(int32_t) * (size_t)ns, c->stream) || ssw_shim_d2h(dx->hvt, d_vt, sizeof(int32_t) * (size_t)ns, c->stream)) {
+			fail(c, "download failed: %s", ssw_shim_last_error()); goto out;
+		}
+		const int32_t halo_max = halo_for((dx->maxlen + 15) / 16 * 16, dx->maxmat, prm->gapE);
+		const int64_t ref_span = halo_max < dx->maxt ? halo_max : dx->maxt;
+		const int64_t slot_bytes = 8 * ((int64_t)dx->maxlen + ref_span + 16) + 4 * (int64_t)dx->maxlen + 256;
+		int64_t slab = (int64_t)(c->cm_budget / 2) / slot_bytes;
+		if (slab < 1024) slab = 1024;
+		if (c->kn.dbx_slab) slab = c->kn.dbx_slab;
+		int32_t* ids = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ns < slab ? ns : slab));
+		int32_t* hneed = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ns < slab ? ns : slab));
+		int64_t* goffs = (int64_t*)malloc(sizeof(int64_t) * (size_t)(ns < slab ? ns : slab));
+		int ok = ids && hneed && goffs;
+		if (!ok) fail(c, "out of host memory%s", "");
+		for (int32_t s0 = 0; ok && s0 < ns; s0 += (int32_t)slab) {
+			const int32_t cnt = ns - s0 < slab ? ns - s0 : (int32_t)slab;
+			trace_out tro; memset(&tro, 0, sizeof tro);
+			if ((prm->flag & 7) != 0) {
+				for (int32_t k = 0; k < cnt; ++k) ids[k] = k;
+				trace_in tri; memset(&tri, 0, sizeof tri);
+				tri.Q = Q; tri.prm = prm; tri.d_tgt = T->d_codes; tri.vm = vm; tri.vm.vq = d_vq + s0; tri.vm.vt = d_vt + s0; tri.d_mat = d_mat; tri.n = prm->n;
+				tri.d_res = d_sres + s0; tri.nslots = cnt; tri.ids = ids; tri.nids = cnt; tri.d_list = d_tl; tri.hneed = hneed; tri.maxlen = dx->maxlen; tri.ref_span = ref_span;
+				if (trace_phase(c, &tri, &tro)) { ok = 0; break; }
+			}
+			if (ssw_shim_d2h(dx->hs + s0, d_sres + s0, sizeof(ssw_dres) * (size_t)cnt, c->stream) || ssw_shim_stream_sync(c->stream)) { fail(c, "result download failed: %s", ssw_shim_last_error()); ok = 0; break; }
+			int64_t gwords = 0;
+			for (int32_t k = 0; k < cnt; ++k) {
+				const ssw_dres* r = &dx->hs[s0 + k];
+				if (r->status >= 2) { fail(c, "internal error: window pass did not reproduce the forward score%s", ""); ok = 0; break; }
+				goffs[k] = gwords; dx->hpo[s0 + k] = *dx->pool_words + gwords;
+				if (r->cigarLen > 0 && r->status == 0) gwords += r->cigarLen;
+			}
+			if (!ok) break;
+			if (gwords > 0) {
+				int64_t* d_goff = (int64_t*)ensure(c, &c->goff, sizeof(int64_t) * (size_t)cnt);
+				uint32_t* d_gpool = (uint32_t*)ensure(c, &c->gpool, sizeof(uint32_t) * (size_t)gwords);
+				if (!d_goff || !d_gpool) { ok = 0; break; }
+				if (*dx->pool_words + gwords > *dx->pool_cap) {
+					*dx->pool_cap = (*dx->pool_words + gwords) * 2 + 1024;
+					uint32_t* npool = (uint32_t*)realloc(*dx->pool, sizeof(uint32_t) * (size_t)*dx->pool_cap);
+					if (!npool) { fail(c, "out of host memory (%s)", "CIGAR pool"); ok = 0; break; }
+					*dx->pool = npool;
+				}
+				ssw_gather_args ga; ga.src = tro.d_cig; ga.res = d_sres + s0; ga.dst_off = d_goff; ga.dst = d_gpool; ga.nq = cnt;
+				if (ssw_shim_h2d(d_goff, goffs, sizeof(int64_t) * (size_t)cnt, c->stream) || ssw_shim_launch_gather(&ga, c->stream) ||
+				    ssw_shim_d2h(*dx->pool + *dx->pool_words, d_gpool, sizeof(uint32_t) * (size_t)gwords, c->stream) || ssw_shim_stream_sync(c->stream)) {
+					fail(c, "CIGAR download failed: %s", ssw_shim_last_error()); ok = 0; break;
+				}
+				*dx->pool_words += gwords;
+			}
+		}
+		free(ids); free(hneed); free(goffs);
+		if (!ok) goto out;
+		ssw_shim_event_record(c->ev_c, c->stream);
+		if (ssw_shim_stream_sync(c->stream)) { fail(c, "stream sync failed: %s", ssw_shim_last_error()); goto out; }
+		dx->locate_ms += ssw_shim_event_elapsed_ms(c->ev_a, c->ev_b);
+		dx->trace_ms += ssw_shim_event_elapsed_ms(c->ev_b, c->ev_c);
+		dx->ns = ns;
+	}
+	rc = 0;
+out:
+	free(hlin); free(hfirst);
+	return rc;
+}
+
 static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T, int32_t tfirst, int32_t tcount,
                               const ssw_gpu_params* prm, ssw_gpu_result* results, uint32_t** cigar_pool, int64_t* cigar_words, db_stream* ds);
 
@@ -705,6 +1225,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 	if (prm->score_size < 0 || prm->score_size > 2) return fail(c, "align_batch: score_size must be 0, 1 or 2%s", "");
 	const int literal = prm->gapO <= prm->gapE;   /* layout-dependent regime of the reference: lane-model kernel (k_literal) */
 	ssw_shim_set_device(c->device);
+	knobs_load(&c->kn);
 	if (cigar_pool) *cigar_pool = 0;
 	if (cigar_words) *cigar_words = 0;
 	const int32_t nq = Q->count, n = prm->n;
@@ -756,9 +1277,9 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 	   round2_sweep_o_config4_xr*.json); the window passes, which carry two target rings and more registers, are fastest at 8 */
 	int32_t xrcap = 8;
 	{
-		const char* e = getenv("SSW_GPU_XLANES"); if (e && atoi(e) == 16) xlanes = 16;
-		e = getenv("SSW_GPU_XR"); if (e && atoi(e) >= 1 && atoi(e) <= 16) { xrmax = atoi(e); xrcap = xrmax; }
-		e = getenv("SSW_GPU_XR_WINDOW"); if (e && atoi(e) >= 1 && atoi(e) <= 16) xrcap = atoi(e);
+		if (c->kn.xlanes16) xlanes = 16;
+		if (c->kn.xr) { xrmax = c->kn.xr; xrcap = xrmax; }
+		if (c->kn.xr_window) xrcap = c->kn.xr_window;
 		/* the target rings hold profile offsets as 16-bit values: residue n (the null column) x ceil(R/4) KiB must stay below 64 KiB */
 		while (xlanes == 64 && xrmax > 4 && (int64_t)n * ((xrmax + 3) / 4) * 1024 > 65535) xrmax -= 4;
 	}
@@ -791,12 +1312,14 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 	free(keys);
 
 	int rc = -1;
+	bplan* bplans = 0;
+	int* border = (int*)malloc(sizeof(int) * (size_t)(nb > 0 ? nb : 1));      /* buckets by size (side-by-side launches go largest first) */
 	uint32_t* pool = 0; int64_t pool_words = 0, pool_cap = 0;
 	ssw_dres* hres = (ssw_dres*)malloc(sizeof(ssw_dres) * (size_t)nq);
 	int32_t* hneed = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
 	memset(&c->tm, 0, sizeof c->tm);
 	c->nev = 0;
-	if (!hres || !hneed) { fail(c, "out of host memory%s", ""); goto done; }
+	if (!hres || !hneed || !border) { fail(c, "out of host memory%s", ""); goto done; }
 
 	int8_t* d_mat = (int8_t*)ensure(c, &c->mat, (size_t)n * n);
 	ssw_pair* d_pairs = (ssw_pair*)ensure(c, &c->pairs, sizeof(ssw_pair) * (size_t)npairs_total);
@@ -810,31 +1333,48 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 
 	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
 	double fill_ms = 0, reduce_ms = 0, locate_ms = 0, trace_ms = 0;
-	int fill_form = -1;      /* tests: SSW_GPU_FILL_FORM=0 (or the older SSW_GPU_FILL_F16=0) keeps the plain int16 form everywhere */
-	{ const char* e = getenv("SSW_GPU_FILL_FORM"); if (e && e[0] == '0') fill_form = 0; }
-	{ const char* e = getenv("SSW_GPU_FILL_F16"); if (e && e[0] == '0') fill_form = 0; }
+	const int fill_form = c->kn.fill_plain ? 0 : -1;      /* tests: SSW_GPU_FILL_FORM=0 (or the older SSW_GPU_FILL_F16=0) keeps the plain int16 form everywhere */
 
 	{   /* database search: scores only, several short targets -> fused kernel for the short-query buckets */
 		int any_short = 0, any_long = 0; int64_t maxt = 0;
 		for (int b = 0; b < nb; ++b) { if (bk[b].use_x && (bk[b].P16 > 640 || (int64_t)n * 10 * 256 > 65535)) any_long = 1; else any_short = 1; }
 		for (int32_t ti = 0; ti < tcount; ++ti) { int64_t L = T->h_off[tfirst + ti + 1] - T->h_off[tfirst + ti]; if (L > maxt) maxt = L; }
-		const char* dis = getenv("SSW_GPU_NO_DB");
 		/* (k_filldb takes the column maximum of two rows with a 16-bit float max3, valid below 31744: 640 rows x max(mat) <= 49) */
-		const int db_ok = !literal && prm->flag == 0 && any_short && maxt <= 65000 && maxmat <= 49 && !(dis && dis[0] == '1');
+		/* flagged batches (begin positions / CIGARs) against several targets: the same fused search + one batched reverse pass and traceback
+		   over the pairs that pass the score filter (dbx_chunk); the survivors' window kernels read from the concatenated targets with 32-bit
+		   column indices, so the target set stays below 2^31 residues here */
+		const int use_dbx = prm->flag != 0 && !ds && !c->kn.no_dbx && tcount >= 4 && T->total < 0x7fff0000;
+		const int db_ok = !literal && (prm->flag == 0 || use_dbx) && any_short && maxt <= 65000 && maxmat <= 49 && !c->kn.no_db;
+		dbx_state dxs; memset(&dxs, 0, sizeof dxs);
+		if (use_dbx) {
+			dxs.order = order; dxs.nqa = nqa; dxs.d_order = d_qlist; dxs.maxmat = maxmat; dxs.minmat = minmat; dxs.maxt = (int32_t)(maxt > 0x7fffffff ? 0x7fffffff : maxt);
+			dxs.xlanes = xlanes; dxs.xrmax = xrmax; dxs.xrcap = xrcap; dxs.fill_form = fill_form;
+			dxs.pool = &pool; dxs.pool_words = &pool_words; dxs.pool_cap = &pool_cap;
+		}
 		if (ds && (!db_ok || any_long)) { rc = SSW_NOT_STREAMABLE; goto done; }
 		if (db_ok && (tcount >= 4 || ds)) {
 			const int mid_ok = (int64_t)n * 10 * 256 <= 65535;     /* 40 rows per lane: 10 chunks of 256 bytes per residue; n x that must stay a 16-bit offset */
-			for (int b = 0; b < nb; ++b) if (!bk[b].use_x || (bk[b].P16 <= 640 && mid_ok)) for (int32_t k = 0; k < bk[b].nq; ++k) qdone[order[bk[b].first_q + k]] = 1;
+			for (int b = 0; b < nb; ++b) if (!bk[b].use_x || (bk[b].P16 <= 640 && mid_ok)) for (int32_t k = 0; k < bk[b].nq; ++k) {
+				const int32_t qq = order[bk[b].first_q + k];
+				qdone[qq] = 1;
+				if (Q->h_off[qq + 1] - Q->h_off[qq] > dxs.maxlen) dxs.maxlen = (int32_t)(Q->h_off[qq + 1] - Q->h_off[qq]);
+			}
 			for (int32_t q = 0; q < nq; ++q) if (Q->h_off[q + 1] == Q->h_off[q]) qdone[q] = 1;     /* empty queries: empty records, written there */
-			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone, ds)) goto done;
+			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone, ds, use_dbx ? &dxs : 0)) goto done;
 			d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq);   /* align_db may have regrown the record buffer */
 			if (!d_res) goto done;
+			locate_ms += dxs.locate_ms; trace_ms += dxs.trace_ms;
+			if (any_long) { free(dxs.hs); free(dxs.hvq); free(dxs.hvt); free(dxs.hpo); dxs.hs = 0; dxs.hvq = 0; dxs.hvt = 0; dxs.hpo = 0; }
 			if (!any_long) {
 				ssw_shim_event_record(c->ev_d, c->stream);
 				if (ssw_shim_stream_sync(c->stream)) { fail(c, "stream sync failed: %s", ssw_shim_last_error()); goto done; }
 				for (int e = 0; e + 1 < c->nev; e += 2) fill_ms += ssw_shim_event_elapsed_ms(c->ev[e], c->ev[e + 1]);
 				c->tm.total_ms = ssw_shim_event_elapsed_ms(c->ev_t0, c->ev_d); c->tm.fill_ms = fill_ms;
-				c->tm.reduce_ms = c->tm.total_ms - fill_ms; if (c->tm.reduce_ms < 0) c->tm.reduce_ms = 0;
+				c->tm.locate_ms = dxs.locate_ms; c->tm.trace_ms = dxs.trace_ms;
+				c->tm.reduce_ms = c->tm.total_ms - fill_ms - dxs.locate_ms - dxs.trace_ms; if (c->tm.reduce_ms < 0) c->tm.reduce_ms = 0;
+				free(dxs.hs); free(dxs.hvq); free(dxs.hvt); free(dxs.hpo);
+				if (cigar_pool) { *cigar_pool = pool; pool = 0; }
+				if (cigar_words) *cigar_words = pool_words;
 				rc = 0;
 				goto done;
 			}
@@ -878,15 +1418,29 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		}
 		if (refLen > 0 && !literal) {
 			const int64_t stride = ((int64_t)refLen + 15) / 16 * 16 + 16;
+			const int64_t seg_stride = stride / 16 + 1;
+			/* ---- plan: tile geometry and scratch of every geometry bucket.  An allocation that fails although it is within the budget
+			   (contexts of ONE process sharing a device; across processes HIP over-subscribes silently) shrinks the budget and plans
+			   again -- to a quarter the first time, a budget that only just fits leaves nothing for the rest of the call, then by
+			   halves; not when every launch is down to one pair already (a smaller budget cannot shrink them further).  The shim clears
+			   HIP's sticky error after the failed allocation, so the launches that follow a successful retry do not report it again;
+			   ssw_gpu_set_budget starts the ladder afresh.  tests/test_emu_pipeline.py runs it. */
+#define ALIGN16(x) (((size_t)(x) + 15) / 16 * 16)
+			if (!bplans) bplans = (bplan*)calloc((size_t)nb, sizeof(bplan));
+			if (!bplans) { fail(c, "out of host memory%s", ""); goto done; }
+			int max_chunk, nact, conc;
+plan_again:
+			max_chunk = 1; nact = 0;
+			size_t tot_cm = 0, tot_sg = 0, tot_bnd = 0, tot_cand = 0, tot_q = 0, tot_cs = 0;      /* all buckets side by side */
+			size_t max_cm = 0, max_sg = 0, max_bnd = 0, max_cand = 0;                              /* one bucket at a time */
+			int any_dbl = 0, any_chunked = 0;
 			for (int b = 0; b < nb; ++b) {
 				const bucket* B = &bk[b];
+				bplan* P = &bplans[b];
+				memset(P, 0, sizeof *P);
 				if (qdone[order[B->first_q]]) continue;     /* bucket already answered by the database-search path */
-				/* An allocation that fails although it is within the budget (contexts of ONE process sharing a device; across processes HIP
-				   over-subscribes silently): shrink the budget and size again -- to a quarter the first time, a budget that only just fits
-				   leaves nothing for the rest of the call, then by halves. */
-#define SSW_ALLOC_RETRY() do { if (c->cm_budget > ((size_t)512 << 20)) { c->cm_budget /= c->budget_shrunk ? 2 : 4; c->budget_shrunk = 1; c->err[0] = 0; goto size_again; } goto done; } while (0)
-size_again:;
-				const int32_t P = B->P16, halo_full = halo_for(P, maxmat, prm->gapE);
+				P->active = 1; ++nact;
+				const int32_t Pq = B->P16, halo_full = halo_for(Pq, maxmat, prm->gapE);
 				const int use_x = B->use_x;     /* long queries: strip kernel, one job per chain */
 				const int gran = use_x ? 1 : 16;     /* k_fill: one workgroup = 16 tiles of one pair */
 				int32_t tile, halo, ntiles;
@@ -912,46 +1466,104 @@ size_again:;
 				/* optional: two column-maximum buffer sets so that k_reduce of chunk i runs on a second stream beside k_fill of chunk i+1 */
 				/* measured on MI355X (config 2): overlapping costs more than it saves -- the fill runs at ~100 % VALU issue, so the
 				   reduction's waves only take slots from it (2347 ms/step with, 2160 ms without); kept as an opt-in experiment */
-				const char* ov = getenv("SSW_GPU_OVERLAP");
-				const int dbl = !use_x && chunk < B->npairs && ov && ov[0] == '1';
+				const int dbl = !use_x && chunk < B->npairs && c->kn.overlap;
 				if (dbl) chunk = (int64_t)((c->cm_budget / 2) / (size_t)per_pair);
 				if (chunk < 1) chunk = 1;
 				if (chunk > B->npairs) chunk = B->npairs;
 				if (!use_x && chunk < B->npairs) {
 					/* All workgroups of a launch do the same amount of work, so a launch is as slow as the CU that got one workgroup more
 					   than the others: the launches of a bucket get the same number of pairs (not full chunks and a remainder), and that
-					   number makes the workgroup count a multiple of the CU count (256 on MI355X: the one device this library is built
-					   for).  16 tiles per pair left 1600 workgroups per launch on a 5 Mb target: 6 or 7 per CU, 12 % lost. */
+					   number makes the workgroup count a multiple of the CU count (256 on an unpartitioned MI355X; read from the device).
+					   16 tiles per pair left 1600 workgroups per launch on a 5 Mb target: 6 or 7 per CU, 12 % lost. */
 					const int64_t bpp = (ntiles + 15) / 16, nl = (B->npairs + chunk - 1) / chunk;
 					int64_t even = (B->npairs + nl - 1) / nl;                      /* pairs per launch if all launches are alike */
-					const int64_t unit = 256 / (bpp > 256 ? 256 : bpp) > 0 ? 256 / (bpp > 256 ? 256 : bpp) : 1;      /* pairs that make 256 workgroups */
+					const int64_t ncu = c->dev_cus;
+					const int64_t unit = ncu / (bpp > ncu ? ncu : bpp) > 0 ? ncu / (bpp > ncu ? ncu : bpp) : 1;      /* pairs that make one workgroup per compute unit */
 					even = (even + unit - 1) / unit * unit;
 					if (even <= chunk) chunk = even;
 					else if (chunk >= unit) chunk = chunk / unit * unit;
 				}
-				uint32_t* d_bnd = 0; int32_t* d_cand = 0;
-				if (use_x) {
-					d_bnd = (uint32_t*)ensure(c, &c->bnd, (size_t)(16 * maxcols * ntiles * chunk));
-					d_cand = (int32_t*)ensure(c, &c->cand, (size_t)(32 * ntiles * chunk));   /* 2 halves x 4 ints per job */
-					if (!d_bnd || !d_cand) SSW_ALLOC_RETRY();
-					{ const char* nt_ = getenv("SSW_GPU_NO_TRACK"); if (nt_ && nt_[0] == '1') d_cand = 0; }   /* diagnostic: always run the locate pass */
+				P->tile = tile; P->halo = halo; P->ntiles = ntiles; P->maxcols = maxcols; P->chunk = chunk; P->dbl = dbl;
+				P->seg = !use_x && !dbl && !c->kn.no_seg_reduce;      /* short-query buckets: k_fill also leaves the maxima of 16-column groups, which is all the reduction reads */
+				P->cm_bytes = ALIGN16(4 * stride * chunk);
+				P->sg_bytes = P->seg ? ALIGN16(4 * seg_stride * chunk) : 0;
+				P->bnd_bytes = use_x ? ALIGN16(16 * maxcols * ntiles * chunk) : 0;
+				P->cand_bytes = use_x ? ALIGN16(32 * ntiles * chunk) : 0;   /* 2 halves x 4 ints per job */
+				if (use_x && B->lanes == 64) { P->q_ints = chainq_queue_ints(chunk * ntiles * B->strips); P->cs_ints = chainq_cands_ints(chunk * ntiles * B->strips); }
+				P->cm_off = tot_cm; P->sg_off = tot_sg; P->bnd_off = tot_bnd; P->cand_off = tot_cand; P->q_off = tot_q; P->cs_off = tot_cs;
+				tot_cm += P->cm_bytes; tot_sg += P->sg_bytes; tot_bnd += P->bnd_bytes; tot_cand += P->cand_bytes; tot_q += P->q_ints; tot_cs += P->cs_ints;
+				if (P->cm_bytes > max_cm) max_cm = P->cm_bytes;
+				if (P->sg_bytes > max_sg) max_sg = P->sg_bytes;
+				if (P->bnd_bytes > max_bnd) max_bnd = P->bnd_bytes;
+				if (P->cand_bytes > max_cand) max_cand = P->cand_bytes;
+				if (chunk > max_chunk) max_chunk = (int)(chunk > 0x7fffffff ? 0x7fffffff : chunk);
+				any_dbl |= dbl; any_chunked |= chunk < B->npairs;
+			}
+			/* Geometry buckets side by side (round 4).  A batch of mixed read lengths -- the reference's own benchmark: 1000 reads of 25-540 bp
+			   -- is ~30 buckets with a few pairs each; one after the other on one stream every bucket pays its own partly filled last round
+			   of workgroups and the strip kernel's few long jobs leave most of the device idle.  When every bucket is ONE launch and all of
+			   them fit the budget together, each gets its own slice of the scratch buffers and its fill + reduction go to one of the side
+			   streams; the main stream continues after all of them.  SSW_GPU_SERIAL_BUCKETS=1 keeps the old order (tests compare). */
+			conc = nact > 1 && !c->kn.serial_buckets && !any_dbl && !any_chunked && 2 * tot_cm + 2 * tot_sg + tot_bnd + tot_cand <= c->cm_budget;
+			if (!conc) for (int b = 0; b < nb; ++b) { bplan* P = &bplans[b]; P->cm_off = P->sg_off = P->bnd_off = P->cand_off = 0; P->q_off = P->cs_off = 0; }
+#define SSW_ALLOC_RETRY() do { if (c->cm_budget > ((size_t)8 << 20) && max_chunk > 1) { c->cm_budget /= c->budget_shrunk ? 2 : 4; c->budget_shrunk = 1; c->err[0] = 0; goto plan_again; } goto done; } while (0)
+			unsigned char *base_cm16 = 0, *base_cm8 = 0, *base_cmB16 = 0, *base_cmB8 = 0, *base_sg16 = 0, *base_sg8 = 0, *base_bnd = 0, *base_cand = 0;
+			int32_t *base_q = 0, *base_cs = 0;
+			if (nact > 0) {
+				base_cm16 = (unsigned char*)ensure(c, &c->cm16, conc ? tot_cm : max_cm);
+				base_cm8 = (unsigned char*)ensure(c, &c->cm8, conc ? tot_cm : max_cm);
+				if (!base_cm16 || !base_cm8) SSW_ALLOC_RETRY();
+				base_cmB16 = base_cm16; base_cmB8 = base_cm8;
+				if (any_dbl) {
+					base_cmB16 = (unsigned char*)ensure(c, &c->cm16b, max_cm); base_cmB8 = (unsigned char*)ensure(c, &c->cm8b, max_cm);
+					if (!base_cmB16 || !base_cmB8) SSW_ALLOC_RETRY();
 				}
-				uint32_t* d_cmA16 = (uint32_t*)ensure(c, &c->cm16, (size_t)(4 * stride * chunk));
-				uint32_t* d_cmA8 = (uint32_t*)ensure(c, &c->cm8, (size_t)(4 * stride * chunk));
-				uint32_t* d_cmB16 = dbl ? (uint32_t*)ensure(c, &c->cm16b, (size_t)(4 * stride * chunk)) : d_cmA16;
-				uint32_t* d_cmB8 = dbl ? (uint32_t*)ensure(c, &c->cm8b, (size_t)(4 * stride * chunk)) : d_cmA8;
-				if (!d_cmA16 || !d_cmA8 || !d_cmB16 || !d_cmB8) SSW_ALLOC_RETRY();
-				/* short-query buckets: k_fill also leaves the maxima of 16-column groups, which is all the reduction reads */
-				const int64_t seg_stride = stride / 16 + 1;
-				uint32_t *d_sg16 = 0, *d_sg8 = 0;
-				{
-					const char* e = getenv("SSW_GPU_SEG_REDUCE");
-					if (!use_x && !dbl && !(e && e[0] == '0')) {
-						d_sg16 = (uint32_t*)ensure(c, &c->sg16, (size_t)(4 * seg_stride * chunk));
-						d_sg8 = (uint32_t*)ensure(c, &c->sg8, (size_t)(4 * seg_stride * chunk));
-						if (!d_sg16 || !d_sg8) SSW_ALLOC_RETRY();
-					}
+				if (max_sg) {
+					base_sg16 = (unsigned char*)ensure(c, &c->sg16, conc ? tot_sg : max_sg); base_sg8 = (unsigned char*)ensure(c, &c->sg8, conc ? tot_sg : max_sg);
+					if (!base_sg16 || !base_sg8) SSW_ALLOC_RETRY();
 				}
+				if (max_bnd) {
+					base_bnd = (unsigned char*)ensure(c, &c->bnd, conc ? tot_bnd : max_bnd); base_cand = (unsigned char*)ensure(c, &c->cand, conc ? tot_cand : max_cand);
+					if (!base_bnd || !base_cand) SSW_ALLOC_RETRY();
+				}
+				if (conc && tot_q) {
+					base_q = (int32_t*)ensure(c, &c->queue, sizeof(int32_t) * tot_q); base_cs = (int32_t*)ensure(c, &c->cands, sizeof(int32_t) * tot_cs);
+					if (!base_q || !base_cs) SSW_ALLOC_RETRY();
+				}
+			}
+			void *ge0 = 0, *ge1 = 0; int side_used[SSW_TSTREAMS]; int nside = 0;
+			for (int sx = 0; sx < SSW_TSTREAMS; ++sx) side_used[sx] = 0;
+			if (conc) {
+				ge0 = next_event(c); ge1 = next_event(c);
+				if (ssw_shim_event_record(ge0, c->stream) || ssw_shim_event_record(c->ev_db, c->stream)) { fail(c, "event record failed: %s", ssw_shim_last_error()); goto done; }
+				/* largest bucket first: the side streams are served round-robin, and the device drains the big launches while the small ones fill its gaps */
+				for (int i = 0; i < nb; ++i) border[i] = i;
+				for (int i = 1; i < nb; ++i) {
+					const int v = border[i]; int j = i;
+					while (j > 0 && (int64_t)bk[border[j - 1]].npairs * bk[border[j - 1]].P16 < (int64_t)bk[v].npairs * bk[v].P16) { border[j] = border[j - 1]; --j; }
+					border[j] = v;
+				}
+			}
+			for (int bi_ = 0; bi_ < nb; ++bi_) {
+				const int b = conc ? border[bi_] : bi_;
+				const bucket* B = &bk[b];
+				const bplan* P = &bplans[b];
+				if (!P->active) continue;
+				const int use_x = B->use_x, dbl = P->dbl;
+				const int32_t tile = P->tile, halo = P->halo, ntiles = P->ntiles;
+				const int64_t maxcols = P->maxcols, chunk = P->chunk;
+				void* st = c->stream;
+				if (conc) {
+					const int sx = nside++ % SSW_TSTREAMS;
+					st = c->tstream[sx];
+					if (!side_used[sx]) { side_used[sx] = 1; if (ssw_shim_stream_wait_event(st, c->ev_db)) { fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; } }
+				}
+				uint32_t* d_bnd = use_x ? (uint32_t*)(base_bnd + P->bnd_off) : 0;
+				int32_t* d_cand = use_x ? (int32_t*)(base_cand + P->cand_off) : 0;
+				if (c->kn.no_track) d_cand = 0;   /* diagnostic: always run the locate pass */
+				uint32_t* d_cmA16 = (uint32_t*)(base_cm16 + P->cm_off); uint32_t* d_cmA8 = (uint32_t*)(base_cm8 + P->cm_off);
+				uint32_t* d_cmB16 = dbl ? (uint32_t*)base_cmB16 : d_cmA16; uint32_t* d_cmB8 = dbl ? (uint32_t*)base_cmB8 : d_cmA8;
+				uint32_t* d_sg16 = P->seg ? (uint32_t*)(base_sg16 + P->sg_off) : 0; uint32_t* d_sg8 = P->seg ? (uint32_t*)(base_sg8 + P->sg_off) : 0;
 				int launch_i = 0;
 				for (int32_t p0 = 0; p0 < B->npairs; p0 += (int32_t)chunk, ++launch_i) {
 					const int32_t np = B->npairs - p0 < chunk ? B->npairs - p0 : (int32_t)chunk;
@@ -967,13 +1579,13 @@ size_again:;
 					/* column-frame form of the recurrence whenever the bucket's scores leave room for the frame offsets below 31744 (no cell of
 					   the bucket scores more than its padded length x max(mat)); else plain int16 */
 					fa.form = 0; fa.fr_base = 0; fa.fr_kmask = 0;
-					if (fill_form != 0 && ssw_frame_params((int64_t)16 * B->R * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, minmat, 16, &fa.fr_base, &fa.fr_kmask)) fa.form = 3;
+					if (fill_form != 0 && ssw_frame_params(&c->kn, (int64_t)16 * B->R * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, minmat, 16, &fa.fr_base, &fa.fr_kmask)) fa.form = 3;
 					int xform = 0;
 					int32_t xfr_base = 0, xfr_kmask = 0;
 					if (fill_form != 0 && B->lanes == 64 &&
-					    ssw_frame_params((int64_t)B->P16 * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, minmat, 64, &xfr_base, &xfr_kmask)) xform = 3;
-					void* e0 = next_event(c); void* e1 = next_event(c);
-					ssw_shim_event_record(e0, c->stream);
+					    ssw_frame_params(&c->kn, (int64_t)B->P16 * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, minmat, 64, &xfr_base, &xfr_kmask)) xform = 3;
+					void *e0 = 0, *e1 = 0;
+					if (!conc) { e0 = next_event(c); e1 = next_event(c); ssw_shim_event_record(e0, st); }
 					if (use_x) {
 						ssw_chainx_args xa; memset(&xa, 0, sizeof xa);
 						xa.tgt = d_tgt; xa.refLen = refLen; xa.qcodes = Q->d_codes; xa.qoff = Q->d_off; xa.mat = d_mat; xa.n = n;
@@ -981,19 +1593,19 @@ size_again:;
 						xa.pairs = fa.pairs; xa.tile = tile; xa.halo = halo; xa.ntiles = ntiles; xa.cm16 = d_cm16; xa.cm8 = d_cm8;
 						xa.cm_stride = stride; xa.bnd = d_bnd; xa.bnd_stride = maxcols; xa.cand = d_cand; xa.lanes = B->lanes;
 						if (B->lanes == 64) {     /* strips of all jobs behind one work queue (k_chainq) */
-							const int qgrid = chainq_grid(B->R, 0, n);
-							if (chainq_prepare(c, &xa, B->strips, (int64_t)np * ntiles, qgrid)) goto done;
+							const int qgrid = chainq_grid(c, B->R, 0, n);
+							if (conc ? chainq_setup(c, &xa, B->strips, (int64_t)np * ntiles, qgrid, base_q + P->q_off, base_cs + P->cs_off, st)
+							         : chainq_prepare(c, &xa, B->strips, (int64_t)np * ntiles, qgrid)) goto done;
 							xa.form = xform; xa.fr_base = xfr_base; xa.fr_kmask = xfr_kmask;
-							if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] chainq fill: R %d, %d jobs x %d strips, %d wavefronts, %s tickets, form %d\n",
+							if (c->kn.debug) fprintf(stderr, "[ssw_gpu] chainq fill: R %d, %d jobs x %d strips, %d wavefronts, %s tickets, form %d\n",
 							                                     B->R, np * ntiles, B->strips, qgrid, xa.whole_jobs ? "job" : "strip", xa.form);
-							if (ssw_shim_launch_chainq(B->R, 0, &xa, qgrid, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
-							if (getenv("SSW_GPU_DEBUG")) { const int src = ssw_shim_stream_sync(c->stream); fprintf(stderr, "[ssw_gpu] chainq fill done (sync rc %d: %s)\n", src, src ? ssw_shim_last_error() : "ok"); }
+							if (ssw_shim_launch_chainq(B->R, 0, &xa, qgrid, st)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
+							if (c->kn.debug) { const int src = ssw_shim_stream_sync(st); fprintf(stderr, "[ssw_gpu] chainq fill done (sync rc %d: %s)\n", src, src ? ssw_shim_last_error() : "ok"); }
 						} else
-						if (ssw_shim_launch_chainx(B->R, 0, &xa, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
+						if (ssw_shim_launch_chainx(B->R, 0, &xa, st)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
 					} else
-					if (ssw_shim_launch_fill(B->R, &fa, c->stream)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
-					ssw_shim_event_record(e1, c->stream);
-					c->tm.fill_launches++;
+					if (ssw_shim_launch_fill(B->R, &fa, st)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
+					if (!conc) { ssw_shim_event_record(e1, st); c->tm.fill_launches++; }
 					{
 						int64_t cols = 0;
 						for (int32_t k = 0; k < ntiles; ++k) {
@@ -1020,239 +1632,48 @@ size_again:;
 						if (ssw_shim_launch_reduce(&ra, c->stream2)) { fail(c, "reduce launch failed: %s", ssw_shim_last_error()); goto done; }
 						ssw_shim_event_record(c->ev_red[bi], c->stream2);
 					} else
-					if (ssw_shim_launch_reduce(&ra, c->stream)) { fail(c, "reduce launch failed: %s", ssw_shim_last_error()); goto done; }
+					if (ssw_shim_launch_reduce(&ra, st)) { fail(c, "reduce launch failed: %s", ssw_shim_last_error()); goto done; }
 				}
 				if (dbl) {   /* everything later on the main stream sees all records of this bucket */
 					ssw_shim_stream_wait_event(c->stream, c->ev_red[0]);
 					if (launch_i > 1) ssw_shim_stream_wait_event(c->stream, c->ev_red[1]);
 				}
 			}
+			if (conc) {      /* the main stream continues after all of them; the group counts as one launch (its event pair brackets the side streams' work) */
+				for (int sx = 0; sx < SSW_TSTREAMS; ++sx)
+					if (side_used[sx] && (ssw_shim_event_record(c->tev[sx], c->tstream[sx]) || ssw_shim_stream_wait_event(c->stream, c->tev[sx]))) {
+						fail(c, "stream join failed: %s", ssw_shim_last_error()); goto done;
+					}
+				ssw_shim_event_record(ge1, c->stream);
+				c->tm.fill_launches++;
+			}
 		}
 		ssw_shim_event_record(c->ev_a, c->stream);
 
 		if (refLen > 0 && !literal) {   /* read_end1 always (ssw.c:342-351); begin position only when asked for (ssw.c:916) */
+			win_in wi; memset(&wi, 0, sizeof wi);
+			wi.Q = Q; wi.prm = prm; wi.d_tgt = d_tgt; wi.refLen = refLen; wi.d_mat = d_mat; wi.n = n; wi.maxmat = maxmat; wi.minmat = minmat;
+			wi.fill_form = fill_form; wi.d_res = d_res; wi.xlanes = xlanes; wi.xrmax = xrmax; wi.xrcap = xrcap;
 			for (int pass = 0; pass < (prm->flag != 0 ? 2 : 1); ++pass)
 				for (int b = 0; b < nb; ++b) {
 					const bucket* B = &bk[b];
 					if (qdone[order[B->first_q]]) continue;
-					/* short-query buckets whose four per-chain profiles would not fit the LDS of a workgroup (alphabets near 32
-					   symbols with many rows per lane) take the strip kernel's window mode: one profile per wavefront */
-					const int cap_x = B->use_x || ssw_shim_capture_lds_need(B->R, n) > SSW_LDS_LIMIT;
-					const int32_t capRmax = xrcap < xrmax ? xrcap : xrmax;
-					const int32_t capR = B->use_x ? (B->lanes == 64 && B->R > capRmax ? capRmax : B->R) : ((B->P16 + 63) / 64 < capRmax ? (B->P16 + 63) / 64 : capRmax),
-					              capL = B->use_x ? B->lanes : xlanes;
-					if (cap_x) {
-						const int32_t hw = halo_for(B->P16, maxmat, prm->gapE);
-						const int64_t wcols = (((int64_t)(hw < refLen ? hw : refLen) + 1) + 31) / 16 * 16;
-						int64_t per = (int64_t)(c->cm_budget / (size_t)(16 * wcols)); if (per < 1) per = 1;
-						for (int32_t q0 = 0; q0 < B->nq; q0 += (int32_t)per) {
-							const int32_t cnt_q = B->nq - q0 < per ? B->nq - q0 : (int32_t)per;
-							uint32_t* d_bnd = (uint32_t*)ensure(c, &c->bnd, (size_t)(16 * wcols * cnt_q));
-							if (!d_bnd) goto done;
-							ssw_chainx_args xa; memset(&xa, 0, sizeof xa);
-							xa.tgt = d_tgt; xa.refLen = refLen; xa.qcodes = Q->d_codes; xa.qoff = Q->d_off; xa.mat = d_mat; xa.n = n;
-							xa.gapO2 = gapO2; xa.gapE2 = gapE2; xa.gapE = prm->gapE; xa.maxmat = maxmat; xa.njobs = cnt_q;
-							xa.qlist = d_qlist + B->first_q + q0; xa.reverse = pass; xa.flag = prm->flag; xa.filters = prm->filters;
-							xa.filterd = prm->filterd; xa.res = d_res; xa.bnd = d_bnd; xa.bnd_stride = wcols; xa.lanes = capL;
-							/* reverse pass: a window of rows + 25 % almost always contains the whole alignment; the exact
-							   halo bound (3x the rows for DNA defaults) is only paid by the alignments that miss */
-							int32_t* d_retry = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * (size_t)nq);
-							if (!d_retry) goto done;
-							int32_t missed = 0;
-							xa.window_extra = pass ? 64 : -1; xa.retry_count = d_retry;
-							/* the window passes of the 64-lane chains in the column-frame form too, when the bucket fits its range */
-							xa.form = 0; xa.fr_base = 0; xa.fr_kmask = 0;
-							if (fill_form != 0 && capL == 64 && !getenv("SSW_GPU_WINDOW_INT16") &&
-							    ssw_frame_params((int64_t)B->P16 * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, minmat, 64, &xa.fr_base, &xa.fr_kmask)) xa.form = 3;
-							const int32_t capS = (B->P16 + capL * capR - 1) / (capL * capR);
-							if (ssw_shim_memset(d_retry, 0, sizeof(int32_t), c->stream) ||
-							    launch_window_pass(c, capR, capL, capS, &xa, n)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
-							if (pass) {
-								if (ssw_shim_d2h(&missed, d_retry, sizeof(int32_t), c->stream) || ssw_shim_stream_sync(c->stream)) { fail(c, "download failed: %s", ssw_shim_last_error()); goto done; }
-								if (missed > 0) {
-									xa.window_extra = -1;
-									if (launch_window_pass(c, capR, capL, capS, &xa, n)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
-								}
-							}
-						}
-						continue;
-					}
-					ssw_capture_args ca;
-					ca.tgt = d_tgt; ca.refLen = refLen; ca.qcodes = Q->d_codes; ca.qoff = Q->d_off; ca.qlist = d_qlist + B->first_q;
-					ca.nq = B->nq; ca.mat = d_mat; ca.n = n; ca.gapO2 = gapO2; ca.gapE2 = gapE2; ca.gapE = prm->gapE; ca.maxmat = maxmat;
-					ca.reverse = pass; ca.flag = prm->flag; ca.filters = prm->filters; ca.filterd = prm->filterd; ca.res = d_res;
-					if (ssw_shim_launch_capture(B->R, &ca, c->stream)) { fail(c, "capture launch failed: %s", ssw_shim_last_error()); goto done; }
+					if (window_pass(c, &wi, B, pass, d_qlist + B->first_q, B->nq)) goto done;
 				}
 		}
 		ssw_shim_event_record(c->ev_b, c->stream);
 
-		int64_t cig_stride = 0;
-		uint32_t* d_cig = 0;
-		int did_trace = 0;
+		/* traceback (+ SAM-style rewrite) of the alignments whose record asks for a CIGAR */
+		trace_out tro; memset(&tro, 0, sizeof tro);
 		if ((prm->flag & 7) != 0 && refLen > 0) {
-			/* one launch over all queries; scratch sized for a band a few doublings wide, grown on demand */
 			const int32_t halo_max = halo_for((maxlen + 15) / 16 * 16, maxmat, prm->gapE);
-			int64_t span = (int64_t)maxlen + (halo_max < refLen ? halo_max : refLen) + 8;
-			cig_stride = (span + 3) / 4 * 4;
-			d_cig = (uint32_t*)ensure(c, &c->cigar, (size_t)(4 * cig_stride * nq));
-			int32_t* d_need = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * 2 * (size_t)nq);
-			int32_t* d_resume = (int32_t*)ensure(c, &c->tresume, sizeof(int32_t) * 8 * (size_t)nq);
-			if (!d_cig || !d_need || !d_resume) goto done;
-			if (ssw_shim_memset(d_resume, 0, sizeof(int32_t) * 8 * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
-			int64_t sstride = ((int64_t)3 * (2 * 16 + 8) * 4 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;
-			/* long reads: one wavefront per alignment (wide bands, 10^4 rows); short reads: one thread per alignment */
-			const char* tw = getenv("SSW_GPU_TRACE_WAVE");
-			const int use_wave = tw ? tw[0] == '1' : maxlen > 1024;
-			const char* tl_ = getenv("SSW_GPU_TRACE_LDS");
-			const int trace_no_lds = tl_ && tl_[0] == '0';     /* experiment / test: band rows in HBM scratch instead of LDS */
-			const char* tv_ = getenv("SSW_GPU_TRACE_WAVES");
-			const int trace_waves_env = tv_ && (atoi(tv_) == 1 || atoi(tv_) == 4 || atoi(tv_) == 16) ? atoi(tv_) : 0;   /* experiment / test */
-			const char* tb_ = getenv("SSW_GPU_TRACE_BLOCKED");
-			const int trace_unblocked = tb_ && tb_[0] == '0';      /* experiment / test: teams with one cell per thread */
-			/* round 0: every alignment with a small scratch (band <= 16).  Alignments whose band had to grow report what
-			   they needed; later rounds run them in classes of similar need (x4 per class) with 4x headroom. */
-			tpend* pend = (tpend*)malloc(sizeof(tpend) * (size_t)nq);     /* key = band that did not fit, need in 4-KiB units, q = query */
-			int32_t* lst = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
-			int32_t* hband = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
-			if (!pend || !lst || !hband) { free(pend); free(lst); free(hband); fail(c, "out of host memory%s", ""); goto done; }
-			int32_t npend = nqa;
-			for (int32_t k = 0; k < nqa; ++k) { pend[k].key = 0; pend[k].need = 0; pend[k].q = order[k]; }
-			const int64_t full = (int64_t)maxlen + (halo_max < refLen ? halo_max : refLen);
-			const int64_t worst = (3 * (2 * full + 8) * 4 + (2 * full + 1) * (int64_t)maxlen * 3 + 64 + 15) / 16 * 16;
-			int trace_ok = 1;
-			for (int round = 0; round < 10 && npend > 0 && trace_ok; ++round) {
-				tpend* nextp = (tpend*)malloc(sizeof(tpend) * (size_t)npend);
-				int32_t nnext = 0;
-				if (!nextp) { fail(c, "out of host memory%s", ""); trace_ok = 0; break; }
-				if (round > 0) qsort(pend, (size_t)npend, sizeof(tpend), tpend_cmp);
-				if (round == 0) {
-					int64_t per_launch = (int64_t)((size_t)32 << 30) / sstride; if (per_launch < 1) per_launch = 1;
-					for (int32_t q0 = 0; q0 < npend && trace_ok; q0 += (int32_t)per_launch) {
-						const int32_t cnt_l = npend - q0 < per_launch ? npend - q0 : (int32_t)per_launch;
-						for (int32_t k = 0; k < cnt_l; ++k) lst[k] = pend[q0 + k].q;
-						uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)(sstride * cnt_l));
-						if (!d_scr) { trace_ok = 0; break; }
-						ssw_trace_args ta;
-						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
-						ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = sstride; ta.soff = 0;
-						ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;     /* CIGAR slots are indexed by query */
-						ta.resume = d_resume; ta.unblocked = trace_unblocked; ta.waves = 1; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)ssw_shim_trace_lds_need(16, 1);
-						if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
-						    (use_wave ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
-						    ssw_shim_d2h(hneed, d_need, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
-						    (use_wave && ssw_shim_d2h(hband, d_need + cnt_l, sizeof(int32_t) * (size_t)cnt_l, c->stream)) ||
-						    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
-						for (int32_t k = 0; k < cnt_l; ++k)
-							if (hneed[k] != 0) {
-								if (hneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
-								nextp[nnext].key = use_wave ? hband[k] : hneed[k]; nextp[nnext].need = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
-							}
-						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] %.1f ms: trace round 0: %d alignments, scratch %lld B each, %d pending so far\n",
-						                                     dbg_ms(), cnt_l, (long long)sstride, nnext);
-					}
-				} else {
-					/* every pending alignment gets a multiple of what it last needed (one or two more band doublings).  The
-					   launches of a round -- one per (LDS size, team size) class, split further by the HBM budget -- work on
-					   different alignments and different scratch: they are issued on separate streams and run side by side
-					   (each is bound by the latency of its longest alignment, not by throughput). */
-					int64_t* hoff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)npend * 2 + 2));
-					int32_t* hall = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)npend);
-					if (!hoff || !hall) { free(hoff); free(hall); free(nextp); fail(c, "out of host memory%s", ""); trace_ok = 0; break; }
-					int64_t budget = (int64_t)c->cm_budget * 2;
-					{   /* ... but not more than the device has left now (the fill's buffers stay with the context) */
-						const int64_t room = (int64_t)c->scratch.cap + (int64_t)(ssw_shim_mem_free_bytes() / 5 * 4);
-						if (room > ((int64_t)1 << 30) && budget > room) budget = room;
-					}
-					for (int32_t k = 0; k < npend; ++k) lst[k] = pend[k].q;
-					int64_t* d_soff = (int64_t*)ensure(c, &c->goff, sizeof(int64_t) * ((size_t)npend * 2 + 2));
-					if (!d_soff || ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)npend, c->stream)) { trace_ok = 0; free(hoff); free(hall); free(nextp); break; }
-					for (int32_t b0 = 0; b0 < npend && trace_ok; ) {       /* one batch = what fits the HBM budget at once */
-						struct { int32_t g0, g1, waves; int64_t lds, base, soff0; } grp[64];
-						int ngrp = 0; int64_t batch_total = 0; int32_t g0 = b0; int64_t soff_at = 0;
-						while (g0 < npend && ngrp < 64) {
-							int32_t g1 = g0; int64_t total = 0, lds_l = 0; int waves_l = 1;
-							hoff[soff_at] = 0;
-							while (g1 < npend) {
-								const int64_t nb_ = (int64_t)pend[g1].need * 4096;
-								int64_t cap_i = (nb_ * (nb_ < ((int64_t)32 << 20) ? 4 : 2) + 65536 + 15) / 16 * 16;
-								if (cap_i > worst) cap_i = worst;
-								if ((g1 > g0 || ngrp > 0) && batch_total + total + cap_i > budget) break;
-								if (use_wave) {
-									/* a band row of 2b+1 cells is walked in chunks of 64 cells per wavefront: wide bands get 4 or 16 wavefronts */
-									const int32_t b2 = pend[g1].key > (1 << 20) ? (1 << 21) : 2 * pend[g1].key;
-									int wv = b2 <= 96 ? 1 : b2 <= 256 ? 4 : 16;
-									if (trace_waves_env > 0) wv = trace_waves_env;
-									/* few LDS classes (16 KiB, 64 KiB, 128 KiB): only a handful of hardware queues run side by side */
-									int64_t l = ssw_shim_trace_lds_need(b2, wv), cls = 16384;
-									while (cls < l && cls < 131072) cls <<= (cls == 16384 ? 2 : 1);
-									if (g1 > g0 && (cls != lds_l || wv != waves_l)) break;     /* pending alignments are sorted by band: classes are contiguous */
-									lds_l = cls; waves_l = wv;
-								}
-								total += cap_i; hoff[soff_at + (g1 - g0) + 1] = total; ++g1;
-							}
-							if (g1 == g0) break;                               /* budget exhausted: next batch */
-							grp[ngrp].g0 = g0; grp[ngrp].g1 = g1; grp[ngrp].waves = waves_l; grp[ngrp].lds = lds_l;
-							grp[ngrp].base = batch_total; grp[ngrp].soff0 = soff_at; ++ngrp;
-							batch_total += total; soff_at += (g1 - g0) + 1; g0 = g1;
-						}
-						uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)batch_total);
-						if (!d_scr) { trace_ok = 0; break; }
-						if (ssw_shim_h2d(d_soff, hoff, sizeof(int64_t) * (size_t)soff_at, c->stream) || ssw_shim_event_record(c->ev_fill[0], c->stream)) {
-							fail(c, "upload failed: %s", ssw_shim_last_error()); trace_ok = 0; break;
-						}
-						/* widest bands first: they take longest, and only a few hardware queues run side by side */
-						for (int gx = 0; gx < ngrp && trace_ok; ++gx) {
-							const int gi = ngrp - 1 - gx;
-							void* st = gx == 0 ? c->stream : c->tstream[(gx - 1) % SSW_TSTREAMS];
-							const int32_t cnt_l = grp[gi].g1 - grp[gi].g0;
-							ssw_trace_args ta;
-							ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist + grp[gi].g0; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n;
-							ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr + grp[gi].base; ta.scratch_stride = 0;
-							ta.soff = d_soff + grp[gi].soff0;
-							ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need + 2 * (int64_t)grp[gi].g0;
-							ta.resume = d_resume; ta.unblocked = trace_unblocked; ta.waves = grp[gi].waves; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)grp[gi].lds;
-							if (st != c->stream) ssw_shim_stream_wait_event(st, c->ev_fill[0]);
-							if (use_wave ? ssw_shim_launch_trace_wave(&ta, st) : ssw_shim_launch_trace(&ta, st)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
-							if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, LDS %lld B x %d waves per alignment, scratch at %lld\n",
-							                                     round, cnt_l, (long long)grp[gi].lds, grp[gi].waves, (long long)grp[gi].base);
-						}
-						for (int gi = 1; gi < ngrp && gi <= SSW_TSTREAMS; ++gi)     /* the main stream continues after all of them */
-							if (ssw_shim_event_record(c->tev[gi - 1], c->tstream[gi - 1]) || ssw_shim_stream_wait_event(c->stream, c->tev[gi - 1])) trace_ok = 0;
-						if (!trace_ok) break;
-						if (ssw_shim_d2h(hall + 2 * (int64_t)b0, d_need + 2 * (int64_t)b0, sizeof(int32_t) * 2 * (size_t)(g0 - b0), c->stream) ||
-						    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
-						for (int gi = 0; gi < ngrp && trace_ok; ++gi) {
-							const int32_t cnt_l = grp[gi].g1 - grp[gi].g0;
-							const int32_t* gneed = hall + 2 * (int64_t)grp[gi].g0; const int32_t* gband = gneed + cnt_l;
-							for (int32_t k = 0; k < cnt_l; ++k)
-								if (gneed[k] != 0) {
-									if (gneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
-									nextp[nnext].key = use_wave ? gband[k] : gneed[k]; nextp[nnext].need = gneed[k]; nextp[nnext].q = lst[grp[gi].g0 + k]; ++nnext;
-								}
-						}
-						if (getenv("SSW_GPU_DEBUG")) fprintf(stderr, "[ssw_gpu] %.1f ms: trace round %d: %d launches side by side, %lld B of scratch, %d pending so far\n",
-						                                     dbg_ms(), round, ngrp, (long long)batch_total, nnext);
-						b0 = g0;
-					}
-					free(hoff); free(hall);
-				}
-				did_trace = 1;
-				free(pend); pend = nextp; npend = nnext;
-			}
-			free(pend); free(lst); free(hband);
-			if (!trace_ok) goto done;
-			if (npend > 0) { fail(c, "internal error: traceback scratch negotiation did not converge%s", ""); goto done; }
-			if (did_trace && ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nqa, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
+			trace_in tri; memset(&tri, 0, sizeof tri);
+			tri.Q = Q; tri.prm = prm; tri.d_tgt = d_tgt; tri.d_mat = d_mat; tri.n = n; tri.d_res = d_res; tri.nslots = nq;
+			tri.ids = order; tri.nids = nqa; tri.d_list = d_qlist; tri.hneed = hneed; tri.maxlen = maxlen; tri.ref_span = halo_max < refLen ? halo_max : refLen;
+			if (trace_phase(c, &tri, &tro)) goto done;
+			if (tro.did_trace && ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nqa, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
 		}
-		if (did_trace && prm->mark_mismatch) {   /* SAM-style CIGARs + edit distance, rewritten on the device */
-			const int64_t m_stride = (cig_stride + maxlen + 8 + 3) / 4 * 4;
-			uint32_t* d_cig2 = (uint32_t*)ensure(c, &c->cigar2, (size_t)(4 * m_stride * nq));
-			if (!d_cig2) goto done;
-			ssw_mark_args ma; ma.tgt = d_tgt; ma.qcodes = Q->d_codes; ma.qoff = Q->d_off; ma.nq = nq; ma.res = d_res; ma.cigar = d_cig;
-			ma.out = d_cig2; ma.out_stride = m_stride;
-			if (ssw_shim_launch_mark(&ma, c->stream)) { fail(c, "mark launch failed: %s", ssw_shim_last_error()); goto done; }
-			d_cig = d_cig2;
-		}
+		uint32_t* const d_cig = tro.d_cig;
 		ssw_shim_event_record(c->ev_c, c->stream);
 
 		if (chainq_check(c)) goto done;
@@ -1318,7 +1739,7 @@ size_again:;
 	if (cigar_words) *cigar_words = pool_words;
 	rc = 0;
 done:
-	free(pool); free(order); free(pairs); free(hres); free(hneed); free(bk); free(qdone);
+	free(pool); free(order); free(pairs); free(hres); free(hneed); free(bk); free(qdone); free(bplans); free(border);
 	return rc;
 }
 

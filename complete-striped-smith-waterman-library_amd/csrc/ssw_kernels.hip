@@ -35,6 +35,10 @@
 
 #define DEAD2 0x80008000u   /* packed (-32768, -32768): a score that pins H to max(E, F) */
 
+/* virtual ids (ssw_vmap, ssw_dev.h): the query whose residues job id `v` uses, and the start of its target */
+SSW_DEV int vm_query(const ssw_vmap& m, int v) { return m.vq ? m.vq[v] : v; }
+SSW_DEV const int8_t* vm_target(const ssw_vmap& m, const int8_t* tgt, int v) { return m.vq ? m.tcodes + m.toff[m.vt[v]] : tgt; }
+
 /* ------------------------------------------------------------------------------------------------
  * LDS map of one chain-group kernel:
  *   [0, prof_bytes)                      score profile(s): word ((b*C + c)*16 + l)*4 + k holds the packed
@@ -425,6 +429,7 @@ SSW_DEV void filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 		for (int k = tchunk * NCH; k <= last; ++k) { const int tt = a.tlist[k]; const int L = (int)(a.toff[tt + 1] - a.toff[tt]); maxcols = L > maxcols ? L : maxcols; }
 	}
 	const int nsteps = (maxcols + 16 + 15) & ~15;
+	const int last_step = maxcols + 15;      /* steps [0, last_step) finish every column of the longest target in every lane */
 
 	lds_st16(lds, ring + 2u * (48 + l16), nulloff);
 	{
@@ -513,8 +518,13 @@ SSW_DEV void filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 		}
 		const u32 rp = ring + 2u * (u32)((s0 - l16) & 63);
 		const u32 ob16 = out16 + 4u * ((u32)s0 & OM), ob8 = out8 + 4u * ((u32)s0 & OM);      /* lanes 15 / TAP park what they finish (k_fill) */
-#pragma unroll UNROLL
-		for (int j = 0; j < 16; ++j) {
+		/* the last column of the workgroup's longest target leaves lane 15 at step maxcols + 14: the steps up to the next multiple of 16
+		   (8 of ~330 on config 5's proteins) would only push dead columns through the chains */
+		const int jend = last_step - s0 < 16 ? (last_step - s0 + UNROLL - 1) / UNROLL * UNROLL : 16;      /* (whole groups of UNROLL steps: the unrolled body has no exit in its middle) */
+		for (int j0 = 0; j0 < jend; j0 += UNROLL)
+#pragma unroll
+		for (int ju = 0; ju < UNROLL; ++ju) {
+			const int j = j0 + ju;
 			const int tc = s0 + j - l16;
 			const u32 pa_next = lds_ld16(lds, rp + 2u * (j + 2));      /* the ring entry of step s + 2 */
 			u32 hin, f;
@@ -630,7 +640,8 @@ SSW_DEV void filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 			} else if (a.out) {
 				ssw_out_rec o;
 				o.score1 = (uint16_t)r.score1; o.score2 = (uint16_t)r.score2; o.ref_begin1 = -1; o.ref_end1 = r.ref_end1; o.read_begin1 = -1;
-				o.read_end1 = r.read_end1; o.ref_end2 = r.ref_end2; o.cigarLen = 0; o.edit_distance = 0; o.cigar_off = -1; o.flag = 0; o.status = (uint16_t)r.status;
+				o.read_end1 = r.read_end1; o.ref_end2 = r.ref_end2; o.cigarLen = 0; o.edit_distance = 0; o.cigar_off = -1; o.flag = 0;
+				o.status = (uint16_t)(r.status | (a.mark_word && r.word ? SSW_OUT_WORD : 0));
 				a.out[(int64_t)q * a.res_nt + (t - a.tfirst)] = o;
 				if (a.counters && r.status == 0 && r.score1 > 0) atomicAdd(a.counters + (r.word ? 0 : 1), 1);
 			} else a.res[(int64_t)q * a.res_nt + (t - a.tfirst)] = r;
@@ -901,8 +912,9 @@ __global__ void __launch_bounds__(64) k_capture(ssw_capture_args a)
 	int qlen = 0, plen = 0, c_edge = 0, ncols = 0, P = 16;
 	const int8_t* qc = a.qcodes;
 	if (active) {
-		qc = a.qcodes + a.qoff[q];
-		qlen = (int)(a.qoff[q + 1] - a.qoff[q]);
+		const int qs = vm_query(a.vm, q);
+		qc = a.qcodes + a.qoff[qs];
+		qlen = (int)(a.qoff[qs + 1] - a.qoff[qs]);
 		plen = a.reverse ? r.read_end1 + 1 : qlen;
 		P = (plen + 15) & ~15;
 		/* exact halo: a positive-scoring path spans < P + P*max(mat)/gapE columns */
@@ -918,7 +930,7 @@ __global__ void __launch_bounds__(64) k_capture(ssw_capture_args a)
 #pragma unroll
 	for (int sh = 16; sh < 64; sh <<= 1) { const int o = (int)xl_shfl((u32)mc, (tid + sh) & 63); mc = o > mc ? o : mc; }
 	const int nsteps = (mc + 16 + 15) & ~15;
-	const int8_t* tg = a.tgt;
+	const int8_t* tg = active ? vm_target(a.vm, a.tgt, q) : a.tgt;
 	const int dirstep = a.reverse ? -1 : 1;
 
 	lds_st16(lds, ring + 2u * (48 + l16), nulloff);
@@ -1368,8 +1380,9 @@ SSW_DEV void cap_half_setup(CapHalf& h, const ssw_chainx_args& a, int q)
 	h.r = a.res[q];
 	h.active = h.r.status == 0 && h.r.score1 > 0 && (a.reverse ? h.r.want_begin == 1 : !h.r.loc_done);
 	if (!h.active) return;
-	h.qc = a.qcodes + a.qoff[q];
-	h.qlen = (int)(a.qoff[q + 1] - a.qoff[q]);
+	const int qs = vm_query(a.vm, q);
+	h.qc = a.qcodes + a.qoff[qs];
+	h.qlen = (int)(a.qoff[qs + 1] - a.qoff[qs]);
 	h.lena = a.reverse ? h.r.read_end1 + 1 : h.qlen;
 	h.rows = (h.lena + 15) & ~15;
 	long long w = (long long)h.rows + ((long long)h.rows * (a.maxmat > 0 ? a.maxmat : 0) + a.gapE - 1) / (a.gapE > 0 ? a.gapE : 1) + 1;
@@ -1380,6 +1393,7 @@ SSW_DEV void cap_half_setup(CapHalf& h, const ssw_chainx_args& a, int q)
 	}
 	h.ncols = (int)w + 1;
 	h.c_edge = a.reverse ? h.r.ref_end1 : h.r.ref_end1 - (int)w;
+	if (a.vm.vq) h.c_edge += (int)a.vm.toff[a.vm.vt[q]];      /* pair jobs: the chain reads from the concatenated targets (the host keeps them below 2^31 residues) */
 }
 
 /* the window's best cell of one half -> the result record (same contract as k_capture) */
@@ -1417,7 +1431,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 	x.prof = (u32)grp * (prof_bytes + G::EXTRA); x.ring = x.prof + prof_bytes; x.ringb = x.ring + G::RINGB; x.bin = x.ringb + G::RINGB;
 	x.bout = x.bin + BND_RING_BYTES; x.nulloff = (u32)a.n * G::PSTRIDE;
 	const u32 red = x.bout + BND_RING_BYTES;
-	x.l16 = l16; x.gapO2 = a.gapO2; x.gapE2 = a.gapE2; x.n = a.n; x.tg = a.tgt; x.bmask = 63u;
+	x.l16 = l16; x.gapO2 = a.gapO2; x.gapE2 = a.gapE2; x.n = a.n; x.tg = CAPTURE && a.vm.vq ? a.vm.tcodes : a.tgt; x.bmask = 63u;
 	x.fr_base = 0; x.fr_kmask = 0; x.gapEi = 0;
 	const int job = (int)blockIdx.x * (64 / GL) + grp;
 	const bool valid = job < a.njobs;
@@ -1557,7 +1571,7 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 	x.prof = 0; x.ring = prof_bytes; x.ringb = x.ring + (CAPTURE ? QG::RINGB : 0u); x.bin = x.ringb + QG::RINGB;
 	x.bout = x.bin + BND_RING_BYTES; x.nulloff = (u32)a.n * G::PSTRIDE; x.bmask = 31u;
 	const u32 red = x.bin;
-	x.l16 = l16; x.gapO2 = a.gapO2; x.gapE2 = a.gapE2; x.n = a.n; x.tg = a.tgt;
+	x.l16 = l16; x.gapO2 = a.gapO2; x.gapE2 = a.gapE2; x.n = a.n; x.tg = CAPTURE && a.vm.vq ? a.vm.tcodes : a.tgt;
 	x.fr_base = a.fr_base; x.fr_kmask = a.fr_kmask; x.gapEi = (int)(a.gapE2 & 0xffffu);
 	const int S = a.strips, nitems = a.njobs * S;
 	int* const ticket = a.queue; int* const flags = a.queue + 1;
@@ -1583,7 +1597,7 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 		x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0;
 		x.ncols2[0] = x.ncols2[1] = 0; x.c_edge2[0] = x.c_edge2[1] = 0;
 		if (sidx > 0) {   /* everything the strip above wrote -- boundary records, its best cell, and (window passes) the records */
-			if (!a.whole_jobs && tid == 0 && !dev_flag_wait(flags + (int64_t)job * S + sidx - 1)) atomicAdd(a.queue + 1 + nitems, 1);   /* error word: the host fails the call */
+			if (!a.whole_jobs && tid == 0 && !dev_flag_wait(flags + (int64_t)job * S + sidx - 1)) atomicAdd(a.err, 1);   /* error word: the host fails the call */
 			dev_fence();
 		}
 		if (!CAPTURE) {
@@ -2442,8 +2456,8 @@ __global__ void __launch_bounds__(64 * NW) k_trace_wave(ssw_trace_args a)
 	ssw_dres r = a.res[q];
 	if (tid == 0) a.need[job] = 0;
 	if (!r.want_cigar || r.status != 0) return;
-	const int8_t* ref = a.tgt + r.ref_begin1;
-	const int8_t* read = a.qcodes + a.qoff[q] + r.read_begin1;
+	const int8_t* ref = vm_target(a.vm, a.tgt, q) + r.ref_begin1;
+	const int8_t* read = a.qcodes + a.qoff[vm_query(a.vm, q)] + r.read_begin1;
 	const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
 	const int d = refLen - readLen;
 	const int band0 = (d < 0 ? -d : d) + 1;
@@ -2497,8 +2511,8 @@ __global__ void __launch_bounds__(64) k_trace(ssw_trace_args a)
 	ssw_dres r = a.res[q];
 	a.need[job] = 0;
 	if (!r.want_cigar || r.status != 0) return;
-	const int8_t* ref = a.tgt + r.ref_begin1;
-	const int8_t* read = a.qcodes + a.qoff[q] + r.read_begin1;
+	const int8_t* ref = vm_target(a.vm, a.tgt, q) + r.ref_begin1;
+	const int8_t* read = a.qcodes + a.qoff[vm_query(a.vm, q)] + r.read_begin1;
 	const int refLen = r.ref_end1 - r.ref_begin1 + 1, readLen = r.read_end1 - r.read_begin1 + 1;
 	const int d = refLen - readLen;
 	int band = (d < 0 ? -d : d) + 1;
@@ -2546,9 +2560,10 @@ __global__ void __launch_bounds__(64) k_mark(ssw_mark_args a)
 	if (r.cigarLen <= 0 || r.status != 0) return;
 	const u32* cig = a.cigar + r.cigar_off;
 	u32* out = a.out + (int64_t)q * a.out_stride;
-	const int8_t* t = a.tgt + r.ref_begin1;
-	const int8_t* rd = a.qcodes + a.qoff[q] + r.read_begin1;
-	const int readLen = (int)(a.qoff[q + 1] - a.qoff[q]);
+	const int8_t* t = vm_target(a.vm, a.tgt, q) + r.ref_begin1;
+	const int qs = vm_query(a.vm, q);
+	const int8_t* rd = a.qcodes + a.qoff[qs] + r.read_begin1;
+	const int readLen = (int)(a.qoff[qs + 1] - a.qoff[qs]);
 	int p = 0, nm = 0; u32 eq = 0, ne = 0;
 	if (r.read_begin1 > 0) out[p++] = ((u32)r.read_begin1 << 4) | 4u;
 	for (int i = 0; i < r.cigarLen; ++i) {
@@ -2580,6 +2595,64 @@ __global__ void __launch_bounds__(256) k_gather(ssw_gather_args a)
 	const u32* src = a.src + a.res[q].cigar_off;
 	u32* dst = a.dst + a.dst_off[q];
 	for (int i = 0; i < len; ++i) dst[i] = src[i];
+}
+
+/* k_select (ssw_select_args): the pairs of a database-search chunk that go on to the reverse pass, compacted in (bucket-ordered
+   query, target) order.  256 pairs per block; linear index i = k * nt + t, query order[k], record out[order[k] * nt + t]. */
+SSW_DEV bool select_pred(const ssw_select_args& a, int64_t i, int64_t n, int& q, int& t, ssw_out_rec& o)
+{
+	if (i >= n) return false;
+	const int k = (int)(i / a.nt);
+	t = (int)(i - (int64_t)k * a.nt);
+	q = a.order[k];
+	o = a.out[(int64_t)q * a.nt + t];
+	return (o.status & 0xffu) == 0 && o.score1 > 0 && !(a.flag == 0 || (a.flag == 2 && (int)o.score1 < a.filters));      /* ssw.c:900-903, 916 */
+}
+
+__global__ void __launch_bounds__(256) k_select(ssw_select_args a)
+{
+	SSW_DYN_LDS(lds);
+	const int tid = (int)threadIdx.x;
+	const int64_t n = (int64_t)a.nk * a.nt;
+	if (a.pass == 1) {      /* one workgroup: exclusive scan of the block counts (each thread a contiguous run of blocks) */
+		const int per = (a.nblk + 255) / 256;
+		const int b0 = tid * per, b1 = b0 + per < a.nblk ? b0 + per : a.nblk;
+		int sum = 0;
+		for (int b = b0; b < b1; ++b) sum += a.blk[b];
+		lds_st32(lds, 4u * tid, (u32)sum);
+		__syncthreads();
+		if (tid == 0) {
+			int run = 0;
+			for (int k = 0; k < 256; ++k) { const int v = (int)lds_ld32(lds, 4u * k); lds_st32(lds, 4u * k, (u32)run); run += v; }
+			a.blk[a.nblk] = run;
+			a.bucket_first[a.nbk] = run;
+		}
+		__syncthreads();
+		int run = (int)lds_ld32(lds, 4u * tid);
+		for (int b = b0; b < b1; ++b) { const int v = a.blk[b]; a.blk[b] = run; run += v; }
+		return;
+	}
+	const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+	int q = 0, t = 0; ssw_out_rec o;
+	const bool keep = select_pred(a, i, n, q, t, o);
+	/* rank of this thread among the block's survivors: ballots of the four wavefronts through LDS */
+	const unsigned long long bal = wave_ballot(keep);
+	const int wave = tid >> 6, lane = tid & 63;
+	if (lane == 0) lds_st32(lds, 4u * wave, (u32)__builtin_popcountll(bal));
+	__syncthreads();
+	int before = 0, total = 0;
+	for (int w = 0; w < 4; ++w) { const int cnt = (int)lds_ld32(lds, 4u * w); if (w < wave) before += cnt; total += cnt; }
+	if (a.pass == 0) { if (tid == 0) a.blk[blockIdx.x] = total; return; }
+	const int pos = a.blk[blockIdx.x] + before + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+	for (int b = 0; b < a.nbk; ++b) if (a.bucket_lin[b] == i) a.bucket_first[b] = pos;      /* (pos = survivors before i, whether i survives or not) */
+	if (i < n && (o.status & SSW_OUT_WORD)) a.out[(int64_t)q * a.nt + t].status = (uint16_t)(o.status & 0xffu);
+	if (keep && pos < a.cap) {
+		ssw_dres r;
+		r.score1 = o.score1; r.score2 = o.score2; r.ref_begin1 = -1; r.ref_end1 = o.ref_end1; r.read_begin1 = -1; r.read_end1 = o.read_end1;
+		r.ref_end2 = o.ref_end2; r.cigarLen = 0; r.flag = 0; r.status = 0; r.word = (o.status & SSW_OUT_WORD) ? 1 : 0; r.want_begin = 1; r.want_cigar = 0;
+		r.rev_score = 0; r.loc_done = 1; r.nm = 0; r.cigar_off = 0;
+		a.sres[pos] = r; a.svq[pos] = q; a.svt[pos] = a.tbase + t; a.vlist[pos] = pos;
+	}
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -2871,6 +2944,16 @@ extern "C" int ssw_shim_launch_mark(const ssw_mark_args* a, void* stream)
 	return SSW_LAUNCH_OK();
 }
 
+extern "C" int ssw_shim_launch_select(const ssw_select_args* a, void* stream)
+{
+	ssw_select_args args = *a;
+	const int64_t n = (int64_t)args.nk * args.nt;
+	const int grid = args.pass == 1 ? 1 : (int)((n + 255) / 256);
+	if (grid <= 0) return 0;
+	SSW_LAUNCH(k_select, ssw_select_args, args, grid, 256, 1024, stream);
+	return SSW_LAUNCH_OK();
+}
+
 extern "C" int ssw_shim_launch_gather(const ssw_gather_args* a, void* stream)
 {
 	ssw_gather_args args = *a;
@@ -2900,14 +2983,18 @@ extern "C" int ssw_shim_stream_sync(void* s) { return shim_check(hipStreamSynchr
 extern "C" void* ssw_shim_malloc(size_t bytes)
 {
 	void* p = 0;
-	if (shim_check(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc")) return 0;
+	if (shim_check(hipMalloc(&p, bytes ? bytes : 16), "hipMalloc")) {
+		(void)hipGetLastError();      /* the runtime keeps the last error until it is read: a caller that recovers from this failure (smaller
+		                                 budget, ssw_host.c SSW_ALLOC_RETRY) must not meet it again as "kernel launch: out of memory" */
+		return 0;
+	}
 	return p;
 }
 extern "C" void ssw_shim_free(void* p) { if (p) (void)hipFree(p); }
 extern "C" void* ssw_shim_host_alloc(size_t bytes)
 {
 	void* p = 0;
-	if (shim_check(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault), "hipHostMalloc")) return 0;
+	if (shim_check(hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault), "hipHostMalloc")) { (void)hipGetLastError(); return 0; }
 	return p;
 }
 extern "C" void ssw_shim_host_free(void* p) { if (p) (void)hipHostFree(p); }
@@ -2919,6 +3006,15 @@ extern "C" size_t ssw_shim_mem_free_bytes(void)
 	size_t f = 0, t = 0;
 	if (hipMemGetInfo(&f, &t) != hipSuccess) return 0;
 	return f;
+}
+extern "C" int ssw_shim_device_props(int* compute_units, int* waves_per_cu)
+{
+	int dev = 0;
+	hipDeviceProp_t pr;
+	if (shim_check(hipGetDevice(&dev), "hipGetDevice") || shim_check(hipGetDeviceProperties(&pr, dev), "hipGetDeviceProperties")) return -1;
+	*compute_units = pr.multiProcessorCount;
+	*waves_per_cu = pr.maxThreadsPerMultiProcessor / 64;
+	return 0;
 }
 extern "C" void* ssw_shim_event_create(void)
 {

@@ -127,7 +127,45 @@ static void* refwrap_db_worker(void* arg)
 	return 0;
 }
 
+/* database mode WITH the caller's flag / filters (the reference's loop calls ssw_align with flag 2 and a score filter for every
+   (read, target) pair: src/main.c:493-506): full records of 10 int32 at res[(q * nt + t) * 10] as in refwrap_worker, and the
+   FNV-1a of every CIGAR at cig_hash[q * nt + t] */
+static void* refwrap_dbx_worker(void* arg)
+{
+	refwrap_job* j = (refwrap_job*)arg;
+	for (int32_t q = j->tid; q < j->nq; q += j->nthreads) {
+		const int8_t* rd = j->qcodes + j->qoff[q];
+		int32_t len = (int32_t)(j->qoff[q + 1] - j->qoff[q]);
+		int32_t maskLen = j->maskLen >= 0 ? j->maskLen : len / 2;
+		s_profile* p = ssw_init(rd, len, j->mat, j->n, 2);
+		for (int32_t t = 0; t < j->nt; ++t) {
+			s_align* a = ssw_align(p, j->tcodes + j->toff[t], (int32_t)(j->toff[t + 1] - j->toff[t]), j->gapO, j->gapE, j->flag, j->filters, j->filterd, maskLen);
+			int32_t* r = j->res + ((int64_t)q * j->nt + t) * 10;
+			uint32_t h = 0u;
+			if (a) {
+				r[0] = a->score1; r[1] = a->score2; r[2] = a->ref_begin1; r[3] = a->ref_end1;
+				r[4] = a->read_begin1; r[5] = a->read_end1; r[6] = a->ref_end2; r[7] = a->cigarLen;
+				r[8] = a->flag; r[9] = 0;
+				if (a->cigarLen > 0 && a->cigar) h = refwrap_fnv(a->cigar, a->cigarLen);
+				align_destroy(a);
+			} else { for (int k = 0; k < 9; ++k) r[k] = 0; r[9] = 1; }
+			if (j->cig_hash) j->cig_hash[(int64_t)q * j->nt + t] = h;
+		}
+		init_destroy(p);
+	}
+	return 0;
+}
+
 static double refwrap_run(refwrap_job proto, int32_t nthreads, void* (*worker)(void*));
+
+double refwrap_bench_dbx(const int8_t* qcodes, const int64_t* qoff, int32_t nq,
+                         const int8_t* tcodes, const int64_t* toff, int32_t nt, const int8_t* mat, int32_t n,
+                         uint8_t gapO, uint8_t gapE, uint8_t flag, uint16_t filters, int32_t filterd, int32_t maskLen, int32_t nthreads,
+                         int32_t* res10, uint32_t* hash)
+{
+	refwrap_job j = { qcodes, qoff, nq, 0, 0, mat, n, gapO, gapE, flag, filters, filterd, maskLen, res10, 0, nthreads, hash, tcodes, toff, nt };
+	return refwrap_run(j, nthreads, refwrap_dbx_worker);
+}
 
 double refwrap_bench(const int8_t* qcodes, const int64_t* qoff, int32_t nq,
                      const int8_t* ref, int32_t refLen, const int8_t* mat, int32_t n,

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""GPU box: begin positions / CIGARs against a whole database in ONE batch call (ssw_host.c dbx_chunk) next to the score-only search and to
+the per-target loop it replaces -- config-5-shaped proteins, BLOSUM50, gaps 3/1, flag 2 with a score filter; every record and every CIGAR
+checked against the reference's own loop (oracle/_ref: refwrap_bench_dbx = ssw_init per query + ssw_align per entry with the same flag /
+filter, src/main.c:493-506).  One JSON line.   usage: gpu_dbx_bench.py [nq] [nt] [keep_percent]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "complete-striped-smith-waterman-library_amd"))
+import ssw_amd          # noqa: E402
+import workloads as W   # noqa: E402
+from sswutil import _ptr, i8p, i32p, i64p, u32p, ref_lib   # noqa: E402
+
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+nt = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+keep = float(sys.argv[3]) if len(sys.argv) > 3 else 0.5
+db, qs, mat = W.protein_config(0, queries=max(nq, 2048), db_entries=nt)
+qs = qs[:nq]
+lib = ssw_amd.load()
+ctx = ssw_amd.Context(0, lib)
+ctx.set_exclusive()
+Q = ctx.upload(qs); T = ctx.upload(db)
+cells = float(sum(len(q) for q in qs)) * float(sum(len(t) for t in db))
+out = {"workload": "%d protein queries x %d DB entries (config 5 generator), BLOSUM50 3/1" % (nq, nt), "cells": cells}
+
+
+def timed(label, flag, filters, filterd=0, reps=2, env=None):
+    for k, v in (env or {}).items():
+        os.environ[k] = v
+    try:
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res, cig = ctx.align_batch(Q, T, mat, 24, 3, 1, flag, filters, filterd, -1, 2)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        tm = ctx.timing()
+        out[label] = {"seconds": round(best, 3), "gcups": round(cells / best / 1e9, 1), "fill_ms": round(tm["fill_ms"], 1), "locate_ms": round(tm["locate_ms"], 1),
+                      "trace_ms": round(tm["trace_ms"], 1), "other_ms": round(tm["reduce_ms"], 1), "cigars": int((res["cigarLen"] > 0).sum())}
+        return res, cig
+    finally:
+        for k in (env or {}):
+            del os.environ[k]
+
+
+res0, _ = timed("score_only_flag0", 0, 0)
+filters = int(np.percentile(res0["score1"], 100.0 - keep))
+out["filters"] = filters
+out["note"] = ("gaps 3/1 on BLOSUM50 are the linear regime (unrelated ~300-aa pairs score ~%d): the filter is set at the %.2f %% highest scores of the batch"
+               % (int(np.median(res0["score1"])), keep))
+res2, cig2 = timed("flag2_filtered_one_call", 2, filters)
+out["ratio_flag2_vs_score_only"] = round(out["flag2_filtered_one_call"]["seconds"] / out["score_only_flag0"]["seconds"], 3)
+# the per-target loop the path replaces, on a slice of the targets (it is one iteration with two stream syncs per target)
+sl = min(nt, 200)
+t0 = time.perf_counter()
+os.environ["SSW_GPU_NO_DBX"] = "1"
+try:
+    r_loop, c_loop = ctx.align_batch(Q, T, mat, 24, 3, 1, 2, filters, 0, -1, 2, target_first=0, target_count=sl)
+finally:
+    del os.environ["SSW_GPU_NO_DBX"]
+dt = time.perf_counter() - t0
+out["per_target_loop_before_round4"] = {"targets": sl, "seconds": round(dt, 3), "extrapolated_seconds_for_all_targets": round(dt * nt / sl, 1)}
+same = all((r_loop[f] == res2[f][:, :sl]).all() for f in ("score1", "score2", "ref_begin1", "ref_end1", "read_begin1", "read_end1", "ref_end2", "cigarLen", "flag"))
+out["per_target_loop_before_round4"]["same_records_as_one_call"] = bool(same)
+# all pairs through the reverse pass and the traceback (filters 0) on a slice: the throughput of those phases, not a use case
+sl2 = min(nt, 256)
+t0 = time.perf_counter()
+r_all, c_all = ctx.align_batch(Q, T, mat, 24, 3, 1, 2, 0, 0, -1, 2, target_first=0, target_count=sl2)
+dt = time.perf_counter() - t0
+tm = ctx.timing()
+out["flag2_unfiltered_slice"] = {"targets": sl2, "pairs": nq * sl2, "seconds": round(dt, 3), "locate_ms": round(tm["locate_ms"], 1), "trace_ms": round(tm["trace_ms"], 1),
+                                 "cigars": int((r_all["cigarLen"] > 0).sum())}
+# parity: the reference's own loop with the same flag and filter
+R = ref_lib()
+if R is not None and hasattr(R, "refwrap_bench_dbx") and "--no-ref" not in sys.argv:
+    import bench
+    cores = bench.usable_cores()
+    qc, qo = W.pack(qs); tc, to = W.pack(db)
+    exp = np.zeros((nq, nt, 10), dtype=np.int32); eh = np.zeros((nq, nt), dtype=np.uint32)
+    secs = R.refwrap_bench_dbx(_ptr(qc, i8p), _ptr(qo, i64p), nq, _ptr(tc, i8p), _ptr(to, i64p), nt, _ptr(mat, i8p), 24, 3, 1, 2, filters, 0, -1, cores,
+                               _ptr(exp, i32p), _ptr(eh, u32p))
+    got = np.stack([res2[f] for f in ("score1", "score2", "ref_begin1", "ref_end1", "read_begin1", "read_end1", "ref_end2", "cigarLen", "flag")], axis=2).astype(np.int32)
+    bad = int((got != exp[..., :9]).any(axis=2).sum())
+    badc = 0
+    for q, t in np.argwhere(res2["cigarLen"] > 0):
+        o = int(res2["cigar_off"][q, t]); k = int(res2["cigarLen"][q, t])
+        badc += W.fnv1a_words(cig2[o:o + k]) != int(eh[q, t])
+    badc += int(((res2["cigarLen"] == 0) != (eh == 0)).sum())
+    out["parity"] = {"pairs": nq * nt, "mismatching_records": bad, "mismatching_cigars": int(badc), "reference_seconds": round(secs, 1), "cores": cores,
+                     "reference_gcups": round(cells / secs / 1e9, 1), "against": "the reference's loop (oracle/_ref refwrap_bench_dbx: ssw_init per query, ssw_align per entry, flag 2, the same filter)"}
+Q.free(); T.free(); ctx.close()
+print(json.dumps(out))

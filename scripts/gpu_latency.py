@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""GPU box: what ONE ssw_align call of the drop-in ABI costs (include/ssw.h: the reference's callers loop "for each read: ssw_init; for each
+target: ssw_align", src/main.c:506, ssw_cpp.cpp:342, pyssw.py:129), per read length / target length / flag.  One JSON line."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "complete-striped-smith-waterman-library_amd"))
+import ssw_amd          # noqa: E402
+from sswutil import SAlign, dna_matrix, i8p, random_ref, sample_reads   # noqa: E402
+
+lib = ssw_amd.load()
+lib.ssw_init.argtypes = [i8p, C.c_int32, i8p, C.c_int32, C.c_int8]; lib.ssw_init.restype = C.c_void_p
+lib.ssw_align.argtypes = [C.c_void_p, i8p, C.c_int32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint16, C.c_int32, C.c_int32]; lib.ssw_align.restype = C.POINTER(SAlign)
+lib.align_destroy.argtypes = [C.POINTER(SAlign)]; lib.init_destroy.argtypes = [C.c_void_p]
+mat = dna_matrix(2, 2)
+out = {}
+for ref_len in (10_000, 1_000_000):
+    ref = random_ref(ref_len, 1, 4)
+    for rl in (150, 1000):
+        reads = sample_reads(ref, 200, rl, seed=5)
+        for flag in (0, 2):
+            ts = []
+            for i, r in enumerate(reads):
+                r = np.ascontiguousarray(r)
+                t0 = time.perf_counter()
+                p = lib.ssw_init(r.ctypes.data_as(i8p), len(r), mat.ctypes.data_as(i8p), 5, 2)
+                a = lib.ssw_align(p, ref.ctypes.data_as(i8p), len(ref), 3, 1, flag, 0, 0, rl // 2)
+                ts.append(time.perf_counter() - t0)
+                assert a and a.contents.score1 > 0
+                lib.align_destroy(a); lib.init_destroy(p)
+            ts = np.array(ts[20:]) * 1e3      # the first calls create the implicit context and size its buffers
+            out["read %d x target %d, flag %d" % (rl, ref_len, flag)] = {"median_ms": round(float(np.median(ts)), 3), "p90_ms": round(float(np.percentile(ts, 90)), 3),
+                                                                          "gcups_of_a_caller_loop": round(rl * ref_len / float(np.median(ts)) / 1e6, 1)}
+print(json.dumps(out))

@@ -117,6 +117,10 @@ def ref_lib(required=False):
             L.refwrap_bench_db.argtypes = [i8p, i64p, C.c_int32, i8p, i64p, C.c_int32, i8p, C.c_int32, C.c_uint8, C.c_uint8,
                                            C.c_int32, C.c_int32, i32p]
             L.refwrap_bench_db.restype = C.c_double
+        if hasattr(L, "refwrap_bench_dbx"):
+            L.refwrap_bench_dbx.argtypes = [i8p, i64p, C.c_int32, i8p, i64p, C.c_int32, i8p, C.c_int32, C.c_uint8, C.c_uint8, C.c_uint8, C.c_uint16,
+                                            C.c_int32, C.c_int32, C.c_int32, i32p, u32p]
+            L.refwrap_bench_dbx.restype = C.c_double
         _ref = L
     return _ref
 

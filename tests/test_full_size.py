@@ -5,7 +5,9 @@ driver's `pytest -m gpu` run sees the full-size inputs (a few GPU-seconds in tot
 
   config 2  all 100 000 reads x 150 bp vs the 1 Mb target: flag 2 (every s_align field + FNV-1a of every CIGAR word) and flag 0
   config 3  the whole 20 000-read block 0 vs the 5 Mb target, flag 2 and flag 0
-  config 4  the first 5 000 of the 10 000 x 10 kb reads vs the 100 kb target, maskLen 5000, flag 2 (banded traceback on the GPU)
+  config 4  all 10 000 x 10 kb reads vs the 100 kb target, maskLen 5000, flag 2 (banded traceback on the GPU)
+  config 2 under the pure 8-bit scoring 1/-3/5/2 (all 100 000 reads), a seeded sample of read blocks 1..7 of configs 2 and 3 (what the
+  ranks of an N-GPU run compute), and the README's benchmark shape (config 6: 1000 mixed-length reads vs 4.94 Mb, both scorings)
   config 5  2 048 queries x all 10 000 DB entries (2.05e7 alignments), streamed database search: one checksum per query and the
             full records of the first 16 queries
 
@@ -39,17 +41,18 @@ def _cigar_hashes(g, cig):
     return out
 
 
-def _dna_full(ctx, cfg, min_reads):
-    z = np.load(os.path.join(FULL, "config%d_block0.npz" % cfg))
+def _dna_full(ctx, cfg, min_reads, scoring=(2, 2, 3, 1), tag=""):
+    z = np.load(os.path.join(FULL, "config%d%s_block0.npz" % (cfg, tag)))
     exp, eh = z["fields"], z["cigar_fnv"]
     k = len(exp)
-    assert k >= min_reads, "tests/golden/full/config%d_block0.npz holds %d reads (scripts/make_expected.py %d)" % (cfg, k, cfg)
+    assert k >= min_reads, "tests/golden/full/config%d%s_block0.npz holds %d reads (scripts/make_expected.py)" % (cfg, tag, k)
     ref, reads, p = W.dna_config(cfg, 0)
     reads = reads[:k]
-    mat = dna_matrix(2, 2)
+    mat = dna_matrix(scoring[0], scoring[1])
+    gO, gE = scoring[2], scoring[3]
     Q = ctx.upload(list(reads)); T = ctx.upload([ref])
     try:
-        res, cig = ctx.align_batch(Q, T, mat, 5, 3, 1, 2, 0, 0, p["mask_len"], 2)
+        res, cig = ctx.align_batch(Q, T, mat, 5, gO, gE, 2, 0, 0, p["mask_len"], 2)
         g = res[:, 0]
         got = _fields(g)
         bad = (got != exp).any(axis=1) | (_cigar_hashes(g, cig) != eh)
@@ -57,7 +60,10 @@ def _dna_full(ctx, cfg, min_reads):
             cfg, int(bad.sum()), k, int(np.flatnonzero(bad)[0]), got[np.flatnonzero(bad)[0]].tolist(), exp[np.flatnonzero(bad)[0]].tolist())
         assert (got[:, 7] > 0).sum() > 0.9 * k                   # the CIGARs were really produced (and compared)
         if cfg != 4:                                             # (config 4 is stated with the CIGAR on)
-            res0, _ = ctx.align_batch(Q, T, mat, 5, 3, 1, 0, 0, 0, p["mask_len"], 2)
+            res0, _ = ctx.align_batch(Q, T, mat, 5, gO, gE, 0, 0, 0, p["mask_len"], 2)
+            if tag == "_u8":                                     # max score 150 < 255 - 3, every read decided by the 8-bit rules
+                tm = ctx.timing()
+                assert tm["n_word"] == 0 and tm["n_byte"] > 0.9 * k
             g0 = _fields(res0[:, 0])
             cols = [0, 1, 3, 5, 6]
             bad0 = (g0[:, cols] != exp[:, cols]).any(axis=1) | (g0[:, 2] != -1) | (g0[:, 4] != -1) | (g0[:, 7] != 0) | (g0[:, 8] != 0)
@@ -76,7 +82,58 @@ def test_config3_whole_read_block_vs_5mb(gpu_ctx):
 
 
 def test_config4_long_reads_with_traceback(gpu_ctx):
-    assert _dna_full(gpu_ctx, 4, 5_000) >= 5_000
+    assert _dna_full(gpu_ctx, 4, 10_000) == 10_000
+
+
+def test_config2_pure_8bit_scoring(gpu_ctx):
+    """the 100 000 reads of config 2 under match 1 / mismatch 3 / gaps 5, 2 (README.md:71) -- pure u8 semantics"""
+    assert _dna_full(gpu_ctx, 2, 100_000, scoring=(1, 3, 5, 2), tag="_u8") == 100_000
+
+
+def test_per_rank_blocks_of_configs_2_and_3(gpu_ctx):
+    """What rank r of an N-GPU bench line computes: read block r.  The seeded 2 000-read sample of blocks 1..7 that
+    bench.py's `parity.per_rank` checks, here through the C-ABI in one process (block 0 is covered in full above)."""
+    mat = dna_matrix(2, 2)
+    for cfg in (2, 3):
+        z = np.load(os.path.join(FULL, "config%d_blocks_sample.npz" % cfg))
+        ref = None
+        T = None
+        try:
+            for b in (1, len(z["idx"]) - 1):                      # two of the blocks keep the test short; bench.py checks each rank's own
+                ref_b, reads, p = W.dna_config(cfg, b)
+                if T is None:
+                    ref = ref_b; T = gpu_ctx.upload([ref])
+                sub = reads[z["idx"][b]]
+                Q = gpu_ctx.upload(list(sub))
+                try:
+                    res, cig = gpu_ctx.align_batch(Q, T, mat, 5, 3, 1, 2, 0, 0, p["mask_len"], 2)
+                finally:
+                    Q.free()
+                g = res[:, 0]
+                bad = (_fields(g) != z["fields"][b]).any(axis=1) | (_cigar_hashes(g, cig) != z["cigar_fnv"][b])
+                assert not bad.any(), "config %d block %d: %d of %d sampled reads differ from the reference" % (cfg, b, int(bad.sum()), len(sub))
+        finally:
+            if T is not None:
+                T.free()
+
+
+def test_config6_mixed_read_lengths_readme_shape(gpu_ctx):
+    """the shape of the one benchmark the reference publishes (README.md:62-74): 1000 reads of 25-540 bp vs a 4.94 Mb genome,
+    default penalties and -m1 -x3 -o5 -e2 -- ~33 geometry buckets with a few pairs each, the longest reads on the strip kernel"""
+    z = np.load(os.path.join(FULL, "config6_block0.npz"))
+    ref, reads, p = W.mixed_config(0)
+    assert (np.array([len(r) for r in reads]) == z["lens"]).all()
+    Q = gpu_ctx.upload(reads); T = gpu_ctx.upload([ref])
+    try:
+        for key, sc in (("default", (2, 2, 3, 1)), ("m1x3o5e2", (1, 3, 5, 2))):
+            mat = dna_matrix(sc[0], sc[1])
+            res, cig = gpu_ctx.align_batch(Q, T, mat, 5, sc[2], sc[3], 2, 0, 0, -1, 2)
+            g = res[:, 0]
+            bad = (_fields(g) != z["fields_" + key]).any(axis=1) | (_cigar_hashes(g, cig) != z["cigar_fnv_" + key])
+            assert not bad.any(), "config 6 (%s): %d of %d reads differ; first: read %d (len %d)" % (
+                key, int(bad.sum()), len(reads), int(np.flatnonzero(bad)[0]), len(reads[int(np.flatnonzero(bad)[0])]))
+    finally:
+        Q.free(); T.free()
 
 
 def test_config5_streamed_database_search(gpu_ctx):

@@ -23,14 +23,21 @@ def test_two_rank_bench_over_gloo(emu_lib_path, tmp_path):
     env = dict(os.environ, SSW_BENCH_DUMP=str(tmp_path), SSW_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--reads", "5", "--ref-len", "2500", "--read-len", "70", "--cpu-sample", "0", "--lib", emu_lib_path]
+           "--reads", "5", "--ref-len", "2500", "--read-len", "70", "--cpu-sample", "3", "--lib", emu_lib_path]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                      # only rank 0 prints
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["metric"] == "GCUPS" and out["value"] >= 0
-    assert out["steps"] == 1 and out["warmup"] == 1 and out["higher_is_better"] is True and "roofline" in out
+    assert out["steps"] == 1 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert out["roofline"]["bound"] == "valu-issue" and "frac_of_isa_ideal" in out["roofline"] and out["roofline_hbm"]["bound"] == "hbm"
+    # an N > 1 line is evidence, not just a rate: every rank's shard checked against the reference, the CPU baseline beside it
+    par = out["parity"]
+    assert par["ranks_checked"] == 2 and [x["rank"] for x in par["per_rank"]] == [0, 1] and par["mismatching_alignments"] == 0
+    assert all(x["sample"] >= 3 and x["mismatching_alignments"] == 0 for x in par["per_rank"])
+    if "cpu_baseline" in out:                   # (oracle/_ref present: the build container and the GPU box)
+        assert out["cpu_baseline"]["kind"] in ("reference", "port") and out["cpu_baseline"]["value"] > 0
     mat = dna_matrix(2, 2)
     seen = []
     for rank in (0, 1):
@@ -48,14 +55,16 @@ def test_two_rank_database_search_over_gloo(emu_lib_path):
     data path), rank 0 prints the one aggregated line"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "5", "--steps", "1", "--warmup", "0",
-           "--reads", "24", "--db-targets", "9", "--db-chunk", "4", "--cpu-sample", "0", "--lib", emu_lib_path]
+           "--reads", "24", "--db-targets", "9", "--db-chunk", "4", "--cpu-sample", "2", "--lib", emu_lib_path]
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, SSW_BENCH_BACKEND="gloo"), timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["alignments_per_step"] == 24 * 9
-    assert out["config"]["baseline_config"] == 5 and "roofline" in out and "roofline_valu" in out
+    if "parity" in out:                         # (needs oracle/_ref)
+        assert out["parity"]["ranks_checked"] == 2 and out["parity"]["mismatching_alignments"] == 0
+    assert out["config"]["baseline_config"] == 5 and out["roofline"]["bound"] == "valu-issue" and out["roofline_hbm"]["bound"] == "hbm"
 
 
 def test_pool_mode_of_bench_on_two_pretend_devices(emu_lib_path):
@@ -88,11 +97,12 @@ def test_gpus_flag_without_a_launcher_starts_the_ranks_itself(emu_lib_path):
 def test_also_block_carries_the_other_configs(emu_lib_path):
     """the metric's line with configs 3, 4 and 5 attached (`also`): here on the emulator with toy shapes, on the GPU at the stated sizes"""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--reads", "3", "--ref-len", "2000", "--read-len", "60",
-           "--cpu-sample", "0", "--also", "3,4,5", "--lib", emu_lib_path]
+           "--cpu-sample", "0", "--also", "2u8,3,4,5,6", "--lib", emu_lib_path]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert out["n_gpus"] == 1 and set(out["also"]) >= {"config3", "config4", "config5"}
-    for c in ("config3", "config4", "config5"):
+    assert out["n_gpus"] == 1 and set(out["also"]) >= {"config2u8", "config3", "config4", "config5", "config6"}
+    assert out["also"]["config2u8"]["mix"]["word_rules"] == 0          # 1/-3/5/2: every read decided under the 8-bit rules
+    for c in ("config2u8", "config3", "config4", "config5", "config6"):
         assert "error" not in out["also"][c], out["also"][c]
         assert out["also"][c]["ms_per_step"] > 0 and out["also"][c]["fill_kernel"]

@@ -52,6 +52,30 @@ def dna_config(cfg, block=0, reads=None):
     return ref, rd, p
 
 
+# The one workload the reference publishes a number for (README.md:62-74): 1000 Ion Torrent reads of 25-540 bp,
+# "most reads are ~200 bp", against the 4 938 920-nt genome of E. coli 536 -- default penalties and -m1 -x3 -o5 -e2.  The data set itself
+# is not in the tree: the same SHAPE from seeds -- a random genome of that length, read lengths 85 % N(200, 45) and 15 % uniform over
+# [25, 540], Ion-Torrent-like errors (indels dominate: 1 % insertions, 1 % deletions, 0.5 % substitutions), 5 % unrelated reads.
+MIXED_CONFIG = dict(ref_len=4_938_920, seed_ref=6, reads=1000, seed_reads=6000, sub=0.005, indel=0.01, min_len=25, max_len=540, flag=0, mask_len=-1,
+                    name="config 6 (README.md:62-74 shape): 1000 reads of 25-540 bp (most ~200) vs a 4 938 920-nt genome")
+
+
+def mixed_config(block=0, reads=None, ref_len=None):
+    """-> (ref int8[ref_len], list of int8 reads of mixed lengths, params)"""
+    p = dict(MIXED_CONFIG)
+    if reads is not None:
+        p["reads"] = int(reads)
+    if ref_len is not None:
+        p["ref_len"] = int(ref_len)
+    ref = random_ref(p["ref_len"], p["seed_ref"], 4)
+    rng = np.random.default_rng(p["seed_reads"] + 7919 * (block + 1))
+    n = p["reads"]
+    lens = np.where(rng.random(n) < 0.85, np.rint(rng.normal(200, 45, size=n)), rng.integers(p["min_len"], p["max_len"] + 1, size=n))
+    lens = np.clip(lens, p["min_len"], min(p["max_len"], p["ref_len"] // 4)).astype(np.int64)
+    full = make_reads_fast(ref, n, int(lens.max()), seed=p["seed_reads"] + block, sub=p["sub"], ins=p["indel"], dele=p["indel"])
+    return ref, [np.ascontiguousarray(full[i, :lens[i]]) for i in range(n)], p
+
+
 _AA_FREQ = np.array([8.3, 5.5, 4.1, 5.5, 1.4, 3.9, 6.8, 7.1, 2.3, 5.9, 9.7, 5.8, 2.4, 3.9, 4.7, 6.6, 5.3, 1.1, 2.9, 6.9])
 _AA_FREQ = _AA_FREQ / _AA_FREQ.sum()
 
