@@ -76,6 +76,14 @@ typedef struct {
 	int32_t fr_base, fr_kmask;   /* form 3: phi(column) = fr_base + ((step & fr_kmask) + lanes - lane) * gapE */
 } ssw_fill_args;
 
+/* several fill launches (geometry buckets of one register class) as ONE grid: k_fillm */
+typedef struct {
+	const ssw_fill_args* sub;   /* nsub argument records (device) */
+	const int32_t* first_wg;    /* nsub + 1: first workgroup of every sub-launch, last = total */
+	const int32_t* subR;        /* rows per lane of every sub-launch */
+	int32_t nsub;
+} ssw_fillm_args;
+
 /* byte-for-byte the layout of ssw_gpu_result (include/ssw_gpu.h); checked by a static assertion in ssw_host.c */
 struct ssw_out_rec {
 	uint16_t score1, score2;
@@ -167,6 +175,13 @@ typedef struct {
 	int64_t seg_stride;
 } ssw_reduce_args;
 
+/* the reductions of several buckets as ONE grid (one workgroup per pair): k_reducem */
+typedef struct {
+	const ssw_reduce_args* sub; /* nsub argument records (device), each with sg16 set */
+	const int32_t* first_wg;    /* nsub + 1 */
+	int32_t nsub;
+} ssw_reducem_args;
+
 /* locate (read_end1) and reverse (begin position) passes: one 16-lane chain per alignment */
 typedef struct {
 	const int8_t* tgt;
@@ -208,6 +223,9 @@ typedef struct {
 	uint32_t* cm16;
 	uint32_t* cm8;
 	int64_t cm_stride;
+	uint32_t* sg16;          /* optional: [pair][seg_stride] maxima of every aligned group of 16 columns, as in ssw_fill_args */
+	uint32_t* sg8;
+	int64_t seg_stride;
 	/* capture mode */
 	const int32_t* qlist;
 	int32_t reverse;
@@ -351,8 +369,11 @@ int   ssw_shim_stream_wait_event(void* stream, void* ev);   /* later work on `st
 float ssw_shim_event_elapsed_ms(void* start, void* stop);   /* both must have completed */
 
 int ssw_shim_launch_fill(int R, const ssw_fill_args* a, void* stream);
+int ssw_shim_fill_class(int R);    /* register class of k_fill<R>: sub-launches of one k_fillm grid share it */
+int ssw_shim_launch_fillm(const ssw_fillm_args* a, const int32_t* host_R, int n, int form, int64_t total_wgs, void* stream);
 int ssw_shim_launch_filldb(int R, const ssw_filldb_args* a, void* stream);
 int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream);
+int ssw_shim_launch_reducem(const ssw_reducem_args* a, int64_t total_pairs, void* stream);
 int ssw_shim_launch_capture(int R, const ssw_capture_args* a, void* stream);
 int64_t ssw_shim_capture_lds_need(int R, int n);   /* dynamic LDS of one k_capture<R> workgroup */
 int ssw_shim_launch_chainx(int R, int capture, const ssw_chainx_args* a, void* stream);

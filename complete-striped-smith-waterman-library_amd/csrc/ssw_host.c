@@ -73,7 +73,7 @@ struct ssw_gpu_ctx {
 	void *ev_fill[2], *ev_red[2];
 	char err[512];
 	ssw_gpu_timing tm;
-	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, cigar2, need, goff, gpool, bnd, tlist, cand, tresume, queue, cands, sg16, sg8, qerr;
+	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, cigar2, need, goff, gpool, bnd, tlist, cand, tresume, queue, cands, sg16, sg8, qerr, fmtab;
 	dbuf sres, svq, svt, scnt;          /* flagged database search: survivor records, their (query, target) maps, counters */
 	void** ev; int nev, capev;          /* event pairs around fill launches */
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d, *ev_db;
@@ -242,7 +242,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	if (c->stream) ssw_shim_stream_sync(c->stream);
 	for (int i = 0; i < 2; ++i) { ssw_shim_free(c->hits_d[i]); ssw_shim_host_free(c->hits_h[i]); }
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
-	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->cigar2); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand); dbuf_free(&c->tresume); dbuf_free(&c->queue); dbuf_free(&c->cands); dbuf_free(&c->sg16); dbuf_free(&c->sg8); dbuf_free(&c->qerr);
+	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->cigar2); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand); dbuf_free(&c->tresume); dbuf_free(&c->queue); dbuf_free(&c->cands); dbuf_free(&c->sg16); dbuf_free(&c->sg8); dbuf_free(&c->qerr); dbuf_free(&c->fmtab);
 	dbuf_free(&c->sres); dbuf_free(&c->svq); dbuf_free(&c->svt); dbuf_free(&c->scnt);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
 	free(c->ev);
@@ -404,7 +404,7 @@ typedef struct {
 	size_t cm_bytes, sg_bytes, bnd_bytes, cand_bytes, q_ints, cs_ints;      /* scratch of one launch */
 	size_t cm_off, sg_off, bnd_off, cand_off, q_off, cs_off;                /* its slice when the buckets run side by side, else 0 */
 } bplan;
-typedef struct { int32_t key, q; } keyed;
+typedef struct { int32_t key, sub, q; } keyed;
 typedef struct { int32_t key, need, q; } tpend;     /* traceback negotiation: key = band (wave kernel) or scratch need */
 static int tpend_cmp(const void* a, const void* b)
 {
@@ -416,6 +416,7 @@ static int keyed_cmp(const void* a, const void* b)
 {
 	const keyed* x = (const keyed*)a; const keyed* y = (const keyed*)b;
 	if (x->key != y->key) return x->key < y->key ? -1 : 1;
+	if (x->sub != y->sub) return x->sub < y->sub ? -1 : 1;
 	return x->q < y->q ? -1 : (x->q > y->q);
 }
 
@@ -564,7 +565,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 			midpairs = (ssw_pair*)malloc(sizeof(ssw_pair) * (size_t)nm);
 			if (!mk || !midpairs) { free(mk); free(midpairs); free(tk); free(tl_all); return fail(c, "out of host memory%s", ""); }
 			int32_t k = 0, np = 0;
-			for (int32_t q = 0; q < nq; ++q) if (qdone[q]) { const int64_t L = Q->h_off[q + 1] - Q->h_off[q]; if (L > 16 * SSW_RMAX && L <= 640) { mk[k].key = (int32_t)L; mk[k].q = q; ++k; } }
+			for (int32_t q = 0; q < nq; ++q) if (qdone[q]) { const int64_t L = Q->h_off[q + 1] - Q->h_off[q]; if (L > 16 * SSW_RMAX && L <= 640) { mk[k].key = (int32_t)L; mk[k].sub = 0; mk[k].q = q; ++k; } }
 			qsort(mk, (size_t)nm, sizeof(keyed), keyed_cmp);
 			for (int cls = SSW_RMAX + 1; cls <= 40; ++cls) {
 				bucket b; b.R = cls; b.strips = 1; b.P16 = 16 * cls; b.lanes = 16; b.use_x = 0; b.first_pair = np; b.first_q = 0; b.nq = 0;
@@ -818,15 +819,19 @@ typedef struct {
 	int32_t xlanes, xrmax, xrcap;
 } win_in;
 
-static int window_pass(ssw_gpu_ctx* c, const win_in* wi, const bucket* B, int pass, const int32_t* d_list, int32_t cnt)
+/* short-query buckets whose four per-chain profiles would not fit the LDS of a workgroup (alphabets near 32 symbols with many rows per
+   lane) take the strip kernel's window mode like the long ones: one profile per wavefront */
+static int window_on_strips(const bucket* B, int n) { return B->use_x || ssw_shim_capture_lds_need(B->R, n) > SSW_LDS_LIMIT; }
+
+/* `stream`: where a k_capture launch goes (buckets of a mixed-length batch side by side); the strip kernel's window mode shares
+   the context's queue and boundary buffers and always runs on the main stream */
+static int window_pass(ssw_gpu_ctx* c, const win_in* wi, const bucket* B, int pass, const int32_t* d_list, int32_t cnt, void* stream)
 {
 	const ssw_gpu_seqs* Q = wi->Q; const ssw_gpu_params* prm = wi->prm;
 	const int32_t n = wi->n, maxmat = wi->maxmat, refLen = wi->refLen;
 	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
 	if (cnt <= 0) return 0;
-	/* short-query buckets whose four per-chain profiles would not fit the LDS of a workgroup (alphabets near 32
-	   symbols with many rows per lane) take the strip kernel's window mode: one profile per wavefront */
-	const int cap_x = B->use_x || ssw_shim_capture_lds_need(B->R, n) > SSW_LDS_LIMIT;
+	const int cap_x = window_on_strips(B, n);
 	const int32_t capRmax = wi->xrcap < wi->xrmax ? wi->xrcap : wi->xrmax;
 	const int32_t capR = B->use_x ? (B->lanes == 64 && B->R > capRmax ? capRmax : B->R) : ((B->P16 + 63) / 64 < capRmax ? (B->P16 + 63) / 64 : capRmax),
 	              capL = B->use_x ? B->lanes : wi->xlanes;
@@ -870,7 +875,7 @@ static int window_pass(ssw_gpu_ctx* c, const win_in* wi, const bucket* B, int pa
 	ca.tgt = wi->d_tgt; ca.refLen = refLen; ca.qcodes = Q->d_codes; ca.qoff = Q->d_off; ca.qlist = d_list;
 	ca.nq = cnt; ca.mat = wi->d_mat; ca.n = n; ca.gapO2 = gapO2; ca.gapE2 = gapE2; ca.gapE = prm->gapE; ca.maxmat = maxmat;
 	ca.reverse = pass; ca.flag = prm->flag; ca.filters = prm->filters; ca.filterd = prm->filterd; ca.res = wi->d_res; ca.vm = wi->vm;
-	if (ssw_shim_launch_capture(B->R, &ca, c->stream)) return fail(c, "capture launch failed: %s", ssw_shim_last_error());
+	if (ssw_shim_launch_capture(B->R, &ca, stream ? stream : c->stream)) return fail(c, "capture launch failed: %s", ssw_shim_last_error());
 	return 0;
 }
 
@@ -912,7 +917,13 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 		if (ssw_shim_memset(d_resume, 0, sizeof(int32_t) * 8 * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); return -1; }
 		int64_t sstride = ((int64_t)3 * (2 * 16 + 8) * 4 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;
 		/* long reads: one wavefront per alignment (wide bands, 10^4 rows); short reads: one thread per alignment */
-		const int use_wave = c->kn.trace_wave >= 0 ? c->kn.trace_wave : maxlen > 1024;
+		/* Which kernel walks a band.  One THREAD per alignment (k_trace) is right where the band is a handful of cells: round 0 of short reads
+		   (150-bp DNA: 100 000 alignments in 49 ms).  Whatever needs a wider band than round 0's scratch holds -- reads with long indels,
+		   and practically every protein pair: band0 = |refLen' - readLen'| + 1 is tens of cells there -- goes to a TEAM of wavefronts
+		   (k_trace_wave: band rows in LDS, a row's cells in parallel): 88 000 protein tracebacks took 1654 ms on threads and 189 ms on teams
+		   (profiles/round4_dbx.txt).  SSW_GPU_TRACE_WAVE=0 / 1 forces one kernel for all rounds (tests). */
+		const int use_wave0 = c->kn.trace_wave >= 0 ? c->kn.trace_wave : maxlen > 1024;
+		const int use_wave = c->kn.trace_wave >= 0 ? c->kn.trace_wave : 1;      /* rounds after the first */
 		const int trace_no_lds = c->kn.trace_no_lds;     /* experiment / test: band rows in HBM scratch instead of LDS */
 		const int trace_waves_env = c->kn.trace_waves;   /* experiment / test */
 		const int trace_unblocked = c->kn.trace_unblocked;      /* experiment / test: teams with one cell per thread */
@@ -945,14 +956,14 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 					ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;     /* CIGAR slots are indexed by query */
 					ta.resume = d_resume; ta.unblocked = trace_unblocked; ta.waves = 1; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)ssw_shim_trace_lds_need(16, 1);
 					if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
-					    (use_wave ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
+					    (use_wave0 ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
 					    ssw_shim_d2h(hneed, d_need, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
-					    (use_wave && ssw_shim_d2h(hband, d_need + cnt_l, sizeof(int32_t) * (size_t)cnt_l, c->stream)) ||
+					    ssw_shim_d2h(hband, d_need + cnt_l, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
 					    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
 					for (int32_t k = 0; k < cnt_l; ++k)
 						if (hneed[k] != 0) {
 							if (hneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
-							nextp[nnext].key = use_wave ? hband[k] : hneed[k]; nextp[nnext].need = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;
+							nextp[nnext].key = hband[k]; nextp[nnext].need = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;      /* (both kernels report the band that did not fit) */
 						}
 					if (c->kn.debug) fprintf(stderr, "[ssw_gpu] %.1f ms: trace round 0: %d alignments, scratch %lld B each, %d pending so far\n",
 					                                     dbg_ms(), cnt_l, (long long)sstride, nnext);
@@ -1034,7 +1045,7 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 						for (int32_t k = 0; k < cnt_l; ++k)
 							if (gneed[k] != 0) {
 								if (gneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
-								nextp[nnext].key = use_wave ? gband[k] : gneed[k]; nextp[nnext].need = gneed[k]; nextp[nnext].q = lst[grp[gi].g0 + k]; ++nnext;
+								nextp[nnext].key = gband[k]; nextp[nnext].need = gneed[k]; nextp[nnext].q = lst[grp[gi].g0 + k]; ++nnext;
 							}
 					}
 					if (c->kn.debug) fprintf(stderr, "[ssw_gpu] %.1f ms: trace round %d: %d launches side by side, %lld B of scratch, %d pending so far\n",
@@ -1126,7 +1137,7 @@ static int dbx_chunk(ssw_gpu_ctx* c, dbx_state* dx, const ssw_gpu_seqs* Q, const
 			const int32_t f0 = hfirst[b], cntb = hfirst[b + 1] - hfirst[b];
 			if (cntb <= 0) continue;
 			wi.d_res = d_sres + f0; wi.vm = vm; wi.vm.vq = d_vq + f0; wi.vm.vt = d_vt + f0;
-			if (window_pass(c, &wi, &bk[b], 1, d_vl, cntb)) goto out;
+			if (window_pass(c, &wi, &bk[b], 1, d_vl, cntb, 0)) goto out;
 		}
 		ssw_shim_event_record(c->ev_b, c->stream);
 		/* ---- traceback over slabs of survivors (a slab = the CIGAR slots that fit half the budget), CIGARs into the host pool */
@@ -1254,7 +1265,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		if (len == 0) continue;
 		if (len > maxlen) maxlen = (int32_t)len;
 		keys[nqa].q = q;
-		keys[nqa].key = len <= 16 * SSW_RMAX ? (int32_t)((len + 15) / 16) : (int32_t)(SSW_RMAX + (len + 15) / 16);
+		keys[nqa].key = (int32_t)len; keys[nqa].sub = 0;      /* (the bucket keys follow below, once the strip geometry is known) */
 		++nqa;
 	}
 	if (nqa == 0 && ds) { free(order); free(pairs); free(keys); free(qdone); return SSW_NOT_STREAMABLE; }
@@ -1267,7 +1278,6 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		free(order); free(pairs); free(keys); free(qdone);
 		return 0;
 	}
-	qsort(keys, (size_t)nqa, sizeof(keyed), keyed_cmp);
 	/* long queries: the wavefront is one chain of 64 lanes; rows per lane bounded so that one profile stays near 24 KiB
 	   of LDS (several waves per CU).  SSW_GPU_XLANES=16 / SSW_GPU_XR=<rows per lane> override (experiments). */
 	int32_t xlanes = 64, xrmax = 4 * (24 / (n + 1) < 1 ? 1 : 24 / (n + 1) > 3 ? 3 : 24 / (n + 1));
@@ -1283,6 +1293,22 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		/* the target rings hold profile offsets as 16-bit values: residue n (the null column) x ceil(R/4) KiB must stay below 64 KiB */
 		while (xlanes == 64 && xrmax > 4 && (int64_t)n * ((xrmax + 3) / 4) * 1024 > 65535) xrmax -= 4;
 	}
+	/* Bucket keys.  Short queries (<= 384): rows per lane R = ceil(len / 16), all queries of a bucket have the same padded length.  Long
+	   queries of ONE strip (up to 64 x 12 rows): the rows per lane -- queries of DIFFERENT padded lengths share a bucket and its launch (every
+	   job of the strip kernel takes its rows from its own queries; rows below a query's padded length are dead for its half), sorted by
+	   length so that the two queries of a pair mostly have the same one; longer ones: the padded length as before.  One launch per padded length (round 3) made a
+	   batch of mixed long reads a series of small, latency-bound launches. */
+	for (int32_t k = 0; k < nqa; ++k) {
+		const int32_t len = keys[k].key, P16q = (len + 15) / 16 * 16;
+		if (len <= 16 * SSW_RMAX) { keys[k].key = P16q / 16; keys[k].sub = 0; }
+		else {
+			const int32_t rows = xlanes * (xlanes == 64 ? xrmax : SSW_RMAX), st = (P16q + rows - 1) / rows, Rq = (P16q + xlanes * st - 1) / (xlanes * st);
+			/* (only single-strip queries share a bucket across padded lengths: with several strips the 16-bit-rule column maximum -- rows below
+			   P8 -- is masked in the job's LAST strip only, which both queries of a pair must then end in) */
+			keys[k].key = st == 1 ? SSW_RMAX + 1 + Rq : SSW_RMAX + 64 + P16q / 16; keys[k].sub = P16q;
+		}
+	}
+	qsort(keys, (size_t)nqa, sizeof(keyed), keyed_cmp);
 	for (int32_t i = 0; i < nqa; ) {
 		int32_t j = i;
 		while (j < nqa && keys[j].key == keys[i].key) ++j;
@@ -1292,7 +1318,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		bucket b;
 		if (keys[i].key <= SSW_RMAX) { b.R = keys[i].key; b.strips = 1; b.P16 = 16 * b.R; b.lanes = 16; b.use_x = 0; }
 		else {
-			b.P16 = 16 * (keys[i].key - SSW_RMAX);
+			b.P16 = keys[j - 1].sub;       /* the longest of the bucket (sorted by padded length) */
 			b.lanes = xlanes; b.use_x = 1;
 			const int32_t rows = b.lanes * (b.lanes == 64 ? xrmax : SSW_RMAX);
 			b.strips = (b.P16 + rows - 1) / rows;
@@ -1313,6 +1339,8 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 
 	int rc = -1;
 	bplan* bplans = 0;
+	struct fill_defer { ssw_fill_args fa; int R, group; int64_t wgs; } *defer = 0;      /* short-query buckets that join a multi-bucket grid */
+	ssw_reduce_args* rdefer = 0;                                                          /* ... and the reductions of all buckets of a side-by-side group */
 	int* border = (int*)malloc(sizeof(int) * (size_t)(nb > 0 ? nb : 1));      /* buckets by size (side-by-side launches go largest first) */
 	uint32_t* pool = 0; int64_t pool_words = 0, pool_cap = 0;
 	ssw_dres* hres = (ssw_dres*)malloc(sizeof(ssw_dres) * (size_t)nq);
@@ -1484,7 +1512,7 @@ plan_again:
 					else if (chunk >= unit) chunk = chunk / unit * unit;
 				}
 				P->tile = tile; P->halo = halo; P->ntiles = ntiles; P->maxcols = maxcols; P->chunk = chunk; P->dbl = dbl;
-				P->seg = !use_x && !dbl && !c->kn.no_seg_reduce;      /* short-query buckets: k_fill also leaves the maxima of 16-column groups, which is all the reduction reads */
+				P->seg = !dbl && !c->kn.no_seg_reduce ;      /* the fill kernels also leave the maxima of 16-column groups, which is all the reduction reads */
 				P->cm_bytes = ALIGN16(4 * stride * chunk);
 				P->sg_bytes = P->seg ? ALIGN16(4 * seg_stride * chunk) : 0;
 				P->bnd_bytes = use_x ? ALIGN16(16 * maxcols * ntiles * chunk) : 0;
@@ -1506,7 +1534,7 @@ plan_again:
 			   streams; the main stream continues after all of them.  SSW_GPU_SERIAL_BUCKETS=1 keeps the old order (tests compare). */
 			conc = nact > 1 && !c->kn.serial_buckets && !any_dbl && !any_chunked && 2 * tot_cm + 2 * tot_sg + tot_bnd + tot_cand <= c->cm_budget;
 			if (!conc) for (int b = 0; b < nb; ++b) { bplan* P = &bplans[b]; P->cm_off = P->sg_off = P->bnd_off = P->cand_off = 0; P->q_off = P->cs_off = 0; }
-#define SSW_ALLOC_RETRY() do { if (c->cm_budget > ((size_t)8 << 20) && max_chunk > 1) { c->cm_budget /= c->budget_shrunk ? 2 : 4; c->budget_shrunk = 1; c->err[0] = 0; goto plan_again; } goto done; } while (0)
+#define SSW_ALLOC_RETRY() do { if (c->cm_budget > ((size_t)2 << 20) && max_chunk > 1) { c->cm_budget /= c->budget_shrunk ? 2 : 4; c->budget_shrunk = 1; c->err[0] = 0; goto plan_again; } goto done; } while (0)
 			unsigned char *base_cm16 = 0, *base_cm8 = 0, *base_cmB16 = 0, *base_cmB8 = 0, *base_sg16 = 0, *base_sg8 = 0, *base_bnd = 0, *base_cand = 0;
 			int32_t *base_q = 0, *base_cs = 0;
 			if (nact > 0) {
@@ -1532,6 +1560,10 @@ plan_again:
 				}
 			}
 			void *ge0 = 0, *ge1 = 0; int side_used[SSW_TSTREAMS]; int nside = 0;
+			int ndefer = 0;
+			if (!defer) defer = (struct fill_defer*)malloc(sizeof(struct fill_defer) * (size_t)(nb > 0 ? nb : 1));
+			if (!rdefer) rdefer = (ssw_reduce_args*)malloc(sizeof(ssw_reduce_args) * (size_t)(nb > 0 ? nb : 1));
+			if (!defer || !rdefer) { fail(c, "out of host memory%s", ""); goto done; }
 			for (int sx = 0; sx < SSW_TSTREAMS; ++sx) side_used[sx] = 0;
 			if (conc) {
 				ge0 = next_event(c); ge1 = next_event(c);
@@ -1544,11 +1576,16 @@ plan_again:
 					border[j] = v;
 				}
 			}
+			int nrdefer = 0;
+			/* side by side: the short-query buckets first (their grids are the bulk of the work and go to the hardware queues at once), then the
+			   strip kernel's launches */
+			for (int pass_x = 0; pass_x < (conc ? 2 : 1); ++pass_x) {
 			for (int bi_ = 0; bi_ < nb; ++bi_) {
 				const int b = conc ? border[bi_] : bi_;
 				const bucket* B = &bk[b];
 				const bplan* P = &bplans[b];
 				if (!P->active) continue;
+				if (conc && (B->use_x != 0) != pass_x) continue;
 				const int use_x = B->use_x, dbl = P->dbl;
 				const int32_t tile = P->tile, halo = P->halo, ntiles = P->ntiles;
 				const int64_t maxcols = P->maxcols, chunk = P->chunk;
@@ -1592,6 +1629,7 @@ plan_again:
 						xa.gapO2 = gapO2; xa.gapE2 = gapE2; xa.gapE = prm->gapE; xa.maxmat = maxmat; xa.njobs = np * ntiles;
 						xa.pairs = fa.pairs; xa.tile = tile; xa.halo = halo; xa.ntiles = ntiles; xa.cm16 = d_cm16; xa.cm8 = d_cm8;
 						xa.cm_stride = stride; xa.bnd = d_bnd; xa.bnd_stride = maxcols; xa.cand = d_cand; xa.lanes = B->lanes;
+						xa.sg16 = d_sg16; xa.sg8 = d_sg8; xa.seg_stride = seg_stride;
 						if (B->lanes == 64) {     /* strips of all jobs behind one work queue (k_chainq) */
 							const int qgrid = chainq_grid(c, B->R, 0, n);
 							if (conc ? chainq_setup(c, &xa, B->strips, (int64_t)np * ntiles, qgrid, base_q + P->q_off, base_cs + P->cs_off, st)
@@ -1603,6 +1641,9 @@ plan_again:
 							if (c->kn.debug) { const int src = ssw_shim_stream_sync(st); fprintf(stderr, "[ssw_gpu] chainq fill done (sync rc %d: %s)\n", src, src ? ssw_shim_last_error() : "ok"); }
 						} else
 						if (ssw_shim_launch_chainx(B->R, 0, &xa, st)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
+					} else
+					if (conc) {      /* short-query buckets side by side: their workgroups join the grid of their register class (k_fillm, below) */
+						defer[ndefer].fa = fa; defer[ndefer].R = B->R; defer[ndefer].wgs = (int64_t)np * fa.bpp; defer[ndefer].group = ssw_shim_fill_class(B->R) * 2 + (fa.form == 3);
 					} else
 					if (ssw_shim_launch_fill(B->R, &fa, st)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
 					if (!conc) { ssw_shim_event_record(e1, st); c->tm.fill_launches++; }
@@ -1632,6 +1673,8 @@ plan_again:
 						if (ssw_shim_launch_reduce(&ra, c->stream2)) { fail(c, "reduce launch failed: %s", ssw_shim_last_error()); goto done; }
 						ssw_shim_event_record(c->ev_red[bi], c->stream2);
 					} else
+					if (conc) { rdefer[nrdefer++] = ra; if (!use_x) ++ndefer; }      /* all reductions of the group as one grid, after the join (below) */
+					else
 					if (ssw_shim_launch_reduce(&ra, st)) { fail(c, "reduce launch failed: %s", ssw_shim_last_error()); goto done; }
 				}
 				if (dbl) {   /* everything later on the main stream sees all records of this bucket */
@@ -1639,11 +1682,55 @@ plan_again:
 					if (launch_i > 1) ssw_shim_stream_wait_event(c->stream, c->ev_red[1]);
 				}
 			}
+			if (conc && pass_x == 0 && ndefer > 0) {
+				/* one grid per (register class, form) of the deferred short-query buckets, longest chains first */
+				const size_t rec = sizeof(ssw_fill_args);
+				unsigned char* htab = (unsigned char*)calloc((rec + 16) * (size_t)ndefer + 64 * 6, 1);
+				unsigned char* dtab = (unsigned char*)ensure(c, &c->fmtab, (rec + 16) * (size_t)ndefer + 64 * 6);
+				if (!htab || !dtab) { free(htab); if (!htab) fail(c, "out of host memory%s", ""); goto done; }
+				size_t at = 0;
+				for (int g = 0; g < 6; ++g) {
+					int idx[SSW_RMAX + 1], ng = 0;
+					for (int i = 0; i < ndefer; ++i) if (defer[i].group == g) idx[ng++] = i;
+					if (ng == 0) continue;
+					for (int i = 1; i < ng; ++i) { const int v = idx[i]; int j = i; while (j > 0 && defer[idx[j - 1]].R < defer[v].R) { idx[j] = idx[j - 1]; --j; } idx[j] = v; }
+					const size_t a0 = at, a1 = a0 + ALIGN16(rec * (size_t)ng), a2 = a1 + ALIGN16(4 * ((size_t)ng + 1));
+					int32_t* hfirst = (int32_t*)(htab + a1); int32_t* hR = (int32_t*)(htab + a2);
+					int64_t total = 0;
+					for (int i = 0; i < ng; ++i) { memcpy(htab + a0 + rec * (size_t)i, &defer[idx[i]].fa, sizeof(ssw_fill_args)); hfirst[i] = (int32_t)total; hR[i] = defer[idx[i]].R; total += defer[idx[i]].wgs; }
+					hfirst[ng] = (int32_t)total;
+					at = a2 + ALIGN16(4 * (size_t)ng);
+					if (total > 0x7fffffff) { free(htab); fail(c, "internal error: %s", "more than 2^31 workgroups in one multi-bucket fill launch"); goto done; }
+					const int sx = nside++ % SSW_TSTREAMS;
+					void* st = c->tstream[sx];
+					if (!side_used[sx]) { side_used[sx] = 1; if (ssw_shim_stream_wait_event(st, c->ev_db)) { free(htab); fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; } }
+					ssw_fillm_args ma; ma.sub = (const ssw_fill_args*)(dtab + a0); ma.first_wg = (const int32_t*)(dtab + a1); ma.subR = (const int32_t*)(dtab + a2); ma.nsub = ng;
+					if (ssw_shim_h2d(dtab + a0, htab + a0, at - a0, st) || ssw_shim_launch_fillm(&ma, hR, n, g & 1 ? 3 : 0, total, st)) {
+						free(htab); fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done;
+					}
+				}
+				free(htab);
+			}
+			}      /* pass_x */
 			if (conc) {      /* the main stream continues after all of them; the group counts as one launch (its event pair brackets the side streams' work) */
 				for (int sx = 0; sx < SSW_TSTREAMS; ++sx)
 					if (side_used[sx] && (ssw_shim_event_record(c->tev[sx], c->tstream[sx]) || ssw_shim_stream_wait_event(c->stream, c->tev[sx]))) {
 						fail(c, "stream join failed: %s", ssw_shim_last_error()); goto done;
 					}
+				if (nrdefer > 0) {      /* every bucket's reduction in one grid: one workgroup per pair */
+					const size_t rec = sizeof(ssw_reduce_args), a1 = ALIGN16(rec * (size_t)nrdefer);
+					unsigned char* htab = (unsigned char*)calloc(a1 + 4 * ((size_t)nrdefer + 1) + 16, 1);
+					unsigned char* dtab = (unsigned char*)ensure(c, &c->fmtab, a1 + 4 * ((size_t)nrdefer + 1) + 16);
+					if (!htab || !dtab) { free(htab); if (!htab) fail(c, "out of host memory%s", ""); goto done; }
+					int32_t* hfirst = (int32_t*)(htab + a1);
+					int64_t total = 0;
+					for (int i = 0; i < nrdefer; ++i) { memcpy(htab + rec * (size_t)i, &rdefer[i], rec); hfirst[i] = (int32_t)total; total += rdefer[i].npairs; }
+					hfirst[nrdefer] = (int32_t)total;
+					ssw_reducem_args rm; rm.sub = (const ssw_reduce_args*)dtab; rm.first_wg = (const int32_t*)(dtab + a1); rm.nsub = nrdefer;
+					const int bad = ssw_shim_h2d(dtab, htab, a1 + 4 * ((size_t)nrdefer + 1), c->stream) || ssw_shim_launch_reducem(&rm, total, c->stream);
+					free(htab);
+					if (bad) { fail(c, "reduce launch failed: %s", ssw_shim_last_error()); goto done; }
+				}
 				ssw_shim_event_record(ge1, c->stream);
 				c->tm.fill_launches++;
 			}
@@ -1654,11 +1741,28 @@ plan_again:
 			win_in wi; memset(&wi, 0, sizeof wi);
 			wi.Q = Q; wi.prm = prm; wi.d_tgt = d_tgt; wi.refLen = refLen; wi.d_mat = d_mat; wi.n = n; wi.maxmat = maxmat; wi.minmat = minmat;
 			wi.fill_form = fill_form; wi.d_res = d_res; wi.xlanes = xlanes; wi.xrmax = xrmax; wi.xrcap = xrcap;
+			/* a batch of many buckets: the k_capture launches (one small, latency-bound grid per bucket) side by side -- a bucket keeps its
+			   side stream for both passes (the reverse pass reads what the locate pass wrote) */
+			int nwin = 0, wused[SSW_TSTREAMS];
+			for (int b = 0; b < nb; ++b) if (!qdone[order[bk[b].first_q]] && !window_on_strips(&bk[b], n)) ++nwin;
+			const int fan = nwin > 2 && !c->kn.serial_buckets;
+			for (int sx = 0; sx < SSW_TSTREAMS; ++sx) wused[sx] = 0;
+			if (fan && ssw_shim_event_record(c->ev_db, c->stream)) { fail(c, "event record failed: %s", ssw_shim_last_error()); goto done; }
 			for (int pass = 0; pass < (prm->flag != 0 ? 2 : 1); ++pass)
 				for (int b = 0; b < nb; ++b) {
 					const bucket* B = &bk[b];
 					if (qdone[order[B->first_q]]) continue;
-					if (window_pass(c, &wi, B, pass, d_qlist + B->first_q, B->nq)) goto done;
+					void* st = 0;
+					if (fan && !window_on_strips(B, n)) {
+						const int sx = b % SSW_TSTREAMS;
+						st = c->tstream[sx];
+						if (!wused[sx]) { wused[sx] = 1; if (ssw_shim_stream_wait_event(st, c->ev_db)) { fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; } }
+					}
+					if (window_pass(c, &wi, B, pass, d_qlist + B->first_q, B->nq, st)) goto done;
+				}
+			for (int sx = 0; sx < SSW_TSTREAMS; ++sx)
+				if (wused[sx] && (ssw_shim_event_record(c->tev[sx], c->tstream[sx]) || ssw_shim_stream_wait_event(c->stream, c->tev[sx]))) {
+					fail(c, "stream join failed: %s", ssw_shim_last_error()); goto done;
 				}
 		}
 		ssw_shim_event_record(c->ev_b, c->stream);
@@ -1739,7 +1843,7 @@ plan_again:
 	if (cigar_words) *cigar_words = pool_words;
 	rc = 0;
 done:
-	free(pool); free(order); free(pairs); free(hres); free(hneed); free(bk); free(qdone); free(bplans); free(border);
+	free(pool); free(order); free(pairs); free(hres); free(hneed); free(bk); free(qdone); free(bplans); free(border); free(defer); free(rdefer);
 	return rc;
 }
 

@@ -175,14 +175,13 @@ SSW_DEV void fill_flush16(unsigned char* lds, u32 out16, u32 out8, int base, int
 /* (up to 10 rows per lane the kernel is held to 72 registers -- seven wavefronts per SIMD; hipcc otherwise takes 74, i.e. 80, and
    the one spill this costs is a pointer reloaded once per 16 steps) */
 template <int R, int FORM>
-__global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fill(ssw_fill_args a)
+SSW_DEV void fill_body(const ssw_fill_args& a, const int bid, unsigned char* lds)
 {
 	constexpr bool FR = FORM == 3;
 	typedef ChainGeom<R> G;
 	constexpr int C = G::C;
-	SSW_DYN_LDS(lds);
 	const int tid = (int)threadIdx.x, l16 = tid & 15, grp = tid >> 4;
-	const int pair = (int)blockIdx.x / a.bpp, tchunk = (int)blockIdx.x - pair * a.bpp;
+	const int pair = bid / a.bpp, tchunk = bid - pair * a.bpp;
 	const int gapEi = (int)(a.gapE2 & 0xffffu);
 	const u32 prof_bytes = (u32)(a.n + 1) * G::PSTRIDE;
 	const u32 ring = prof_bytes + (u32)grp * CHAIN_BYTES, out16 = ring + RING_BYTES, out8 = out16 + 256;
@@ -301,6 +300,39 @@ __global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fi
 	wave_lds_fence();
 	for (int base = nsteps - 32; base < nsteps; base += 16)
 		if (base >= 0) fill_flush16<R, FORM>(lds, out16, out8, base, l16, store_from, ncols, o16, o8, g16, g8, a.fr_base, a.fr_kmask, gapEi);
+}
+
+template <int R, int FORM>
+__global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(R <= 10 ? 7 : 1, 8) k_fill(ssw_fill_args a)
+{
+	SSW_DYN_LDS(lds);
+	fill_body<R, FORM>(a, (int)blockIdx.x, lds);
+}
+
+/* k_fillm: SEVERAL geometry buckets in one launch (round 4).  A batch of mixed read lengths -- the reference's own benchmark: 1000 reads of
+   25-540 bp -- is ~25 buckets with a few pairs each; as 25 launches they queue up behind each other on the four hardware queues and the
+   device ends with a long thin tail of small kernels (profiles/round4_config6_timeline.txt).  Here the workgroups of all buckets of one
+   register class (rows per lane 1-10 / 11-16 / 17-24: 72 / 96 / 128 registers) form one grid -- the sub-launch of a workgroup is found from
+   a table, the body is the same fill_body<R> -- longest chains first, and the hardware dispatches them as slots free up. */
+template <int CLS> struct FillClass { static constexpr int LO = CLS == 0 ? 1 : CLS == 1 ? 11 : 17, HI = CLS == 0 ? 10 : CLS == 1 ? 16 : 24; };
+template <int R, int CLS, int FORM> SSW_DEV void fillm_case(const ssw_fill_args& a, int bid, unsigned char* lds)
+{
+	if (R >= FillClass<CLS>::LO && R <= FillClass<CLS>::HI) fill_body<(R >= FillClass<CLS>::LO && R <= FillClass<CLS>::HI) ? R : FillClass<CLS>::LO, FORM>(a, bid, lds);
+}
+template <int CLS, int FORM>
+__global__ void __launch_bounds__(256) SSW_WAVES_PER_EU(CLS == 0 ? 7 : 1, 8) k_fillm(ssw_fillm_args m)
+{
+	SSW_DYN_LDS(lds);
+	int s = 0;
+	while (s + 1 < m.nsub && (int)blockIdx.x >= m.first_wg[s + 1]) ++s;      /* (uniform: scalar loads) */
+	const ssw_fill_args a = m.sub[s];
+	const int bid = (int)blockIdx.x - m.first_wg[s];
+	switch (m.subR[s]) {
+#define X(r) case r: fillm_case<r, CLS, FORM>(a, bid, lds); break;
+		X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+#undef X
+		default: break;
+	}
 }
 
 /* ================================================================================================
@@ -800,10 +832,9 @@ SSW_DEV void seg_first_column(const uint32_t* cols, int seg, int refLen, int hi,
 	}
 }
 
-__global__ void __launch_bounds__(256) k_reduce_seg(ssw_reduce_args a)
+SSW_DEV void reduce_seg_body(const ssw_reduce_args& a, const int pair, unsigned char* lds)
 {
-	SSW_DYN_LDS(lds);
-	const int tid = (int)threadIdx.x, pair = (int)blockIdx.x;
+	const int tid = (int)threadIdx.x;
 	const ssw_pair pr = a.pairs[pair];
 	const uint32_t* c16 = a.cm16 + (int64_t)pair * a.cm_stride;
 	const uint32_t* c8 = a.cm8 + (int64_t)pair * a.cm_stride;
@@ -881,10 +912,35 @@ __global__ void __launch_bounds__(256) k_reduce_seg(ssw_reduce_args a)
 					r[h].score2 = s2[h]; r[h].ref_end2 = s2[h] > 0 ? i2 : 0;
 				} else { r[h].score2 = 0; r[h].ref_end2 = -1; }
 				r[h].want_begin = !(a.flag == 0 || (a.flag == 2 && best[h] < a.filters));   /* ssw.c:916 */
+				if (a.cand) {   /* the strip kernel tracked its best cell: the tile that owns ref_end1 knows the row (as k_reduce) */
+					const int32_t* cd = a.cand + (((int64_t)pair * a.ntiles + bidx[h] / a.tile) * 2 + h) * 4;
+					if (cd[0] == best[h] && cd[1] == bidx[h]) {
+						const int len = (int)(a.qoff[q + 1] - a.qoff[q]);
+						r[h].read_end1 = cd[2] < len - 1 ? cd[2] : len - 1;
+						r[h].loc_done = 1;
+					}
+				}
 			}
 			a.res[q] = r[h];
 		}
 	}
+}
+
+__global__ void __launch_bounds__(256) k_reduce_seg(ssw_reduce_args a)
+{
+	SSW_DYN_LDS(lds);
+	reduce_seg_body(a, (int)blockIdx.x, lds);
+}
+
+/* the reductions of several buckets in one grid (one workgroup per pair; a launch per bucket is as slow as ONE pair's scan -- 1.5 ms
+   over a 5 Mb target -- however few pairs the bucket has, and 25 of them in a row were a tenth of a mixed-length batch's time) */
+__global__ void __launch_bounds__(256) k_reducem(ssw_reducem_args m)
+{
+	SSW_DYN_LDS(lds);
+	int s = 0;
+	while (s + 1 < m.nsub && (int)blockIdx.x >= m.first_wg[s + 1]) ++s;
+	const ssw_reduce_args a = m.sub[s];
+	reduce_seg_body(a, (int)blockIdx.x - m.first_wg[s], lds);
 }
 
 /* ================================================================================================
@@ -1094,6 +1150,7 @@ struct StripCtx {
 	const int8_t* tg;
 	u32* bnd;          /* this job's boundary records */
 	u32* o16; u32* o8; /* fill: column maxima of the last strip */
+	u32* g16; u32* g8; /* fill, optional: maxima of every aligned group of 16 columns (as k_fill writes them): k_reduce_seg scans these */
 	u32 gapO2, gapE2;
 	int n;
 	u32 bmask;         /* boundary-out ring: entries - 1 (63, or 31 in the LDS-trimmed queue kernel) */
@@ -1126,6 +1183,19 @@ SSW_DEV void strip_record(u32 now, u32 pre, int tc, const StripCtx& x, const u32
 			}
 		}
 	}
+}
+
+/* last strip of a fill job: the maximum of the 16 finished columns [base, base + 16) that the staging lanes (one DPP row) have just
+   flushed, for both padding rules -- what k_fill's fill_flush16 leaves for k_reduce_seg.  Executed by every lane of the wavefront (the
+   butterfly stays inside a DPP row; only the chain's lane 0 stores). */
+SSW_DEV void strip_group_max(const u32x4& rec, bool valid, int base, const StripCtx& x)
+{
+	u32 m16 = valid ? rec[2] : 0u, m8 = valid ? rec[3] : 0u;
+	m16 = pk_max(m16, xl_row_ror<1>(m16)); m8 = pk_max(m8, xl_row_ror<1>(m8));
+	m16 = pk_max(m16, xl_row_ror<2>(m16)); m8 = pk_max(m8, xl_row_ror<2>(m8));
+	m16 = pk_max(m16, xl_row_ror<4>(m16)); m8 = pk_max(m8, xl_row_ror<4>(m8));
+	m16 = pk_max(m16, xl_row_ror<8>(m16)); m8 = pk_max(m8, xl_row_ror<8>(m8));
+	if (x.l16 == 0 && x.mine && base >= x.store_from && base < x.ncols) { x.g16[base >> 4] = m16; x.g8[base >> 4] = m8; }
 }
 
 /* FR (fill mode only): column-frame form of the recurrence (chain_rows_fr).  Boundary records travel between strips as TRUE values:
@@ -1229,13 +1299,16 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			nb = bnd_in(nb, tc);
 		}
 		wave_lds_fence();
-		if (s0 >= GL + 16 && stg) {   /* boundary-out records of columns [s0-GL-16, s0-GL) are complete */
+		if (s0 >= GL + 16) {   /* boundary-out records of columns [s0-GL-16, s0-GL) are complete */
 			const int tc = s0 - GL - 16 + l16;
-			if (x.mine && tc < x.ncols) {
-				const u32x4 rec = bnd_out(lds_ld128(lds, x.bout + 16u * ((u32)tc & x.bmask)), tc);
+			u32x4 rec = zero4;
+			const bool have = stg && x.mine && tc < x.ncols;
+			if (have) {
+				rec = bnd_out(lds_ld128(lds, x.bout + 16u * ((u32)tc & x.bmask)), tc);
 				if (!x.last) *(u32x4*)(x.bnd + 4 * (int64_t)tc) = rec;
 				else if (!CAPTURE && tc >= x.store_from) { x.o16[tc] = rec[2]; x.o8[tc] = rec[3]; }
 			}
+			if (!CAPTURE && x.last && x.g16) strip_group_max(rec, have && tc >= x.store_from, s0 - GL - 16, x);
 		}
 		wave_lds_fence();
 		const u32 rpo = 2u * (u32)((s0 - l16) & (RB - 1));
@@ -1347,11 +1420,14 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	wave_lds_fence();
 	for (int base = x.nsteps - GL - 16; base < x.nsteps - GL + 16; base += 16) {
 		const int tc = base + l16;
-		if (stg && x.mine && tc >= 0 && tc < x.ncols) {
-			const u32x4 rec = bnd_out(lds_ld128(lds, x.bout + 16u * ((u32)tc & x.bmask)), tc);
+		u32x4 rec = zero4;
+		const bool have = stg && x.mine && tc >= 0 && tc < x.ncols;
+		if (have) {
+			rec = bnd_out(lds_ld128(lds, x.bout + 16u * ((u32)tc & x.bmask)), tc);
 			if (!x.last) *(u32x4*)(x.bnd + 4 * (int64_t)tc) = rec;
 			else if (!CAPTURE && tc >= x.store_from) { x.o16[tc] = rec[2]; x.o8[tc] = rec[3]; }
 		}
+		if (!CAPTURE && x.last && x.g16 && base >= 0) strip_group_max(rec, have && tc >= x.store_from, base, x);
 	}
 	if (!CAPTURE) {   /* merge the strip's best cell into the lane's: higher value, then earlier column, then smaller row */
 #pragma unroll
@@ -1440,7 +1516,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 	int lena = 0, lenb = 0, rev = 0, rowsa = 0, rowsb = 0, rows_total = 0, p8a = 0, p8b = 0;
 	bool active = false;
 	CapHalf ch[2];
-	x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0;
+	x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0; x.g16 = 0; x.g8 = 0;
 	x.ncols2[0] = x.ncols2[1] = 0; x.c_edge2[0] = x.c_edge2[1] = 0;
 	if (!CAPTURE) {
 		if (valid) {
@@ -1449,12 +1525,13 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 			qa = a.qcodes + a.qoff[pr.qa]; lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
 			if (pr.qb >= 0) { qb = a.qcodes + a.qoff[pr.qb]; lenb = (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]); }
 			rows_total = ((lena > lenb ? lena : lenb) + 15) & ~15;
-			rowsa = rowsb = rows_total;
+			rowsa = (lena + 15) & ~15; rowsb = qb ? (lenb + 15) & ~15 : rows_total;      /* rows below a query's OWN padded length are dead for its half */
 			p8a = (lena + 7) & ~7; p8b = qb ? (lenb + 7) & ~7 : rows_total;
 			const int tile_lo = t * a.tile, tile_hi = tile_lo + a.tile < a.refLen ? tile_lo + a.tile : a.refLen;
 			const int c_first = tile_lo - a.halo > 0 ? tile_lo - a.halo : 0;
 			x.c_edge = c_first; x.ncols = tile_hi - c_first; x.store_from = tile_lo - c_first;
 			x.o16 = a.cm16 + (int64_t)pair * a.cm_stride + c_first; x.o8 = a.cm8 + (int64_t)pair * a.cm_stride + c_first;
+			if (a.sg16) { x.g16 = a.sg16 + (int64_t)pair * a.seg_stride + (c_first >> 4); x.g8 = a.sg8 + (int64_t)pair * a.seg_stride + (c_first >> 4); }      /* (tiles and halos are multiples of 16 columns) */
 			active = true;
 		}
 	} else {
@@ -1594,7 +1671,7 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 		int lena = 0, lenb = 0, rev = 0, rowsa = 0, rowsb = 0, rows_total = 0, p8a = 0, p8b = 0;
 		bool active = false;
 		CapHalf ch[2];
-		x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0;
+		x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0; x.g16 = 0; x.g8 = 0;
 		x.ncols2[0] = x.ncols2[1] = 0; x.c_edge2[0] = x.c_edge2[1] = 0;
 		if (sidx > 0) {   /* everything the strip above wrote -- boundary records, its best cell, and (window passes) the records */
 			if (!a.whole_jobs && tid == 0 && !dev_flag_wait(flags + (int64_t)job * S + sidx - 1)) atomicAdd(a.err, 1);   /* error word: the host fails the call */
@@ -1606,12 +1683,13 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 			qa = a.qcodes + a.qoff[pr.qa]; lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
 			if (pr.qb >= 0) { qb = a.qcodes + a.qoff[pr.qb]; lenb = (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]); }
 			rows_total = ((lena > lenb ? lena : lenb) + 15) & ~15;
-			rowsa = rowsb = rows_total;
+			rowsa = (lena + 15) & ~15; rowsb = qb ? (lenb + 15) & ~15 : rows_total;      /* rows below a query's OWN padded length are dead for its half */
 			p8a = (lena + 7) & ~7; p8b = qb ? (lenb + 7) & ~7 : rows_total;
 			const int tile_lo = t * a.tile, tile_hi = tile_lo + a.tile < a.refLen ? tile_lo + a.tile : a.refLen;
 			const int c_first = tile_lo - a.halo > 0 ? tile_lo - a.halo : 0;
 			x.c_edge = c_first; x.ncols = tile_hi - c_first; x.store_from = tile_lo - c_first;
 			x.o16 = a.cm16 + (int64_t)pair * a.cm_stride + c_first; x.o8 = a.cm8 + (int64_t)pair * a.cm_stride + c_first;
+			if (a.sg16) { x.g16 = a.sg16 + (int64_t)pair * a.seg_stride + (c_first >> 4); x.g8 = a.sg8 + (int64_t)pair * a.seg_stride + (c_first >> 4); }      /* (tiles and halos are multiples of 16 columns) */
 			active = true;
 		} else {
 			cap_half_setup(ch[0], a, a.qlist[2 * job]);
@@ -2525,7 +2603,7 @@ __global__ void __launch_bounds__(64) k_trace(ssw_trace_args a)
 		int64_t need = 0;
 		nops = trace_one(ref, read, refLen, readLen, r.score1, a.gapO, a.gapE, band, a.mat, a.n, scratch, scap,
 		                 cig, (int)a.cigar_stride, &need);
-		if (nops == -2) { a.need[job] = need > 0 ? (int)((need + 4095) >> 12) : -1; return; }   /* in 4-KiB units */
+		if (nops == -2) { a.need[job] = need > 0 ? (int)((need + 4095) >> 12) : -1; a.need[a.nq + job] = band; return; }   /* in 4-KiB units; the band that did not fit (as k_trace_wave) */
 		if (nops < 0) break;
 		if (cigar_score(cig, nops, ref, read, a.mat, a.n, a.gapO, a.gapE) == r.score1) break;
 		if (band >= full) { nops = -1; break; }
@@ -2772,12 +2850,40 @@ extern "C" int ssw_shim_launch_filldb(int R, const ssw_filldb_args* a, void* str
 	return SSW_LAUNCH_OK();
 }
 
+/* several buckets in one grid: hR = the rows per lane of the nsub sub-launches (host copy: sizes the LDS), all of one register class and form */
+extern "C" int ssw_shim_fill_class(int R) { return R <= 10 ? 0 : R <= 16 ? 1 : 2; }
+extern "C" int ssw_shim_launch_fillm(const ssw_fillm_args* a, const int32_t* hR, int n, int form, int64_t total_wgs, void* stream)
+{
+	ssw_fillm_args args = *a;
+	if (total_wgs <= 0 || args.nsub <= 0) return 0;
+	const int cls = ssw_shim_fill_class(hR[0]);
+	size_t ldsb = 0;
+	for (int i = 0; i < args.nsub; ++i) {
+		if (ssw_shim_fill_class(hR[i]) != cls || hR[i] < 1 || hR[i] > SSW_RMAX) return -2;
+		const size_t b = (size_t)(n + 1) * (size_t)((hR[i] + 3) / 4) * 256 + 16 * CHAIN_BYTES;
+		if (b > ldsb) ldsb = b;
+	}
+#define X(c) if (cls == c) { if (form == 3) SSW_LAUNCH((k_fillm<c, 3>), ssw_fillm_args, args, total_wgs, 256, ldsb, stream); \
+                             else SSW_LAUNCH((k_fillm<c, 0>), ssw_fillm_args, args, total_wgs, 256, ldsb, stream); }
+	X(0) X(1) X(2)
+#undef X
+	return SSW_LAUNCH_OK();
+}
+
 extern "C" int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream)
 {
 	ssw_reduce_args args = *a;
 	if (args.npairs <= 0) return 0;
 	if (args.sg16) SSW_LAUNCH(k_reduce_seg, ssw_reduce_args, args, args.npairs, 256, 256 * 8, stream);
 	else SSW_LAUNCH(k_reduce, ssw_reduce_args, args, args.npairs, 256, 256 * 8, stream);
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_launch_reducem(const ssw_reducem_args* a, int64_t total_pairs, void* stream)
+{
+	ssw_reducem_args args = *a;
+	if (total_pairs <= 0 || args.nsub <= 0) return 0;
+	SSW_LAUNCH(k_reducem, ssw_reducem_args, args, total_pairs, 256, 256 * 8, stream);
 	return SSW_LAUNCH_OK();
 }
 

@@ -365,3 +365,70 @@ def test_team_traceback_many_cells_per_thread(ectx, teams, blocked, monkeypatch)
     monkeypatch.setenv("SSW_GPU_TRACE_BLOCKED", blocked)
     for reads, ref in team_traceback_cases(1):
         _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
+
+
+def test_mixed_read_lengths_buckets_side_by_side_and_one_after_the_other(ectx, monkeypatch):
+    """the README's benchmark shape in small: ~15 geometry buckets with a few reads each.  By default the short-query buckets join one
+    grid per register class (k_fillm) and the launches run on side streams; SSW_GPU_SERIAL_BUCKETS=1 keeps one launch per bucket on the
+    main stream.  Both against the reference, and against each other."""
+    import workloads as W
+    ref, reads, _ = W.mixed_config(0, reads=40, ref_len=6000)
+    mat = dna_matrix(2, 2)
+    Q = ectx.upload(reads); T = ectx.upload([ref])
+    try:
+        for flag in (0, 2):
+            res, cig = ectx.align_batch(Q, T, mat, 5, 3, 1, flag, 0, 0, -1, 2)
+            groups = ectx.timing()["fill_launches"]
+            bad = compare_batch(res, cig, reads, [ref], mat, 5, 3, 1, flag, 0, 0, -1, 2)
+            assert not bad, "\n".join(bad)
+            monkeypatch.setenv("SSW_GPU_SERIAL_BUCKETS", "1")
+            res2, cig2 = ectx.align_batch(Q, T, mat, 5, 3, 1, flag, 0, 0, -1, 2)
+            monkeypatch.delenv("SSW_GPU_SERIAL_BUCKETS")
+            assert groups == 1 and ectx.timing()["fill_launches"] > 8       # one launch group vs one launch per bucket
+            assert all((res[f] == res2[f]).all() for f in res.dtype.names if f != "cigar_off")
+    finally:
+        Q.free(); T.free()
+
+
+def test_long_reads_of_different_padded_lengths_share_a_launch(ectx):
+    """single-strip long reads (385..768 residues) are bucketed by rows per lane, not by padded length: the two queries of a pair may
+    have different padded lengths (rows below a query's own padded length are dead for its half), padded and unpadded lengths
+    (len mod 16 in 1..8 changes the 16-bit-rule maximum), next to multi-strip reads that keep one bucket per padded length"""
+    from sswutil import mutate
+    rng = np.random.default_rng(9)
+    ref = random_ref(5000, 3, 4)
+    lens = [385, 392, 393, 400, 401, 407, 408, 409, 430, 449, 500, 513, 520, 575, 577, 640, 641, 700, 759, 768, 769, 800, 1000, 1537, 1700]
+    reads = []
+    for L in lens:
+        o = int(rng.integers(0, len(ref) - L - 20))
+        reads.append(np.ascontiguousarray(mutate(ref[o:o + L + 10], rng, 0.03, 0.01, 0.01, 4)[:L]))
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=0)
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
+    _run(ectx, reads[:14], [ref], dna_matrix(1, 3), 5, gapO=5, gapE=2, flag=2)
+
+
+def test_allocation_failure_shrinks_the_budget_and_retries(emu_lib_path, monkeypatch):
+    """SSW_ALLOC_RETRY: a device allocation that fails although it is within the budget (contexts of one process sharing a device) cuts
+    the budget and plans the launches again.  The emulator's allocator refuses single allocations above SSW_EMU_MALLOC_LIMIT_MB."""
+    rng = np.random.default_rng(12)
+    ref = random_ref(40000, 5, 4)
+    reads = make_reads(rng, ref, 96, [32], 4)                  # 48 pairs x 40 016 columns x 4 bytes = 7.7 MB per column-maximum array
+    mat = dna_matrix(2, 2)
+    lib = ssw_amd.load(emu_lib_path)
+    ctx = ssw_amd.Context(0, lib)
+    try:
+        Q = ctx.upload(reads); T = ctx.upload([ref])
+        lib.ssw_gpu_set_budget(ctx.h, 256 << 20)
+        monkeypatch.setenv("SSW_EMU_MALLOC_LIMIT_MB", "3")
+        res, cig = ctx.align_batch(Q, T, mat, 5, 3, 1, 0, 0, 0, -1, 2)
+        assert ctx.timing()["fill_launches"] >= 3               # the bucket was cut into launches that fit
+        assert lib.ssw_gpu_get_budget(ctx.h) < (256 << 20)      # ... because the budget was cut
+        monkeypatch.delenv("SSW_EMU_MALLOC_LIMIT_MB")
+        bad = compare_batch(res[:12], cig, reads[:12], [ref], mat, 5, 3, 1, 0, 0, 0, -1, 2)
+        assert not bad, "\n".join(bad)
+        lib.ssw_gpu_set_budget(ctx.h, 256 << 20)                # an explicit budget starts the ladder afresh
+        res2, _ = ctx.align_batch(Q, T, mat, 5, 3, 1, 0, 0, 0, -1, 2)
+        assert ctx.timing()["fill_launches"] == 1 and all((res[f] == res2[f]).all() for f in ("score1", "score2", "ref_end1", "read_end1", "ref_end2"))
+        Q.free(); T.free()
+    finally:
+        ctx.close()
