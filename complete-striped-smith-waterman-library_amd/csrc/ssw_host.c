@@ -58,6 +58,7 @@ typedef struct {
 	int trace_unblocked;    /* SSW_GPU_TRACE_BLOCKED=0: teams with one cell per thread */
 	int serial_buckets;     /* SSW_GPU_SERIAL_BUCKETS=1: geometry buckets one after the other on the main stream (the form before round 4) */
 	int no_dbx;             /* SSW_GPU_NO_DBX=1: flagged batches against many targets take the per-target loop (the form before round 4) */
+	int call_trace;         /* SSW_GPU_CALL_TRACE=1: host timestamps of the phases of every batch call on stderr */
 	int db_tsub, dbx_slab;  /* SSW_GPU_DB_TSUB / SSW_GPU_DBX_SLAB: targets per chunk of the database search / survivors per traceback slab (tests: force
 	                           several chunks and slabs on toy batches); 0: from the budget */
 } ssw_knobs;
@@ -97,6 +98,9 @@ struct ssw_gpu_seqs {
 
 static __thread char g_open_err[512];   /* error of the last failed ssw_gpu_open of this thread */
 
+/* SSW_GPU_CALL_TRACE=1: host wall-clock at the phases of a batch call (what a single-pair ssw_align spends where) */
+#define CALL_TRACE(what) do { if (c->kn.call_trace) fprintf(stderr, "[ssw_gpu call] %9.3f ms  %s\n", dbg_ms(), what); } while (0)
+
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e && e[0] ? atoi(e) : dflt; }
 static int env_is(const char* name, char ch) { const char* e = getenv(name); return e && e[0] == ch; }
 static void knobs_load(ssw_knobs* k)
@@ -123,6 +127,7 @@ static void knobs_load(ssw_knobs* k)
 	k->trace_unblocked = env_is("SSW_GPU_TRACE_BLOCKED", '0');
 	k->serial_buckets = env_is("SSW_GPU_SERIAL_BUCKETS", '1');
 	k->no_dbx = env_is("SSW_GPU_NO_DBX", '1');
+	k->call_trace = env_is("SSW_GPU_CALL_TRACE", '1');
 	{ const int v = env_int("SSW_GPU_DB_TSUB", 0); k->db_tsub = v > 0 ? v : 0; }
 	{ const int v = env_int("SSW_GPU_DBX_SLAB", 0); k->dbx_slab = v > 0 ? v : 0; }
 }
@@ -892,10 +897,11 @@ typedef struct {
 	const int32_t* ids; int32_t nids;      /* host */
 	int32_t* d_list;                       /* device scratch for job lists: >= nslots ints (contents are overwritten) */
 	int32_t* hneed;                        /* host scratch: nslots ints */
+	int list_on_device;                    /* d_list already holds `ids` (the caller's bucket-ordered query list) */
 	int32_t maxlen;                        /* longest query */
 	int64_t ref_span;                      /* what the target side can add to an alignment's span: min(exact halo of maxlen, longest target) */
 } trace_in;
-typedef struct { uint32_t* d_cig; int64_t cig_stride; int did_trace; } trace_out;
+typedef struct { uint32_t* d_cig; int64_t cig_stride; int did_trace; int list_dirty; /* d_list was overwritten */ } trace_out;
 
 static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 {
@@ -905,7 +911,7 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 	const ssw_gpu_seqs* Q = ti->Q; const ssw_gpu_params* prm = ti->prm;
 	const int8_t* d_tgt = ti->d_tgt; const int8_t* d_mat = ti->d_mat; ssw_dres* d_res = ti->d_res; int32_t* d_qlist = ti->d_list; int32_t* hneed = ti->hneed;
 	const int32_t n = ti->n, nq = ti->nslots, maxlen = ti->maxlen;
-	to->d_cig = 0; to->cig_stride = 0; to->did_trace = 0;
+	to->d_cig = 0; to->cig_stride = 0; to->did_trace = 0; to->list_dirty = 0;
 	if (ti->nids > 0) {
 		/* one launch over all queries; scratch sized for a band a few doublings wide, grown on demand */
 		int64_t span = (int64_t)maxlen + ti->ref_span + 8;
@@ -913,16 +919,16 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 		d_cig = (uint32_t*)ensure(c, &c->cigar, (size_t)(4 * cig_stride * nq));
 		int32_t* d_need = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * 2 * (size_t)nq);
 		int32_t* d_resume = (int32_t*)ensure(c, &c->tresume, sizeof(int32_t) * 8 * (size_t)nq);
-		if (!d_cig || !d_need || !d_resume) return -1;
-		if (ssw_shim_memset(d_resume, 0, sizeof(int32_t) * 8 * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); return -1; }
+		if (!d_cig || !d_need || !d_resume) return -1;      /* (the teams' resume state is zeroed before the first team launch) */
 		int64_t sstride = ((int64_t)3 * (2 * 16 + 8) * 4 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;
 		/* long reads: one wavefront per alignment (wide bands, 10^4 rows); short reads: one thread per alignment */
-		/* Which kernel walks a band.  One THREAD per alignment (k_trace) is right where the band is a handful of cells: round 0 of short reads
-		   (150-bp DNA: 100 000 alignments in 49 ms).  Whatever needs a wider band than round 0's scratch holds -- reads with long indels,
-		   and practically every protein pair: band0 = |refLen' - readLen'| + 1 is tens of cells there -- goes to a TEAM of wavefronts
-		   (k_trace_wave: band rows in LDS, a row's cells in parallel): 88 000 protein tracebacks took 1654 ms on threads and 189 ms on teams
+		/* Which kernel walks a band.  One THREAD per alignment (k_trace) is right where the band is a handful of cells and the rows are few:
+		   round 0 of short reads (150-bp DNA: 100 000 alignments in 17 ms).  Whatever needs a wider band than round 0's scratch holds -- reads
+		   with long indels -- and every batch with queries above 256 residues (proteins: band0 = |refLen' - readLen'| + 1 is tens of cells, and
+		   a thread's scattered direction bytes over 300 rows miss every cache) goes to a TEAM of wavefronts (k_trace_wave: band rows in LDS, a
+		   row's cells in parallel): 88 000 protein tracebacks took 1654 ms on threads and 189 ms on teams, 524 000: 11.6 s and 0.64 s
 		   (profiles/round4_dbx.txt).  SSW_GPU_TRACE_WAVE=0 / 1 forces one kernel for all rounds (tests). */
-		const int use_wave0 = c->kn.trace_wave >= 0 ? c->kn.trace_wave : maxlen > 1024;
+		const int use_wave0 = c->kn.trace_wave >= 0 ? c->kn.trace_wave : maxlen > 256;
 		const int use_wave = c->kn.trace_wave >= 0 ? c->kn.trace_wave : 1;      /* rounds after the first */
 		const int trace_no_lds = c->kn.trace_no_lds;     /* experiment / test: band rows in HBM scratch instead of LDS */
 		const int trace_waves_env = c->kn.trace_waves;   /* experiment / test */
@@ -931,8 +937,10 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 		   they needed; later rounds run them in classes of similar need (x4 per class) with 4x headroom. */
 		tpend* pend = (tpend*)malloc(sizeof(tpend) * (size_t)nq);     /* key = band that did not fit, need in 4-KiB units, q = query */
 		int32_t* lst = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
-		int32_t* hband = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
-		if (!pend || !lst || !hband) { free(pend); free(lst); free(hband); fail(c, "out of host memory%s", ""); return -1; }
+		int32_t* hnb = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)nq);      /* need + band of a round-0 launch */
+		int resume_zeroed = 0;
+		(void)hneed;
+		if (!pend || !lst || !hnb) { free(pend); free(lst); free(hnb); fail(c, "out of host memory%s", ""); return -1; }
 		int32_t npend = ti->nids;
 		for (int32_t k = 0; k < ti->nids; ++k) { pend[k].key = 0; pend[k].need = 0; pend[k].q = ti->ids[k]; }
 		const int64_t full = (int64_t)maxlen + ti->ref_span;
@@ -955,15 +963,19 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 					ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = sstride; ta.soff = 0;
 					ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;     /* CIGAR slots are indexed by query */
 					ta.resume = d_resume; ta.unblocked = trace_unblocked; ta.waves = 1; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)ssw_shim_trace_lds_need(16, 1);
-					if (ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
+					/* (the job list is already on the device when the caller's list IS the ids and one launch takes them all; need and band come
+					   back in one copy: need[0 .. cnt), band[cnt .. 2 cnt)) */
+					const int list_ready = ti->list_on_device && q0 == 0 && cnt_l == npend;
+					if (!list_ready) to->list_dirty = 1;
+					if (use_wave0 && !resume_zeroed) { resume_zeroed = 1; if (ssw_shim_memset(d_resume, 0, sizeof(int32_t) * 8 * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); trace_ok = 0; break; } }
+					if ((!list_ready && ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream)) ||
 					    (use_wave0 ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
-					    ssw_shim_d2h(hneed, d_need, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
-					    ssw_shim_d2h(hband, d_need + cnt_l, sizeof(int32_t) * (size_t)cnt_l, c->stream) ||
+					    ssw_shim_d2h(hnb, d_need, sizeof(int32_t) * 2 * (size_t)cnt_l, c->stream) ||
 					    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
 					for (int32_t k = 0; k < cnt_l; ++k)
-						if (hneed[k] != 0) {
-							if (hneed[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
-							nextp[nnext].key = hband[k]; nextp[nnext].need = hneed[k]; nextp[nnext].q = lst[k]; ++nnext;      /* (both kernels report the band that did not fit) */
+						if (hnb[k] != 0) {
+							if (hnb[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
+							nextp[nnext].key = hnb[cnt_l + k]; nextp[nnext].need = hnb[k]; nextp[nnext].q = lst[k]; ++nnext;      /* (both kernels report the band that did not fit) */
 						}
 					if (c->kn.debug) fprintf(stderr, "[ssw_gpu] %.1f ms: trace round 0: %d alignments, scratch %lld B each, %d pending so far\n",
 					                                     dbg_ms(), cnt_l, (long long)sstride, nnext);
@@ -976,12 +988,14 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 				int64_t* hoff = (int64_t*)malloc(sizeof(int64_t) * ((size_t)npend * 2 + 2));
 				int32_t* hall = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)npend);
 				if (!hoff || !hall) { free(hoff); free(hall); free(nextp); fail(c, "out of host memory%s", ""); trace_ok = 0; break; }
-				int64_t budget = (int64_t)c->cm_budget * 2;
+				int64_t budget = (int64_t)c->cm_budget;      /* (the same budget as every other phase of the call) */
 				{   /* ... but not more than the device has left now (the fill's buffers stay with the context) */
 					const int64_t room = (int64_t)c->scratch.cap + (int64_t)(ssw_shim_mem_free_bytes() / 5 * 4);
 					if (room > ((int64_t)1 << 30) && budget > room) budget = room;
 				}
 				for (int32_t k = 0; k < npend; ++k) lst[k] = pend[k].q;
+				to->list_dirty = 1;
+				if (use_wave && !resume_zeroed) { resume_zeroed = 1; if (ssw_shim_memset(d_resume, 0, sizeof(int32_t) * 8 * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); trace_ok = 0; free(hoff); free(hall); free(nextp); break; } }
 				int64_t* d_soff = (int64_t*)ensure(c, &c->goff, sizeof(int64_t) * ((size_t)npend * 2 + 2));
 				if (!d_soff || ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)npend, c->stream)) { trace_ok = 0; free(hoff); free(hall); free(nextp); break; }
 				for (int32_t b0 = 0; b0 < npend && trace_ok; ) {       /* one batch = what fits the HBM budget at once */
@@ -1057,7 +1071,7 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 			did_trace = 1;
 			free(pend); pend = nextp; npend = nnext;
 		}
-		free(pend); free(lst); free(hband);
+		free(pend); free(lst); free(hnb);
 		if (!trace_ok) return -1;
 		if (npend > 0) { fail(c, "internal error: traceback scratch negotiation did not converge%s", ""); return -1; }
 	}
@@ -1339,6 +1353,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 
 	int rc = -1;
 	bplan* bplans = 0;
+	unsigned char* hhdr = 0;      /* host copy of the packed small inputs */
 	struct fill_defer { ssw_fill_args fa; int R, group; int64_t wgs; } *defer = 0;      /* short-query buckets that join a multi-bucket grid */
 	ssw_reduce_args* rdefer = 0;                                                          /* ... and the reductions of all buckets of a side-by-side group */
 	int* border = (int*)malloc(sizeof(int) * (size_t)(nb > 0 ? nb : 1));      /* buckets by size (side-by-side launches go largest first) */
@@ -1349,15 +1364,24 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 	c->nev = 0;
 	if (!hres || !hneed || !border) { fail(c, "out of host memory%s", ""); goto done; }
 
-	int8_t* d_mat = (int8_t*)ensure(c, &c->mat, (size_t)n * n);
-	ssw_pair* d_pairs = (ssw_pair*)ensure(c, &c->pairs, sizeof(ssw_pair) * (size_t)npairs_total);
-	int32_t* d_qlist = (int32_t*)ensure(c, &c->qlist, sizeof(int32_t) * (size_t)nq);
+	/* the call's small inputs -- scoring matrix, query pairs, bucket-ordered query list -- travel in ONE upload (a single-pair ssw_align call is
+	   bound by the number of dependent operations on its stream, not by their size: profiles/round4_latency.txt) */
+	const size_t hdr_mat = ((size_t)n * n + 15) / 16 * 16, hdr_pairs = (sizeof(ssw_pair) * (size_t)npairs_total + 15) / 16 * 16;
+	const size_t hdr_bytes = hdr_mat + hdr_pairs + sizeof(int32_t) * (size_t)nq;
+	unsigned char* d_hdr = (unsigned char*)ensure(c, &c->mat, hdr_bytes);
 	ssw_dres* d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq);
-	if (!d_mat || !d_pairs || !d_qlist || !d_res) goto done;
+	hhdr = (unsigned char*)malloc(hdr_bytes);
+	if (!d_hdr || !d_res) goto done;
+	if (!hhdr) { fail(c, "out of host memory%s", ""); goto done; }
+	int8_t* d_mat = (int8_t*)d_hdr;
+	ssw_pair* d_pairs = (ssw_pair*)(d_hdr + hdr_mat);
+	int32_t* d_qlist = (int32_t*)(d_hdr + hdr_mat + hdr_pairs);
+	memcpy(hhdr, prm->mat, (size_t)n * n);
+	memcpy(hhdr + hdr_mat, pairs, sizeof(ssw_pair) * (size_t)npairs_total);
+	memcpy(hhdr + hdr_mat + hdr_pairs, order, sizeof(int32_t) * (size_t)nqa);
 	ssw_shim_event_record(c->ev_t0, c->stream);
-	if (ssw_shim_h2d(d_mat, prm->mat, (size_t)n * n, c->stream) ||
-	    ssw_shim_h2d(d_pairs, pairs, sizeof(ssw_pair) * (size_t)npairs_total, c->stream) ||
-	    ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nqa, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
+	CALL_TRACE("entry: bucketed, buffers ready");
+	if (ssw_shim_h2d(d_hdr, hhdr, hdr_mat + hdr_pairs + sizeof(int32_t) * (size_t)nqa, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
 
 	const uint32_t gapO2 = (uint32_t)prm->gapO * 0x10001u, gapE2 = (uint32_t)prm->gapE * 0x10001u;
 	double fill_ms = 0, reduce_ms = 0, locate_ms = 0, trace_ms = 0;
@@ -1417,7 +1441,8 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		const int32_t refLen = (int32_t)refLen64;
 		const int8_t* d_tgt = T->d_codes + T->h_off[t];
 		const int ev_first = c->nev;
-		if (ssw_shim_memset(d_res, 0, sizeof(ssw_dres) * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
+		/* (every non-empty query's record is written whole by the reduction; only empty queries and queries answered elsewhere rely on zeroes) */
+		if (nqa != nq || tcount > 1) { if (ssw_shim_memset(d_res, 0, sizeof(ssw_dres) * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; } }
 
 		if (refLen > 0 && literal) {
 			/* scratch per alignment: 4 x [segments][16] int16 + codes + maxColumn (sized for the 16-bit kernel: 8 lanes) */
@@ -1472,21 +1497,39 @@ plan_again:
 				const int use_x = B->use_x;     /* long queries: strip kernel, one job per chain */
 				const int gran = use_x ? 1 : 16;     /* k_fill: one workgroup = 16 tiles of one pair */
 				int32_t tile, halo, ntiles;
-				if ((int64_t)halo_full * 8 * gran >= refLen) { ntiles = 1; tile = (refLen + 15) / 16 * 16; halo = 0; }
-				else {
+				int64_t want = 1;
+				if ((int64_t)halo_full * 8 * gran < refLen) {
 					/* enough chains PER LAUNCH to fill the device several times over, halo overhead <= 1/8.  A launch covers the pairs
 					   whose column-maximum arrays fit the budget (8 bytes per column and pair): a 5 Mb target leaves 1600 pairs per
 					   launch, which with 16 tiles (one workgroup) per pair would fill little more than half of the device */
 					int64_t launch_pairs = use_x ? B->npairs : (int64_t)(c->cm_budget / (size_t)(8 * stride));
 					if (launch_pairs < 1) launch_pairs = 1;
 					if (launch_pairs > B->npairs) launch_pairs = B->npairs;
-					int64_t want = (4 * 32768 + B->npairs - 1) / B->npairs;
+					want = (4 * 32768 + B->npairs - 1) / B->npairs;
 					if (!use_x && launch_pairs * ((want + 15) / 16) < 6000) want = 16 * ((6000 + launch_pairs - 1) / launch_pairs);   /* >= ~2 rounds of workgroups per launch */
 					int64_t maxt = refLen / ((int64_t)halo_full * 8);
 					if (want > maxt) want = maxt;
-					want = (want + gran - 1) / gran * gran; if (want < gran) want = gran;
+				}
+				{
+					/* A call that cannot fill the device anyway -- one ssw_align pair, a handful of reads -- is bound by the LATENCY of a chain, tile +
+					   halo columns in sequence: then the tiles go down to half the halo (at least 64 columns) as long as all chains of the
+					   call still fit the device at once; the recomputed halos run on compute units that would idle.  One 150-bp read against a
+					   10-kb target: 736 steps instead of 10 000 (2.3 -> 0.x ms per ssw_align call, profiles/round4_latency.txt). */
+					const int64_t slots = use_x ? (int64_t)c->dev_wave_slots : (int64_t)c->dev_cus * 96;      /* chains the device holds at once */
+					const int64_t all_pairs = npairs_total > 0 ? npairs_total : 1;
+					if (all_pairs * want < slots && halo_full < refLen) {
+						const int64_t mint = halo_full / 2 > 64 ? halo_full / 2 : 64;
+						int64_t small = slots / all_pairs;
+						if (small > refLen / mint) small = refLen / mint;
+						if (small > want) want = small;
+					}
+				}
+				if (want <= 1) { ntiles = 1; tile = (refLen + 15) / 16 * 16; halo = 0; }
+				else {
+					if (want >= gran) want = (want + gran - 1) / gran * gran;      /* (fewer tiles than a workgroup has chains: the others stay idle) */
 					tile = (int32_t)(((refLen + want - 1) / want + 15) / 16 * 16);
 					ntiles = (refLen + tile - 1) / tile; halo = (halo_full + 15) / 16 * 16;     /* (more halo is always exact; multiples of 16 keep the 16-column groups inside one tile) */
+					if (ntiles <= 1) { ntiles = 1; tile = (refLen + 15) / 16 * 16; halo = 0; }
 				}
 				const int64_t maxcols = (((int64_t)tile + halo < refLen ? (int64_t)tile + halo : refLen) + 31) / 16 * 16;
 				int64_t per_pair = 8 * stride + (use_x ? 16 * maxcols * ntiles : 0);
@@ -1591,7 +1634,12 @@ plan_again:
 				const int64_t maxcols = P->maxcols, chunk = P->chunk;
 				void* st = c->stream;
 				if (conc) {
-					const int sx = nside++ % SSW_TSTREAMS;
+					/* The runtime maps streams onto FOUR hardware queues (seen on ROCm 7.2: the context's eight streams land on queues
+					   1 2 3 4 4 3 2 1), and launches that share a queue run one after the other: the strip kernel's few, latency-bound
+					   launches all go to ONE side stream, in sequence (together they are shorter than the short-query grids beside them);
+					   the multi-bucket grids take three others.  profiles/round4_config6_timeline.txt */
+					const int sx = 5;
+					(void)nside;
 					st = c->tstream[sx];
 					if (!side_used[sx]) { side_used[sx] = 1; if (ssw_shim_stream_wait_event(st, c->ev_db)) { fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; } }
 				}
@@ -1689,7 +1737,12 @@ plan_again:
 				unsigned char* dtab = (unsigned char*)ensure(c, &c->fmtab, (rec + 16) * (size_t)ndefer + 64 * 6);
 				if (!htab || !dtab) { free(htab); if (!htab) fail(c, "out of host memory%s", ""); goto done; }
 				size_t at = 0;
-				for (int g = 0; g < 6; ++g) {
+				for (int gi_ = 0; gi_ < 6; ++gi_) {
+					int64_t gw[6] = { 0, 0, 0, 0, 0, 0 };      /* groups by size, largest first */
+					for (int i = 0; i < ndefer; ++i) gw[defer[i].group] += defer[i].wgs * defer[i].R;
+					int gord[6] = { 0, 1, 2, 3, 4, 5 };
+					for (int i = 1; i < 6; ++i) { const int v = gord[i]; int j = i; while (j > 0 && gw[gord[j - 1]] < gw[v]) { gord[j] = gord[j - 1]; --j; } gord[j] = v; }
+					const int g = gord[gi_];
 					int idx[SSW_RMAX + 1], ng = 0;
 					for (int i = 0; i < ndefer; ++i) if (defer[i].group == g) idx[ng++] = i;
 					if (ng == 0) continue;
@@ -1701,7 +1754,8 @@ plan_again:
 					hfirst[ng] = (int32_t)total;
 					at = a2 + ALIGN16(4 * (size_t)ng);
 					if (total > 0x7fffffff) { free(htab); fail(c, "internal error: %s", "more than 2^31 workgroups in one multi-bucket fill launch"); goto done; }
-					const int sx = nside++ % SSW_TSTREAMS;
+					static const int grid_streams[3] = { 0, 1, 4 };      /* three different hardware queues (see above) */
+					const int sx = grid_streams[nside++ % 3];
 					void* st = c->tstream[sx];
 					if (!side_used[sx]) { side_used[sx] = 1; if (ssw_shim_stream_wait_event(st, c->ev_db)) { free(htab); fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; } }
 					ssw_fillm_args ma; ma.sub = (const ssw_fill_args*)(dtab + a0); ma.first_wg = (const int32_t*)(dtab + a1); ma.subR = (const int32_t*)(dtab + a2); ma.nsub = ng;
@@ -1736,6 +1790,7 @@ plan_again:
 			}
 		}
 		ssw_shim_event_record(c->ev_a, c->stream);
+		CALL_TRACE("fill + reduction enqueued");
 
 		if (refLen > 0 && !literal) {   /* read_end1 always (ssw.c:342-351); begin position only when asked for (ssw.c:916) */
 			win_in wi; memset(&wi, 0, sizeof wi);
@@ -1766,6 +1821,7 @@ plan_again:
 				}
 		}
 		ssw_shim_event_record(c->ev_b, c->stream);
+		CALL_TRACE("window passes enqueued");
 
 		/* traceback (+ SAM-style rewrite) of the alignments whose record asks for a CIGAR */
 		trace_out tro; memset(&tro, 0, sizeof tro);
@@ -1774,11 +1830,13 @@ plan_again:
 			trace_in tri; memset(&tri, 0, sizeof tri);
 			tri.Q = Q; tri.prm = prm; tri.d_tgt = d_tgt; tri.d_mat = d_mat; tri.n = n; tri.d_res = d_res; tri.nslots = nq;
 			tri.ids = order; tri.nids = nqa; tri.d_list = d_qlist; tri.hneed = hneed; tri.maxlen = maxlen; tri.ref_span = halo_max < refLen ? halo_max : refLen;
+			tri.list_on_device = 1;
 			if (trace_phase(c, &tri, &tro)) goto done;
-			if (tro.did_trace && ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nqa, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
+			if (tro.list_dirty && ti + 1 < tcount && ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nqa, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
 		}
 		uint32_t* const d_cig = tro.d_cig;
 		ssw_shim_event_record(c->ev_c, c->stream);
+		CALL_TRACE("traceback enqueued / negotiated");
 
 		if (chainq_check(c)) goto done;
 		if (ssw_shim_d2h(hres, d_res, sizeof(ssw_dres) * (size_t)nq, c->stream) || ssw_shim_stream_sync(c->stream)) {
@@ -1801,10 +1859,18 @@ plan_again:
 				if (!npool) { fail(c, "out of host memory (%s)", "CIGAR pool"); free(goffs); goto done; }
 				pool = npool;
 			}
+			if (nq <= 4) {      /* a handful of alignments: every CIGAR straight from its slot (no offset upload, no gather launch) */
+				for (int32_t q = 0; q < nq; ++q)
+					if (hres[q].cigarLen > 0 && hres[q].status == 0 &&
+					    ssw_shim_d2h(pool + pool_words + goffs[q], d_cig + hres[q].cigar_off, sizeof(uint32_t) * (size_t)hres[q].cigarLen, c->stream)) {
+						fail(c, "CIGAR download failed: %s", ssw_shim_last_error()); free(goffs); goto done;
+					}
+			} else {
 			ssw_gather_args ga; ga.src = d_cig; ga.res = d_res; ga.dst_off = d_goff; ga.dst = d_gpool; ga.nq = nq;
 			if (ssw_shim_h2d(d_goff, goffs, sizeof(int64_t) * (size_t)nq, c->stream) || ssw_shim_launch_gather(&ga, c->stream) ||
 			    ssw_shim_d2h(pool + pool_words, d_gpool, sizeof(uint32_t) * (size_t)gwords, c->stream)) {
 				fail(c, "CIGAR download failed: %s", ssw_shim_last_error()); free(goffs); goto done;
+			}
 			}
 		}
 		for (int32_t q = 0; q < nq; ++q) {
@@ -1824,6 +1890,7 @@ plan_again:
 		pool_words += gwords;
 		free(goffs);
 		ssw_shim_event_record(c->ev_d, c->stream);
+		CALL_TRACE("results + CIGARs on the host");
 		if (ssw_shim_stream_sync(c->stream)) { fail(c, "stream sync failed: %s", ssw_shim_last_error()); goto done; }
 		for (int e = ev_first; e + 1 < c->nev; e += 2) fill_ms += ssw_shim_event_elapsed_ms(c->ev[e], c->ev[e + 1]);
 		locate_ms += ssw_shim_event_elapsed_ms(c->ev_a, c->ev_b);
@@ -1843,7 +1910,7 @@ plan_again:
 	if (cigar_words) *cigar_words = pool_words;
 	rc = 0;
 done:
-	free(pool); free(order); free(pairs); free(hres); free(hneed); free(bk); free(qdone); free(bplans); free(border); free(defer); free(rdefer);
+	free(pool); free(order); free(pairs); free(hres); free(hneed); free(bk); free(qdone); free(bplans); free(border); free(defer); free(rdefer); free(hhdr);
 	return rc;
 }
 
@@ -1982,6 +2049,7 @@ typedef struct {
 	int64_t q_hoff[2], t_hoff[2];
 	size_t qcap, tcap;              /* device code capacity */
 	int8_t* tcopy; size_t tcopy_cap; int t_valid;     /* bytes of the target that is resident in t */
+	unsigned char* stage; size_t stage_cap;           /* host staging of one upload (offsets + codes) */
 } implicit_ctx;
 
 static pthread_key_t g_ictx_key;
@@ -1995,10 +2063,10 @@ static void implicit_destroy(void* p)
 	if (ic->ctx) {
 		ssw_shim_set_device(ic->ctx->device);
 		ssw_shim_stream_sync(ic->ctx->stream);
-		ssw_shim_free(ic->q.d_codes); ssw_shim_free(ic->q.d_off); ssw_shim_free(ic->t.d_codes); ssw_shim_free(ic->t.d_off);
+		ssw_shim_free(ic->q.d_off); ssw_shim_free(ic->t.d_off);      /* (one allocation each: offsets, then codes) */
 		ssw_gpu_close(ic->ctx);
 	}
-	free(ic->tcopy); free(ic);
+	free(ic->tcopy); free(ic->stage); free(ic);
 }
 static void implicit_key_init(void) { pthread_key_create(&g_ictx_key, implicit_destroy); }
 
@@ -2017,9 +2085,6 @@ static implicit_ctx* implicit_get(void)
 	ic->ctx = c;
 	ic->q.ctx = c; ic->q.count = 1; ic->q.h_off = ic->q_hoff;
 	ic->t.ctx = c; ic->t.count = 1; ic->t.h_off = ic->t_hoff;
-	ic->q.d_off = (int64_t*)ssw_shim_malloc(2 * sizeof(int64_t));
-	ic->t.d_off = (int64_t*)ssw_shim_malloc(2 * sizeof(int64_t));
-	if (!ic->q.d_off || !ic->t.d_off) { fail(0, "device allocation failed: %s", ssw_shim_last_error()); implicit_destroy(ic); return 0; }
 	pthread_setspecific(g_ictx_key, ic);
 	return ic;
 }
@@ -2027,17 +2092,27 @@ static implicit_ctx* implicit_get(void)
 /* (re)fill a pooled one-sequence set; the copies are ordered before the kernels of the batch call on the same stream */
 static int implicit_load(implicit_ctx* ic, ssw_gpu_seqs* s, size_t* cap, const int8_t* codes, int32_t len)
 {
+	/* offsets and codes live in ONE device allocation -- [0, len as int64][codes] -- and travel in one copy from a staging buffer: a
+	   single-pair call is bound by the number of dependent operations on its stream */
 	ssw_gpu_ctx* c = ic->ctx;
-	if (!s->d_codes || *cap < (size_t)len + 64) {
-		if (s->d_codes) { ssw_shim_stream_sync(c->stream); ssw_shim_free(s->d_codes); s->d_codes = 0; *cap = 0; }
+	if (!s->d_off || *cap < (size_t)len + 64) {
+		if (s->d_off) { ssw_shim_stream_sync(c->stream); ssw_shim_free(s->d_off); s->d_off = 0; s->d_codes = 0; *cap = 0; }
 		const size_t want = (size_t)len + (size_t)len / 4 + 4096;
-		s->d_codes = (int8_t*)ssw_shim_malloc(want);
-		if (!s->d_codes) return fail(c, "device allocation failed: %s", ssw_shim_last_error());
+		s->d_off = (int64_t*)ssw_shim_malloc(want + 16);
+		if (!s->d_off) return fail(c, "device allocation failed: %s", ssw_shim_last_error());
+		s->d_codes = (int8_t*)s->d_off + 16;
 		*cap = want;
 	}
+	if (ic->stage_cap < (size_t)len + 16) {
+		free(ic->stage);
+		ic->stage_cap = (size_t)len + (size_t)len / 4 + 4096;
+		ic->stage = (unsigned char*)malloc(ic->stage_cap);
+		if (!ic->stage) { ic->stage_cap = 0; return fail(c, "out of host memory%s", ""); }
+	}
 	s->h_off[0] = 0; s->h_off[1] = len; s->total = len;
-	if (ssw_shim_h2d(s->d_codes, codes, (size_t)len, c->stream) || ssw_shim_h2d(s->d_off, s->h_off, 2 * sizeof(int64_t), c->stream))
-		return fail(c, "upload failed: %s", ssw_shim_last_error());
+	memcpy(ic->stage, s->h_off, 16);
+	if (len > 0) memcpy(ic->stage + 16, codes, (size_t)len);
+	if (ssw_shim_h2d(s->d_off, ic->stage, (size_t)len + 16, c->stream)) return fail(c, "upload failed: %s", ssw_shim_last_error());
 	return 0;
 }
 
@@ -2077,8 +2152,9 @@ s_align* ssw_align(const s_profile* prof, const int8_t* ref, int32_t refLen, con
 		return 0;
 	}
 	ssw_gpu_ctx* c = ic->ctx;
+	CALL_TRACE("ssw_align: enter");
 	ssw_shim_set_device(c->device);
-	int ok = implicit_load(ic, &ic->q, &ic->qcap, prof->read, prof->readLen) == 0;
+	int ok = 1;
 	if (ok && !(ic->t_valid && ic->t.total == refLen && (refLen == 0 || memcmp(ic->tcopy, ref, (size_t)refLen) == 0))) {
 		ic->t_valid = 0;
 		if (ic->tcopy_cap < (size_t)refLen) {
@@ -2087,8 +2163,10 @@ s_align* ssw_align(const s_profile* prof, const int8_t* ref, int32_t refLen, con
 			ic->tcopy_cap = ic->tcopy ? (size_t)refLen + (size_t)refLen / 4 + 64 : 0;
 		}
 		ok = implicit_load(ic, &ic->t, &ic->tcap, ref, refLen) == 0;
+		if (ok) ok = ssw_shim_stream_sync(c->stream) == 0;      /* (the staging buffer is about to be reused for the query) */
 		if (ok && ic->tcopy) { memcpy(ic->tcopy, ref, (size_t)refLen); ic->t_valid = 1; }   /* no host copy: the target is simply uploaded every time */
 	}
+	if (ok) ok = implicit_load(ic, &ic->q, &ic->qcap, prof->read, prof->readLen) == 0;
 	if (ok) {
 		ssw_gpu_params prm;
 		prm.mat = prof->mat; prm.n = prof->n; prm.gapO = weight_gapO; prm.gapE = weight_gapE; prm.flag = flag;
@@ -2105,5 +2183,6 @@ s_align* ssw_align(const s_profile* prof, const int8_t* ref, int32_t refLen, con
 		} else { fprintf(stderr, "ssw_align: %s\n", ssw_gpu_last_error(c)); ic->t_valid = 0; }
 		free(pool);
 	} else { fprintf(stderr, "ssw_align: %s\n", ssw_gpu_last_error(c)); ic->t_valid = 0; }
+	CALL_TRACE("ssw_align: return");
 	return out;
 }
