@@ -922,13 +922,13 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 		if (!d_cig || !d_need || !d_resume) return -1;      /* (the teams' resume state is zeroed before the first team launch) */
 		int64_t sstride = ((int64_t)3 * (2 * 16 + 8) * 4 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;
 		/* long reads: one wavefront per alignment (wide bands, 10^4 rows); short reads: one thread per alignment */
-		/* Which kernel walks a band.  One THREAD per alignment (k_trace) is right where the band is a handful of cells and the rows are few:
-		   round 0 of short reads (150-bp DNA: 100 000 alignments in 17 ms).  Whatever needs a wider band than round 0's scratch holds -- reads
-		   with long indels -- and every batch with queries above 256 residues (proteins: band0 = |refLen' - readLen'| + 1 is tens of cells, and
-		   a thread's scattered direction bytes over 300 rows miss every cache) goes to a TEAM of wavefronts (k_trace_wave: band rows in LDS, a
-		   row's cells in parallel): 88 000 protein tracebacks took 1654 ms on threads and 189 ms on teams, 524 000: 11.6 s and 0.64 s
-		   (profiles/round4_dbx.txt).  SSW_GPU_TRACE_WAVE=0 / 1 forces one kernel for all rounds (tests). */
-		const int use_wave0 = c->kn.trace_wave >= 0 ? c->kn.trace_wave : maxlen > 256;
+		/* Which kernel walks a band.  Rounds 1-3 gave short reads ONE THREAD per alignment (k_trace) and only reads above 1 kb a TEAM of wavefronts
+		   (k_trace_wave: band rows in LDS, a row's cells in parallel, direction bytes packed).  Measured in round 4, the team kernel wins
+		   everywhere: a thread's band rows and direction bytes live in HBM scratch and every cell waits for them -- 100 000 x 150-bp
+		   tracebacks 17 ms on threads, 6 ms on teams (one wavefront each); 88 000 protein tracebacks 1654 vs 189 ms, 524 000: 11.6 vs 0.64 s;
+		   one ssw_align call with flag 2: 1.24 vs 0.96 ms (profiles/round4_dbx.txt, round4_latency.txt).  The thread kernel stays for
+		   SSW_GPU_TRACE_WAVE=0 (tests compare the two). */
+		const int use_wave0 = c->kn.trace_wave >= 0 ? c->kn.trace_wave : 1;
 		const int use_wave = c->kn.trace_wave >= 0 ? c->kn.trace_wave : 1;      /* rounds after the first */
 		const int trace_no_lds = c->kn.trace_no_lds;     /* experiment / test: band rows in HBM scratch instead of LDS */
 		const int trace_waves_env = c->kn.trace_waves;   /* experiment / test */
@@ -1471,7 +1471,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		}
 		if (refLen > 0 && !literal) {
 			const int64_t stride = ((int64_t)refLen + 15) / 16 * 16 + 16;
-			const int64_t seg_stride = stride / 16 + 1;
+			const int64_t seg_stride = (stride / 16 + 4 + 3) / 4 * 4;      /* rows of the group arrays: 16-byte aligned, padded by >= 4 words (k_reduce_seg loads four groups at a time) */
 			/* ---- plan: tile geometry and scratch of every geometry bucket.  An allocation that fails although it is within the budget
 			   (contexts of ONE process sharing a device; across processes HIP over-subscribes silently) shrinks the budget and plans
 			   again -- to a quarter the first time, a budget that only just fits leaves nothing for the rest of the call, then by
@@ -1498,6 +1498,7 @@ plan_again:
 				const int gran = use_x ? 1 : 16;     /* k_fill: one workgroup = 16 tiles of one pair */
 				int32_t tile, halo, ntiles;
 				int64_t want = 1;
+				int small_call = 0;
 				if ((int64_t)halo_full * 8 * gran < refLen) {
 					/* enough chains PER LAUNCH to fill the device several times over, halo overhead <= 1/8.  A launch covers the pairs
 					   whose column-maximum arrays fit the budget (8 bytes per column and pair): a 5 Mb target leaves 1600 pairs per
@@ -1509,6 +1510,7 @@ plan_again:
 					if (!use_x && launch_pairs * ((want + 15) / 16) < 6000) want = 16 * ((6000 + launch_pairs - 1) / launch_pairs);   /* >= ~2 rounds of workgroups per launch */
 					int64_t maxt = refLen / ((int64_t)halo_full * 8);
 					if (want > maxt) want = maxt;
+					want = (want + gran - 1) / gran * gran; if (want < gran) want = gran;      /* whole workgroups of 16 chains */
 				}
 				{
 					/* A call that cannot fill the device anyway -- one ssw_align pair, a handful of reads -- is bound by the LATENCY of a chain, tile +
@@ -1521,12 +1523,12 @@ plan_again:
 						const int64_t mint = halo_full / 2 > 64 ? halo_full / 2 : 64;
 						int64_t small = slots / all_pairs;
 						if (small > refLen / mint) small = refLen / mint;
-						if (small > want) want = small;
+						if (small > want) { want = small; small_call = 1; }
 					}
 				}
 				if (want <= 1) { ntiles = 1; tile = (refLen + 15) / 16 * 16; halo = 0; }
 				else {
-					if (want >= gran) want = (want + gran - 1) / gran * gran;      /* (fewer tiles than a workgroup has chains: the others stay idle) */
+					if (!small_call || want >= gran) want = (want + gran - 1) / gran * gran;      /* (a small call may have fewer tiles than a workgroup has chains: the others stay idle) */
 					tile = (int32_t)(((refLen + want - 1) / want + 15) / 16 * 16);
 					ntiles = (refLen + tile - 1) / tile; halo = (halo_full + 15) / 16 * 16;     /* (more halo is always exact; multiples of 16 keep the 16-column groups inside one tile) */
 					if (ntiles <= 1) { ntiles = 1; tile = (refLen + 15) / 16 * 16; halo = 0; }

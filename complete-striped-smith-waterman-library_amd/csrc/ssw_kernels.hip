@@ -843,12 +843,21 @@ SSW_DEV void reduce_seg_body(const ssw_reduce_args& a, const int pair, unsigned 
 	const int nseg = (a.refLen + 15) >> 4;
 
 	/* pass 1: best score and the first group that holds it, both queries in one sweep */
+	/* (four groups per 16-byte load, the next load in flight while these are compared: with ONE pair in the launch -- a single ssw_align call
+	   against a 1 Mb target is 62 500 groups -- the scan is a chain of memory latencies, 0.3 ms with one word per iteration; the rows of the
+	   group arrays are 16-byte aligned and padded: seg_stride is a multiple of 4 and >= nseg + 4) */
 	int best[2] = { 0, 0 }, bseg[2] = { 0x7fffffff, 0x7fffffff };
-	for (int g = tid; g < nseg; g += 256) {
-		const u32 w = g16[g];
-		const int lo = (int)(w & 0xffffu), hi = (int)(w >> 16);
-		if (lo > best[0]) { best[0] = lo; bseg[0] = g; }
-		if (hi > best[1]) { best[1] = hi; bseg[1] = g; }
+	for (int g0 = tid * 4; g0 < nseg; g0 += 1024) {
+		const u32x4 w4 = *(const u32x4*)(g16 + g0);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int g = g0 + k;
+			if (g < nseg) {
+				const int lo = (int)(w4[k] & 0xffffu), hi = (int)(w4[k] >> 16);
+				if (lo > best[0]) { best[0] = lo; bseg[0] = g; }
+				if (hi > best[1]) { best[1] = hi; bseg[1] = g; }
+			}
+		}
 	}
 	block_argmax(lds, tid, best[0], bseg[0]);
 	block_argmax(lds, tid, best[1], bseg[1]);
@@ -889,13 +898,19 @@ SSW_DEV void reduce_seg_body(const ssw_reduce_args& a, const int pair, unsigned 
 		if (!live[h]) continue;
 		const uint32_t* gs = use8[h] ? g8 : g16;
 		const uint32_t* cs = use8[h] ? c8 : c16;
-		for (int g = tid; g < nseg; g += 256) {
-			const int c0 = g * 16, c1 = c0 + 16 < a.refLen ? c0 + 16 : a.refLen;      /* columns [c0, c1) */
-			int v = 0;
-			if (c1 <= lo_edge[h] || c0 >= up_from[h]) v = half16(gs[g], h);              /* wholly allowed */
-			else if (c0 >= lo_edge[h] && c1 <= up_from[h]) continue;                      /* wholly masked */
-			else for (int c = c0; c < c1; ++c) if (c < lo_edge[h] || c >= up_from[h]) { const int w = half16(cs[c], h); v = w > v ? w : v; }
-			if (v > s2[h]) { s2[h] = v; g2[h] = g; }
+		for (int g0 = tid * 4; g0 < nseg; g0 += 1024) {
+			const u32x4 w4 = *(const u32x4*)(gs + g0);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const int g = g0 + k;
+				if (g >= nseg) continue;
+				const int c0 = g * 16, c1 = c0 + 16 < a.refLen ? c0 + 16 : a.refLen;      /* columns [c0, c1) */
+				int v = 0;
+				if (c1 <= lo_edge[h] || c0 >= up_from[h]) v = half16(w4[k], h);              /* wholly allowed */
+				else if (c0 >= lo_edge[h] && c1 <= up_from[h]) continue;                      /* wholly masked */
+				else for (int c = c0; c < c1; ++c) if (c < lo_edge[h] || c >= up_from[h]) { const int w = half16(cs[c], h); v = w > v ? w : v; }
+				if (v > s2[h]) { s2[h] = v; g2[h] = g; }
+			}
 		}
 	}
 	block_argmax(lds, tid, s2[0], g2[0]);
