@@ -1,25 +1,31 @@
-# rocprofv3 evidence, end of round 1 (written under gpurun_out/, summaries copied to profiles/ by scripts/summarize_profiles.py)
-set -x
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# rocprofv3 evidence (outputs under gpurun_out/prof, summaries -> profiles/<round>_* by scripts/summarize_profile.py):
+#   kernel-trace --stats of the bench commands of configs 2, 4, 5, 6;  PMC passes (FETCH_SIZE / WRITE_SIZE / SQ counters / GRBM, one pass
+#   per counter group, no tracing domains next to --pmc) on reduced batches of configs 2 and 5 and on config 4 at full size
+#   usage: bash scripts/gpu_profile.sh [round-name, default round4]
+cd "${GRAFT_REPO_ROOT:-.}"
+ROUND=${1:-round4}
 export TMPDIR=/tmp
-rm -rf gpurun_out/prof gpurun_out/prof4 gpurun_out/prof5
-mkdir -p gpurun_out/prof gpurun_out/prof4 gpurun_out/prof5
-python bench.py --steps 2 --warmup 1 > gpurun_out/bench_config2.log 2>&1
-BENCH="python bench.py --steps 1 --warmup 1 --cpu-sample 0"
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/trace -o bench -- $BENCH > gpurun_out/prof/trace.log 2>&1
-SMALL="python bench.py --steps 1 --warmup 0 --cpu-sample 0 --reads 16000"
-timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY -d gpurun_out/prof/pmc_sq1 -o bench -- $SMALL > gpurun_out/prof/pmc_sq1.log 2>&1
-timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM GRBM_GUI_ACTIVE -d gpurun_out/prof/pmc_sq2 -o bench -- $SMALL > gpurun_out/prof/pmc_sq2.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof/pmc_fetch -o bench -- $SMALL > gpurun_out/prof/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof/pmc_write -o bench -- $SMALL > gpurun_out/prof/pmc_write.log 2>&1
-C4="--reads 10000 --read-len 10000 --ref-len 100000 --flag 2 --sub 0.01 --indel 0.0025 --mask-len 5000 --steps 1 --warmup 0"
-python bench.py $C4 --cpu-sample 256 > gpurun_out/bench_config4.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof4/trace -o bench -- python bench.py $C4 --cpu-sample 0 > gpurun_out/prof4/trace.log 2>&1
-C4S="--reads 10000 --read-len 10000 --ref-len 20000 --flag 0 --sub 0.01 --indel 0.0025 --mask-len 5000 --steps 1 --warmup 0 --cpu-sample 0"
-timeout 400 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY -d gpurun_out/prof4/pmc_sq1 -o bench -- python bench.py $C4S > gpurun_out/prof4/pmc_sq1.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof4/pmc_fetch -o bench -- python bench.py $C4S > gpurun_out/prof4/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof4/pmc_write -o bench -- python bench.py $C4S > gpurun_out/prof4/pmc_write.log 2>&1
-C5="--reads 8192 --db-targets 2048 --steps 1 --warmup 0"
-python bench.py $C5 --cpu-sample 64 > gpurun_out/bench_config5.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof5/trace -o bench -- python bench.py $C5 --cpu-sample 0 > gpurun_out/prof5/trace.log 2>&1
+P=$PWD/gpurun_out/prof
+rm -rf $P; mkdir -p $P
+B=$PWD/bench.py
+R=$PWD
+cd /tmp
+trace() { timeout $1 rocprofv3 --kernel-trace --stats -d $P/$2 -o bench -- python $B $3 > $P/$2.log 2>&1; echo "$2 rc=$?"; }
+pmc() { timeout $1 rocprofv3 --pmc $4 -d $P/$2 -o bench -- python $B $3 > $P/$2.log 2>&1; echo "$2 rc=$?"; }
+trace 200 trace_config2 "--config 2 --steps 1 --warmup 1 --cpu-sample 0 --also none"
+trace 200 trace_config4 "--config 4 --steps 1 --warmup 1 --cpu-sample 0"
+trace 300 trace_config5 "--config 5 --steps 1 --warmup 0 --cpu-sample 0"
+trace 200 trace_config6 "--config 6 --steps 1 --warmup 1 --cpu-sample 0"
+S2="--config 2 --reads 16000 --steps 1 --warmup 0 --cpu-sample 0 --also none"
+S4="--config 4 --steps 1 --warmup 0 --cpu-sample 0"      # full size: below ~2048 jobs the queue hands out whole jobs and runs one wavefront per SIMD
+S5="--config 5 --reads 8192 --db-targets 2048 --steps 1 --warmup 0 --cpu-sample 0"
+SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY"
+GR="GRBM_GUI_ACTIVE GRBM_COUNT"
+pmc 150 pmc2_fetch "$S2" FETCH_SIZE; pmc 150 pmc2_write "$S2" WRITE_SIZE; pmc 150 pmc2_sq1 "$S2" "$SQ1"; pmc 150 pmc2_grbm "$S2" "$GR"
+pmc 150 pmc4_fetch "$S4" FETCH_SIZE; pmc 150 pmc4_write "$S4" WRITE_SIZE; pmc 150 pmc4_sq1 "$S4" "$SQ1"; pmc 150 pmc4_grbm "$S4" "$GR"
+pmc 150 pmc5_fetch "$S5" FETCH_SIZE; pmc 150 pmc5_write "$S5" WRITE_SIZE; pmc 150 pmc5_sq1 "$S5" "$SQ1"; pmc 150 pmc5_grbm "$S5" "$GR"
+cd $R
+python scripts/summarize_profile.py $ROUND gpurun_out/prof > gpurun_out/prof_summary.log 2>&1; tail -n 40 gpurun_out/prof_summary.log
+find $P -name "*.db" -delete
 du -sh gpurun_out

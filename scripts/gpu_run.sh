@@ -10,6 +10,7 @@
 #   dbx            begin positions / CIGARs against a whole database in one call vs score only vs the per-target loop (scripts/gpu_dbx_bench.py)
 #   latency        one ssw_align call of the drop-in ABI (scripts/gpu_latency.py)
 #   literal        the lane-model kernel (gapO <= gapE) at 2 000 and 20 000 reads
+#   dropin         the reference main.c on libssw.so (one ssw_align per read) beside ssw_test_gpu, 10 000 reads x 1 Mb (scripts/gpu_dropin_cli.py)
 #   profile        rocprofv3 kernel-trace + PMC passes (scripts/gpu_profile.sh)
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
@@ -47,6 +48,7 @@ for step in "$@"; do
     literal)
       bench literal_2k --reads 2000 --gap-open 1 --gap-extend 1 --steps 1 --warmup 1 --cpu-sample 200 --also none
       bench literal_20k --reads 20000 --gap-open 1 --gap-extend 1 --steps 1 --warmup 1 --cpu-sample 200 --also none ;;
+    dropin) timeout 600 python scripts/gpu_dropin_cli.py > gpurun_out/${TAG}_dropin_cli.log 2>&1; tail -c 2500 gpurun_out/${TAG}_dropin_cli.log ;;
     profile) bash scripts/gpu_profile.sh > gpurun_out/${TAG}_profile.log 2>&1; tail -6 gpurun_out/${TAG}_profile.log ;;
     *) echo "unknown step $step" ;;
   esac

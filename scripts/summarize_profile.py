@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""rocprofv3 outputs of scripts/gpu_profile_round3.sh (rocpd sqlite) -> the small summaries committed under profiles/:
-per-kernel time statistics of the kernel-trace runs, per-kernel PMC counter sums, and profiles/round3_traffic.json (HBM bytes
-per alignment of the dominant fill kernel of each config, with the hash of the kernel source they were measured on).
-Run on the GPU box right after the passes (the databases are too big to travel); writes into gpurun_out/ and profiles/."""
+"""rocprofv3 outputs of scripts/gpu_profile.sh (rocpd sqlite) -> the small summaries committed under profiles/:
+per-kernel time statistics of the kernel-trace runs, per-kernel PMC counter sums, and profiles/<round>_traffic.json (HBM bytes
+per alignment of the dominant fill kernel of each config, with the hash of the device sources they were measured on).
+Run on the GPU box right after the passes (the databases are too big to travel); writes into gpurun_out/profiles_<round>/, to be
+copied into profiles/.   usage: summarize_profile.py <round-name> <rocprof output dir>"""
 import glob
 import hashlib
 import json
@@ -10,9 +11,11 @@ import os
 import sqlite3
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof3"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "round4"
+src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out_dir = os.path.join(ROOT, "gpurun_out", "profiles_round3")
+sys.path.insert(0, ROOT)
+out_dir = os.path.join(ROOT, "gpurun_out", "profiles_" + ROUND)
 os.makedirs(out_dir, exist_ok=True)
 
 
@@ -20,27 +23,29 @@ def dbs(pattern):
     return sorted(glob.glob(os.path.join(src, pattern, "**", "*results.db"), recursive=True))
 
 
-for cfg in (2, 4, 5):
+for cfg in (2, 4, 5, 6):
     for d in dbs("trace_config%d" % cfg):
         db = sqlite3.connect(d)
         rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), max(sgpr_count), "
                           "max(lds_size), max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
         tot = sum(r[2] for r in rows) or 1
-        with open(os.path.join(out_dir, "round3_config%d_kernel_stats.csv" % cfg), "w") as f:
+        with open(os.path.join(out_dir, ROUND + "_config%d_kernel_stats.csv" % cfg), "w") as f:
             f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --config %d --steps 1 --warmup %d --cpu-sample 0 [--also none]   (durations in ns; vgpr = the trace record's arch_vgpr field, NOT the allocation: the code objects say 72 for k_fill<10,frame>)\n" % (cfg, 0 if cfg == 5 else 1))
             f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent,vgpr,sgpr,lds_bytes,max_grid_x,workgroup_x\n")
             for r in rows:
                 f.write("\"%s\",%d,%d,%.0f,%d,%d,%.3f,%d,%d,%d,%d,%d\n" % (r[0], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot, r[6], r[7], r[8], r[9], r[10]))
-        print(open(os.path.join(out_dir, "round3_config%d_kernel_stats.csv" % cfg)).read()[:1500])
+        print(open(os.path.join(out_dir, ROUND + "_config%d_kernel_stats.csv" % cfg)).read()[:1500])
 
-traffic = {"kernel_source_sha16": hashlib.sha256(open(os.path.join(ROOT, "complete-striped-smith-waterman-library_amd", "csrc", "ssw_kernels.hip"), "rb").read()).hexdigest()[:16],
-           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (scripts/gpu_profile_round3.sh); FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 reports half of a wide coalesced read); KB -> bytes"}
+import bench      # noqa: E402  (kernel_source_id: the hash over ssw_kernels.hip + lanes.h + ssw_dev.h that bench.py compares)
+traffic = {"kernel_source_sha16": bench.kernel_source_id(),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (scripts/gpu_profile.sh); FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 reports half of a wide coalesced read); KB -> bytes"}
 # bench.py runs the batch `steps + warmup` times and once more (the upload-inclusive step of the DNA configs, the verification
-# step of config 5): the PMC commands use --steps 1 --warmup 0, i.e. TWO passes of the fill kernel over the batch
-PASSES = 2
-alns = {2: 16000 * PASSES, 4: 10000 * PASSES, 5: 8192 * 2048 * PASSES}
+# step of config 5): the PMC commands use --steps 1 --warmup 0, i.e. TWO passes of the fill kernel over the batch -- THREE for config 5,
+# whose allocation warm-up is one chunk of DB entries = the whole reduced DB of the PMC command
+PASSES = {2: 2, 4: 2, 5: 3}
+alns = {2: 16000 * PASSES[2], 4: 10000 * PASSES[4], 5: 8192 * 2048 * PASSES[5]}
 dominant = {2: "k_fill", 4: "k_chainq", 5: "k_filldb"}
-with open(os.path.join(out_dir, "round3_pmc.csv"), "w") as f:
+with open(os.path.join(out_dir, ROUND + "_pmc.csv"), "w") as f:
     f.write("# rocprofv3 --pmc <counters> -- python bench.py --config N (config 2: 16000 reads, config 4: full size, config 5: 8192 x 2048), one pass per counter group\n")
     f.write("pass,kernel,counter,dispatches,sum,avg_per_dispatch,avg_dispatch_ns\n")
     sums = {}
@@ -57,14 +62,14 @@ with open(os.path.join(out_dir, "round3_pmc.csv"), "w") as f:
 for cfg, v in sums.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         hbm = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
-        traffic["config%d" % cfg] = {"kernel": dominant[cfg] + "<...> (fill launches only; window passes of the same template excluded)", "alignments_counted": alns[cfg], "passes_over_the_batch": PASSES,
+        traffic["config%d" % cfg] = {"kernel": dominant[cfg] + "<...> (fill launches only; window passes of the same template excluded)", "alignments_counted": alns[cfg], "passes_over_the_batch": PASSES[cfg],
                                      "FETCH_SIZE_KB": v["FETCH_SIZE"], "WRITE_SIZE_KB": v["WRITE_SIZE"], "hbm_bytes_per_alignment": hbm / alns[cfg]}
 if 2 in sums:
     traffic["config3"] = dict(traffic.get("config2", {}), note="config 3 shares config 2's kernel (k_fill<10,frame>); per-alignment traffic scales with the target length: not measured separately")
     traffic.pop("config3")
 # VALU issue statistics of the dominant fill kernels from the SQ / GRBM passes just written (GRBM_GUI_ACTIVE sums the 8 XCDs)
 import csv
-rows = [r for r in csv.reader(l for l in open(os.path.join(out_dir, "round3_pmc.csv")) if not l.startswith("#"))][1:]
+rows = [r for r in csv.reader(l for l in open(os.path.join(out_dir, ROUND + "_pmc.csv")) if not l.startswith("#"))][1:]
 issue = {}
 for cfg, k in ((2, "k_fill<10, 3>"), (4, "k_chainq<12, false, 3>"), (5, "k_filldb<20, 16, true>")):
     d = {r[2]: (float(r[5]), float(r[6])) for r in rows if r[0].startswith("pmc%d" % cfg) and k in r[1]}
@@ -73,9 +78,9 @@ for cfg, k in ((2, "k_fill<10, 3>"), (4, "k_chainq<12, false, 3>"), (5, "k_filld
         issue["config%d" % cfg] = {"kernel": k, "SQ_INSTS_VALU_per_dispatch": valu, "GRBM_GUI_ACTIVE_per_dispatch": gui, "dispatch_ms": ns / 1e6,
                                   "effective_clock_GHz": round(gui / 8.0 / ns, 3), "cycles_per_valu_instruction": round(gui / 8.0 * 1024.0 / valu, 3),
                                   "issue_slot_occupancy_at_4_cycles": round(4.0 * valu / (gui / 8.0 * 1024.0), 3)}
-issue["note"] = ("SQ_INSTS_VALU and GRBM_GUI_ACTIVE (summed over the 8 XCDs) of the dominant fill kernel, separate PMC passes (round3_pmc.csv): "
+issue["note"] = ("SQ_INSTS_VALU and GRBM_GUI_ACTIVE (summed over the 8 XCDs) of the dominant fill kernel, separate PMC passes (<round>_pmc.csv): "
                  "SIMD-cycles per VALU instruction = 1024 SIMDs x GRBM_GUI_ACTIVE / 8 / SQ_INSTS_VALU; above 1.0 occupancy = some 2-cycle adds pair up")
 traffic["valu_issue"] = issue
-with open(os.path.join(out_dir, "round3_traffic.json"), "w") as f:
+with open(os.path.join(out_dir, ROUND + "_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
 print(json.dumps(traffic, indent=1))
