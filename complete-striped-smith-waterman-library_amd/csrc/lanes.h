@@ -39,19 +39,21 @@ SSW_DEV u32 xl_row_shr1_zero(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)
 SSW_DEV u32 xl_row_shr1_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x111, 0xf, 0xf, false); }
 /* Column-frame chains: the hand-off to the next lane FUSED with the arithmetic that follows it -- a DPP modifier on a 32-bit VOP2 costs
    nothing, a separate v_mov_b32_dpp is one of ~75 vector instructions of a step in a kernel that is bound by their issue.  hipcc's DPP
-   combiner does this only now and then (never across the basic blocks of a step), hence the asm.  `s_nop 1`: the two wait states a DPP
-   operand needs after the vector instruction that wrote it -- the compiler's hazard recogniser does not look into an asm block.
+   combiner does this only now and then (never across the basic blocks of a step), hence the asm.  `s_nop 4`: the compiler's hazard
+   recogniser does not look into an asm block, so the block pads for the longest DPP hazard itself -- five wait states after a vector write
+   of EXEC (two after the vector instruction that wrote the operand) -- whatever code happens to precede it after a compiler update; the
+   three extra scalar cycles are filled by the other wavefronts of the SIMD (measured: profiles/round4_bench_default_with_also.json).
    xl_row_shr1_umax: max(previous lane's v, b) as unsigned words; lane 0 of a row: b (the zero row_shr:1 fills in, bound_ctrl).
    xl_row_shr1_sub_keep: dst = previous lane's v - b; lane 0 of a row keeps dst (no bound_ctrl: lanes without a source are disabled). */
 SSW_DEV u32 xl_row_shr1_umax(u32 v, u32 b)
 {
 	u32 r;
-	asm("s_nop 1\n\tv_max_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(b));
+	asm("s_nop 4\n\tv_max_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(b));
 	return r;
 }
 SSW_DEV void xl_row_shr1_sub_keep(u32& dst, u32 v, u32 b)
 {
-	asm("s_nop 1\n\tv_sub_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(dst) : "v"(v), "v"(b));
+	asm("s_nop 4\n\tv_sub_u32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(dst) : "v"(v), "v"(b));
 }
 template <int N> SSW_DEV u32 xl_row_ror(u32 v) { return (u32)__builtin_amdgcn_mov_dpp((int)v, 0x120 + N, 0xf, 0xf, true); }
 /* wave_shr:1 (0x138, GFX9 family only): lane i reads lane i-1 across the whole wavefront; lane 0 keeps `keep` */

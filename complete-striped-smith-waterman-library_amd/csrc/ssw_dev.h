@@ -248,6 +248,7 @@ typedef struct {
 	int32_t fr_base, fr_kmask;
 	int32_t whole_jobs;      /* 1: a ticket is a whole job (its strips in sequence on one wavefront); 0: a ticket is one strip */
 	ssw_vmap vm;             /* capture mode only */
+	int32_t banded;          /* capture mode, k_chainq, capped reverse pass: strips walk a diagonal band of the window (accepted only with cap_half_finish's proof) */
 } ssw_chainx_args;
 
 /*

@@ -58,6 +58,7 @@ typedef struct {
 	int trace_unblocked;    /* SSW_GPU_TRACE_BLOCKED=0: teams with one cell per thread */
 	int serial_buckets;     /* SSW_GPU_SERIAL_BUCKETS=1: geometry buckets one after the other on the main stream (the form before round 4) */
 	int no_dbx;             /* SSW_GPU_NO_DBX=1: flagged batches against many targets take the per-target loop (the form before round 4) */
+	int no_band;            /* SSW_GPU_NO_BAND=1: the capped reverse pass of the strip kernel visits whole windows (the form before round 4) */
 	int call_trace;         /* SSW_GPU_CALL_TRACE=1: host timestamps of the phases of every batch call on stderr */
 	int db_tsub, dbx_slab;  /* SSW_GPU_DB_TSUB / SSW_GPU_DBX_SLAB: targets per chunk of the database search / survivors per traceback slab (tests: force
 	                           several chunks and slabs on toy batches); 0: from the budget */
@@ -128,6 +129,7 @@ static void knobs_load(ssw_knobs* k)
 	k->serial_buckets = env_is("SSW_GPU_SERIAL_BUCKETS", '1');
 	k->no_dbx = env_is("SSW_GPU_NO_DBX", '1');
 	k->call_trace = env_is("SSW_GPU_CALL_TRACE", '1');
+	k->no_band = env_is("SSW_GPU_NO_BAND", '1');
 	{ const int v = env_int("SSW_GPU_DB_TSUB", 0); k->db_tsub = v > 0 ? v : 0; }
 	{ const int v = env_int("SSW_GPU_DBX_SLAB", 0); k->dbx_slab = v > 0 ? v : 0; }
 }
@@ -859,6 +861,7 @@ static int window_pass(ssw_gpu_ctx* c, const win_in* wi, const bucket* B, int pa
 			if (!d_retry) return -1;
 			int32_t missed = 0;
 			xa.window_extra = pass ? 64 : -1; xa.retry_count = d_retry;
+			xa.banded = pass && capL == 64 && !c->kn.no_band;      /* first try of the reverse pass: the strips walk a diagonal band of the capped window (k_chainq) */
 			/* the window passes of the 64-lane chains in the column-frame form too, when the bucket fits its range */
 			xa.form = 0; xa.fr_base = 0; xa.fr_kmask = 0;
 			if (wi->fill_form != 0 && capL == 64 && !c->kn.window_int16 &&
@@ -868,8 +871,9 @@ static int window_pass(ssw_gpu_ctx* c, const win_in* wi, const bucket* B, int pa
 			    launch_window_pass(c, capR, capL, capS, &xa, n)) return fail(c, "capture launch failed: %s", ssw_shim_last_error());
 			if (pass) {
 				if (ssw_shim_d2h(&missed, d_retry, sizeof(int32_t), c->stream) || ssw_shim_stream_sync(c->stream)) return fail(c, "download failed: %s", ssw_shim_last_error());
+				if (c->kn.debug) fprintf(stderr, "[ssw_gpu] reverse pass (%s): %d of %d alignments are rerun with the exact window\n", xa.banded ? "capped window, diagonal band" : "capped window", missed, cnt_q);
 				if (missed > 0) {
-					xa.window_extra = -1;
+					xa.window_extra = -1; xa.banded = 0;
 					if (launch_window_pass(c, capR, capL, capS, &xa, n)) return fail(c, "capture launch failed: %s", ssw_shim_last_error());
 				}
 			}

@@ -1169,6 +1169,8 @@ struct StripCtx {
 	u32 gapO2, gapE2;
 	int n;
 	u32 bmask;         /* boundary-out ring: entries - 1 (63, or 31 in the LDS-trimmed queue kernel) */
+	int bnd_avail;     /* traversal columns [0, bnd_avail) have a boundary record from the strip above (= ncols unless the strips walk a diagonal band) */
+	int col_shift;     /* capture, banded reverse pass: this strip's traversal column 0 is column col_shift of the job's window */
 	int fr_base, fr_kmask, gapEi;   /* column-frame form of the fill (run_strip<..., FR>) */
 };
 
@@ -1252,12 +1254,12 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 	const bool take = !x.first && x.mine && stg;
 	if (stg) {
 		u32x4 rec = zero4;
-		if (take && l16 < x.ncols) rec = *(const u32x4*)(x.bnd + 4 * (int64_t)l16);
+		if (take && l16 < x.bnd_avail) rec = *(const u32x4*)(x.bnd + 4 * (int64_t)l16);
 		lds_st128(lds, x.bin + 16u * l16, bnd_in(rec, l16));
 		lds_st128(lds, x.bin + 16u * (48 + l16), zero4);
 	}
 	u32x4 nb = zero4;
-	if (take && 16 + l16 < x.ncols) nb = *(const u32x4*)(x.bnd + 4 * (int64_t)(16 + l16));
+	if (take && 16 + l16 < x.bnd_avail) nb = *(const u32x4*)(x.bnd + 4 * (int64_t)(16 + l16));
 	nb = bnd_in(nb, 16 + l16);
 	/* frame form: the all-zero state of the column before the lane's first one; `fl` = phi one column ahead */
 	const u32 zero0 = FR ? pk_dup(fr_phi(0, l16, GL, x.fr_base, x.fr_kmask, x.gapEi) - x.gapEi) : 0u;
@@ -1310,7 +1312,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 			nxt = strip_code_off<G::PSTRIDE>(x, 0, tc, CAPTURE);
 			if (CAPTURE) nxtb = strip_code_off<G::PSTRIDE>(x, 1, tc, true);
 			nb = zero4;
-			if (take && tc < x.ncols) nb = *(const u32x4*)(x.bnd + 4 * (int64_t)tc);
+			if (take && tc < x.bnd_avail) nb = *(const u32x4*)(x.bnd + 4 * (int64_t)tc);
 			nb = bnd_in(nb, tc);
 		}
 		wave_lds_fence();
@@ -1420,8 +1422,8 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 #pragma unroll
 					for (int h = 0; h < 2; ++h) {
 						const int mf = (int)((lm >> (16 * h)) & 0xffffu), m = mf - phi;
-						if (tc < x.ncols2[h] && (m > st.best[h] || (m == st.best[h] && m > 0 && tc < st.btc[h]))) {
-							st.best[h] = m; st.btc[h] = tc;
+						if (tc < x.ncols2[h] && (m > st.best[h] || (m == st.best[h] && m > 0 && tc + x.col_shift < st.btc[h]))) {
+							st.best[h] = m; st.btc[h] = tc + x.col_shift;      /* (columns of the job's window: the strips of a banded pass start at different ones) */
 #pragma unroll
 							for (int k = R - 1; k >= 0; --k) if ((int)((st.H[k] >> (16 * h)) & 0xffffu) == mf) st.brow[h] = x.row0 + l16 * R + k;
 						}
@@ -1459,6 +1461,7 @@ SSW_DEV void run_strip(unsigned char* lds, const StripCtx& x, ChainState<R>& st,
 /* capture mode: one query half of a job (see k_chainx) */
 struct CapHalf {
 	int q, qlen, lena, rows, ncols, c_edge;
+	int band;      /* > 0: capped reverse pass on a diagonal band -- a strip of rows [r0, r0 + n) only visits columns [r0 - band, r0 + n + band) */
 	bool active, capped;
 	ssw_dres r;
 	const int8_t* qc;
@@ -1466,7 +1469,7 @@ struct CapHalf {
 
 SSW_DEV void cap_half_setup(CapHalf& h, const ssw_chainx_args& a, int q)
 {
-	h.q = q; h.active = false; h.capped = false; h.qlen = 0; h.lena = 0; h.rows = 0; h.ncols = 0; h.c_edge = 0; h.qc = a.qcodes;
+	h.q = q; h.active = false; h.capped = false; h.qlen = 0; h.lena = 0; h.rows = 0; h.ncols = 0; h.c_edge = 0; h.qc = a.qcodes; h.band = 0;
 	if (q < 0) return;
 	h.r = a.res[q];
 	h.active = h.r.status == 0 && h.r.score1 > 0 && (a.reverse ? h.r.want_begin == 1 : !h.r.loc_done);
@@ -1480,7 +1483,7 @@ SSW_DEV void cap_half_setup(CapHalf& h, const ssw_chainx_args& a, int q)
 	if (a.gapE <= 0 || w > h.r.ref_end1) w = h.r.ref_end1;
 	if (a.reverse && a.window_extra >= 0) {   /* first try: the alignment rarely spans more than its rows + 25 % */
 		const long long cap = (long long)h.rows + h.rows / 4 + a.window_extra;
-		if (cap < w) { w = cap; h.capped = true; }
+		if (cap < w) { w = cap; h.capped = true; h.band = h.rows / 4 + a.window_extra; }
 	}
 	h.ncols = (int)w + 1;
 	h.c_edge = a.reverse ? h.r.ref_end1 : h.r.ref_end1 - (int)w;
@@ -1495,7 +1498,14 @@ SSW_DEV void cap_half_finish(const CapHalf& h, const ssw_chainx_args& a, int bv,
 		a.res[q].read_end1 = (bv == h.r.score1) ? (br < h.qlen - 1 ? br : h.qlen - 1) : -1;
 		if (bv != h.r.score1) a.res[q].status = 3;
 	} else {
-		if (bv != h.r.score1 && h.capped) { if (a.retry_count) atomicAdd(a.retry_count, 1); }   /* stays want_begin == 1: rerun uncapped */
+		/* A banded pass (a.banded: every strip only visited the columns within `band` of its rows) is accepted when no cell it skipped, at
+		   or before the column found, can hold score1: a path through a cell (r, c) with |r - c| >= band and c <= bc has at most bc + 1
+		   diagonal steps and gaps of >= band residues in one direction, i.e. scores <= max(mat) * (bc + 1) - gapO - (band - 1) * gapE.
+		   Otherwise -- like a capped window that did not reproduce score1 -- the alignment is rerun with the exact window. */
+		bool proven = true;
+		if (a.banded && h.capped && bv == h.r.score1)
+			proven = (long long)(a.maxmat > 0 ? a.maxmat : 0) * (bc + 1) - (long long)(a.gapO2 & 0xffffu) - (long long)(h.band - 1) * a.gapE < (long long)h.r.score1;
+		if ((bv != h.r.score1 || !proven) && h.capped) { if (a.retry_count) atomicAdd(a.retry_count, 1); }   /* stays want_begin == 1: rerun uncapped */
 		else if (bv != h.r.score1 && h.ncols <= h.r.ref_end1) a.res[q].status = 3;
 		else {
 			const int rb = h.r.ref_end1 - bc, qbeg = h.r.read_end1 - (br < h.lena - 1 ? br : h.lena - 1);
@@ -1531,7 +1541,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 	int lena = 0, lenb = 0, rev = 0, rowsa = 0, rowsb = 0, rows_total = 0, p8a = 0, p8b = 0;
 	bool active = false;
 	CapHalf ch[2];
-	x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0; x.g16 = 0; x.g8 = 0;
+	x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0; x.g16 = 0; x.g8 = 0; x.col_shift = 0;
 	x.ncols2[0] = x.ncols2[1] = 0; x.c_edge2[0] = x.c_edge2[1] = 0;
 	if (!CAPTURE) {
 		if (valid) {
@@ -1570,6 +1580,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
 	}
 	x.nsteps = (mc + GL + 15) & ~15;
 	x.bnd = a.bnd + (int64_t)(valid ? job : 0) * a.bnd_stride * 4;
+	x.bnd_avail = x.ncols;
 
 	ChainState<R> st;
 	st.best[0] = st.best[1] = 0; st.btc[0] = st.btc[1] = 0x7fffffff; st.brow[0] = st.brow[1] = 0;
@@ -1686,7 +1697,7 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 		int lena = 0, lenb = 0, rev = 0, rowsa = 0, rowsb = 0, rows_total = 0, p8a = 0, p8b = 0;
 		bool active = false;
 		CapHalf ch[2];
-		x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0; x.g16 = 0; x.g8 = 0;
+		x.ncols = 0; x.c_edge = 0; x.dirstep = 1; x.store_from = 0; x.o16 = 0; x.o8 = 0; x.g16 = 0; x.g8 = 0; x.col_shift = 0;
 		x.ncols2[0] = x.ncols2[1] = 0; x.c_edge2[0] = x.c_edge2[1] = 0;
 		if (sidx > 0) {   /* everything the strip above wrote -- boundary records, its best cell, and (window passes) the records */
 			if (!a.whole_jobs && tid == 0 && !dev_flag_wait(flags + (int64_t)job * S + sidx - 1)) atomicAdd(a.err, 1);   /* error word: the host fails the call */
@@ -1723,8 +1734,40 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 			if (tid == 0) dev_flag_set(my_flag);
 			continue;
 		}
-		x.nsteps = (x.ncols + GL + 15) & ~15;
 		x.bnd = a.bnd + (int64_t)job * a.bnd_stride * 4;
+		x.bnd_avail = x.ncols;
+		if (CAPTURE && a.banded) {
+			/* capped reverse pass on a diagonal band (round 4): the alignment leaves the end cell along the diagonal and strays from it by
+			   at most its indel budget, so the strip of rows [r0, r0 + 64 R) only walks the columns [r0 - band, r0 + 64 R + band) of the
+			   window -- 5 600 instead of 12 500 columns per strip of a 10-kb read.  Cells outside count as the zero boundary (a lower bound
+			   of the true values); cap_half_finish accepts the result only with a proof that none of them could hold score1. */
+			int band = 0;
+			bool all_capped = true;
+			for (int h = 0; h < 2; ++h) {
+				if (ch[h].active && ch[h].capped && ch[h].band > band) band = ch[h].band;
+				if (ch[h].active && !ch[h].capped) all_capped = false;
+			}
+			if (band > 0 && all_capped) {
+				const int r0 = sidx * GL * R;
+				const int lo = r0 - band > 0 ? (r0 - band) & ~15 : 0;
+				int hi_up = 0;
+				x.ncols = 0;
+				for (int h = 0; h < 2; ++h) {
+					const int nc = ch[h].active ? ch[h].ncols : 0;
+					int hi = r0 + GL * R + band; if (hi > nc) hi = nc;
+					int hu = r0 + band; if (hu > nc) hu = nc;      /* where the strip above (rows [r0 - 64 R, r0)) stopped */
+					x.ncols2[h] = hi - lo > 0 ? hi - lo : 0;
+					x.c_edge2[h] = ch[h].c_edge + x.dirstep * lo;
+					if (x.ncols2[h] > x.ncols) x.ncols = x.ncols2[h];
+					if (hu > hi_up) hi_up = hu;
+				}
+				x.col_shift = lo;
+				x.bnd += 4 * (int64_t)lo;
+				x.bnd_avail = hi_up - lo > 0 ? hi_up - lo : 0;
+				if (x.bnd_avail > x.ncols) x.bnd_avail = x.ncols;
+			}
+		}
+		x.nsteps = (x.ncols + GL + 15) & ~15;
 		x.mine = true; x.first = sidx == 0; x.last = sidx == Sjob - 1; x.row0 = sidx * GL * R;
 
 		/* the best cell so far of this job: what the strips above found (value, first column, smallest row per half) */

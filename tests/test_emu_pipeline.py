@@ -432,3 +432,32 @@ def test_allocation_failure_shrinks_the_budget_and_retries(emu_lib_path, monkeyp
         Q.free(); T.free()
     finally:
         ctx.close()
+
+
+def test_banded_reverse_pass_of_long_reads(ectx, monkeypatch):
+    """the capped reverse pass of the strip kernel walks a diagonal band of the window (every strip only the columns within the indel
+    budget of its rows) and is accepted only with a proof that no skipped cell could hold score1; reads whose alignment strays further
+    (one long deletion), reads with a weak alignment (proof fails) and unrelated reads are rerun with the exact window.  Against the
+    reference, and against the same call with whole windows (SSW_GPU_NO_BAND=1)."""
+    from sswutil import mutate
+    rng = np.random.default_rng(31)
+    ref = random_ref(9000, 17, 4)
+    reads = []
+    for L, sub, ind in ((1500, 0.01, 0.003), (2100, 0.02, 0.01), (2600, 0.005, 0.002), (1800, 0.10, 0.03), (3000, 0.01, 0.004)):
+        o = int(rng.integers(0, len(ref) - L - 200))
+        reads.append(np.ascontiguousarray(mutate(ref[o:o + L + 60], rng, sub, ind, ind, 4)[:L]))
+    o = 1000
+    reads.append(np.ascontiguousarray(np.concatenate([ref[o:o + 900], ref[o + 900 + 700:o + 900 + 700 + 900]])))     # a 700-base deletion: outside the band of 1800 / 4 + 64
+    reads.append(rng.integers(0, 4, size=1600, dtype=np.int8))                                                       # unrelated
+    reads.append(np.ascontiguousarray(ref[4000:4000 + 1536]))                                                        # exactly three window strips
+    mat = dna_matrix(2, 2)
+    Q = ectx.upload(reads); T = ectx.upload([ref])
+    try:
+        res, cig = ectx.align_batch(Q, T, mat, 5, 3, 1, 2, 0, 0, -1, 2)
+        bad = compare_batch(res, cig, reads, [ref], mat, 5, 3, 1, 2, 0, 0, -1, 2)
+        assert not bad, "\n".join(bad)
+        monkeypatch.setenv("SSW_GPU_NO_BAND", "1")
+        res2, cig2 = ectx.align_batch(Q, T, mat, 5, 3, 1, 2, 0, 0, -1, 2)
+        assert all((res[f] == res2[f]).all() for f in res.dtype.names) and (cig == cig2).all()
+    finally:
+        Q.free(); T.free()
