@@ -872,6 +872,12 @@ static int window_pass(ssw_gpu_ctx* c, const win_in* wi, const bucket* B, int pa
 			if (pass) {
 				if (ssw_shim_d2h(&missed, d_retry, sizeof(int32_t), c->stream) || ssw_shim_stream_sync(c->stream)) return fail(c, "download failed: %s", ssw_shim_last_error());
 				if (c->kn.debug) fprintf(stderr, "[ssw_gpu] reverse pass (%s): %d of %d alignments are rerun with the exact window\n", xa.banded ? "capped window, diagonal band" : "capped window", missed, cnt_q);
+				if (missed > 0 && xa.banded) {      /* second tier: the alignments whose band did not hold (or could not be proven) take the whole capped window */
+					xa.banded = 0;
+					if (ssw_shim_memset(d_retry, 0, sizeof(int32_t), c->stream) || launch_window_pass(c, capR, capL, capS, &xa, n)) return fail(c, "capture launch failed: %s", ssw_shim_last_error());
+					if (ssw_shim_d2h(&missed, d_retry, sizeof(int32_t), c->stream) || ssw_shim_stream_sync(c->stream)) return fail(c, "download failed: %s", ssw_shim_last_error());
+					if (c->kn.debug) fprintf(stderr, "[ssw_gpu] reverse pass (capped window): %d alignments are rerun with the exact window\n", missed);
+				}
 				if (missed > 0) {
 					xa.window_extra = -1; xa.banded = 0;
 					if (launch_window_pass(c, capR, capL, capS, &xa, n)) return fail(c, "capture launch failed: %s", ssw_shim_last_error());

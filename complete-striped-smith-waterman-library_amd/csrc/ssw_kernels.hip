@@ -1483,7 +1483,20 @@ SSW_DEV void cap_half_setup(CapHalf& h, const ssw_chainx_args& a, int q)
 	if (a.gapE <= 0 || w > h.r.ref_end1) w = h.r.ref_end1;
 	if (a.reverse && a.window_extra >= 0) {   /* first try: the alignment rarely spans more than its rows + 25 % */
 		const long long cap = (long long)h.rows + h.rows / 4 + a.window_extra;
-		if (cap < w) { w = cap; h.capped = true; h.band = h.rows / 4 + a.window_extra; }
+		if (cap < w) {
+			w = cap; h.capped = true;
+			/* the diagonal band is only worth trying where its acceptance proof (cap_half_finish) can succeed: an alignment that scores
+			   close to max(mat) per row.  A weak one -- an unrelated read's best local alignment, hundreds of rows of the linear regime --
+			   would be found and then rerun with the exact window; it keeps the whole capped window instead. */
+			/* how far a path of this score can stray from the diagonal: every residue of deviation costs >= gapE of the max(mat) * rows an
+			   ungapped perfect alignment would score -- plus rows / 32 + window_extra of slack, at most the capped window's rows / 4 + extra */
+			const long long mm = a.maxmat > 0 ? a.maxmat : 0;
+			long long lost = (mm * h.rows - h.r.score1) / (a.gapE > 0 ? a.gapE : 1);
+			if (lost < 0) lost = 0;
+			long long band = lost + h.rows / 32 + a.window_extra;
+			if (band > h.rows / 4 + a.window_extra) band = h.rows / 4 + a.window_extra;
+			if (mm * (h.rows + h.rows / 64) - (long long)(a.gapO2 & 0xffffu) - (band - 1) * a.gapE < (long long)h.r.score1) h.band = (int)band;
+		}
 	}
 	h.ncols = (int)w + 1;
 	h.c_edge = a.reverse ? h.r.ref_end1 : h.r.ref_end1 - (int)w;
@@ -1503,7 +1516,7 @@ SSW_DEV void cap_half_finish(const CapHalf& h, const ssw_chainx_args& a, int bv,
 		   diagonal steps and gaps of >= band residues in one direction, i.e. scores <= max(mat) * (bc + 1) - gapO - (band - 1) * gapE.
 		   Otherwise -- like a capped window that did not reproduce score1 -- the alignment is rerun with the exact window. */
 		bool proven = true;
-		if (a.banded && h.capped && bv == h.r.score1)
+		if (a.banded && h.capped && h.band > 0 && bv == h.r.score1)      /* (band > 0: this job really walked the band, k_chainq) */
 			proven = (long long)(a.maxmat > 0 ? a.maxmat : 0) * (bc + 1) - (long long)(a.gapO2 & 0xffffu) - (long long)(h.band - 1) * a.gapE < (long long)h.r.score1;
 		if ((bv != h.r.score1 || !proven) && h.capped) { if (a.retry_count) atomicAdd(a.retry_count, 1); }   /* stays want_begin == 1: rerun uncapped */
 		else if (bv != h.r.score1 && h.ncols <= h.r.ref_end1) a.res[q].status = 3;
@@ -1745,7 +1758,7 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 			bool all_capped = true;
 			for (int h = 0; h < 2; ++h) {
 				if (ch[h].active && ch[h].capped && ch[h].band > band) band = ch[h].band;
-				if (ch[h].active && !ch[h].capped) all_capped = false;
+				if (ch[h].active && (!ch[h].capped || ch[h].band <= 0)) all_capped = false;
 			}
 			if (band > 0 && all_capped) {
 				const int r0 = sidx * GL * R;
@@ -1765,7 +1778,7 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 				x.bnd += 4 * (int64_t)lo;
 				x.bnd_avail = hi_up - lo > 0 ? hi_up - lo : 0;
 				if (x.bnd_avail > x.ncols) x.bnd_avail = x.ncols;
-			}
+			} else { ch[0].band = 0; ch[1].band = 0; }      /* whole windows for this job: nothing to prove */
 		}
 		x.nsteps = (x.ncols + GL + 15) & ~15;
 		x.mine = true; x.first = sidx == 0; x.last = sidx == Sjob - 1; x.row0 = sidx * GL * R;
