@@ -457,7 +457,7 @@ def bench_dna(args, world, rank, local_rank, dist):
             # readLen + n^2 query/matrix bytes, 4*refLen column-maximum bytes written (2 rule sets x u16), 40 B result; long queries add the
             # boundary records between strips (16 B per column and pair, written once and read once)
             aln_per_launch = nreads * args.steps / max(1, acc["fill_launches"])
-            bytes_per_aln = p["ref_len"] + rlen + 25 + 40 + 4 * p["ref_len"]
+            bytes_per_aln = p["ref_len"] + rlen + 25 + 40 + 4 * p["ref_len"] + p["ref_len"] // 4      # (+ the 16-column group maxima: two u32 streams per pair / 16)
             if tm["fill_strips"] > 1:
                 bytes_per_aln += 16 * p["ref_len"] * (tm["fill_strips"] - 1)
             achieved = aln_per_launch * bytes_per_aln / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
