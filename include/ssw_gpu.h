@@ -104,6 +104,11 @@ int32_t ssw_gpu_seqs_count(const ssw_gpu_seqs* s);
  * Align every query to targets [target_first, target_first + target_count).
  * results[q * target_count + t] receives the record of (query q, target target_first + t).
  * cigar_pool (optional) receives a malloc()ed array of *cigar_words BAM-packed words (caller frees).
+ *
+ * Against four or more short targets the call is ONE database search whatever the flag: scores and end positions of all pairs from a
+ * fused kernel; with flag != 0 the pairs that pass the reference's gates (src/ssw.c:916: not when flag == 2 and score1 < filters) go
+ * through one batched reverse pass and traceback -- the loop of src/main.c:493-506 without a per-target iteration.  Queries of mixed
+ * lengths run side by side.  A call with one query and one target is what ssw_align is made of.
  */
 int ssw_gpu_align_batch(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* queries, const ssw_gpu_seqs* targets,
                         int32_t target_first, int32_t target_count, const ssw_gpu_params* params,
@@ -126,7 +131,8 @@ const char* ssw_gpu_strerror(int rc);
    (several ranks or pool workers per GPU) should each get their share: ssw_gpu_pool_open does that for its workers.
    ssw_gpu_set_budget(ctx, 0) recomputes the default; ssw_gpu_set_budget_exclusive(ctx) is the caller's statement that the context
    has the device to itself: min(200 GiB, 60 % of the free HBM) -- the 288 GB of an MI355X then hold 3 fill launches per 100 000
-   150-bp reads against 1 Mb instead of 6 (+1 %). */
+   150-bp reads against 1 Mb instead of 6 (+1 %).  UNSAFE on a device that other processes use: their allocations are not refused, a later
+   kernel launch of either side fails instead.  Every phase of a call, the traceback included, stays within the budget. */
 int ssw_gpu_set_budget(ssw_gpu_ctx* ctx, size_t bytes);
 int ssw_gpu_set_budget_exclusive(ssw_gpu_ctx* ctx);
 size_t ssw_gpu_get_budget(const ssw_gpu_ctx* ctx);
