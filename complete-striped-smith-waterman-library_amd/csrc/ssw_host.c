@@ -1422,11 +1422,15 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 				if (Q->h_off[qq + 1] - Q->h_off[qq] > dxs.maxlen) dxs.maxlen = (int32_t)(Q->h_off[qq + 1] - Q->h_off[qq]);
 			}
 			for (int32_t q = 0; q < nq; ++q) if (Q->h_off[q + 1] == Q->h_off[q]) qdone[q] = 1;     /* empty queries: empty records, written there */
-			if (align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone, ds, use_dbx ? &dxs : 0)) goto done;
+			{
+				const int db_rc = align_db(c, Q, T, tfirst, tcount, prm, results, bk, nb, d_pairs, d_mat, bias, (int32_t)maxt, qdone, ds, use_dbx ? &dxs : 0);
+				free(dxs.hs); free(dxs.hvq); free(dxs.hvt); free(dxs.hpo); dxs.hs = 0; dxs.hvq = 0; dxs.hvt = 0; dxs.hpo = 0;      /* (the survivors' host copies were patched into the records inside) */
+				if (db_rc) goto done;
+			}
 			d_res = (ssw_dres*)ensure(c, &c->res, sizeof(ssw_dres) * (size_t)nq);   /* align_db may have regrown the record buffer */
 			if (!d_res) goto done;
 			locate_ms += dxs.locate_ms; trace_ms += dxs.trace_ms;
-			if (any_long) { free(dxs.hs); free(dxs.hvq); free(dxs.hvt); free(dxs.hpo); dxs.hs = 0; dxs.hvq = 0; dxs.hvt = 0; dxs.hpo = 0; }
+
 			if (!any_long) {
 				ssw_shim_event_record(c->ev_d, c->stream);
 				if (ssw_shim_stream_sync(c->stream)) { fail(c, "stream sync failed: %s", ssw_shim_last_error()); goto done; }
@@ -1434,7 +1438,6 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 				c->tm.total_ms = ssw_shim_event_elapsed_ms(c->ev_t0, c->ev_d); c->tm.fill_ms = fill_ms;
 				c->tm.locate_ms = dxs.locate_ms; c->tm.trace_ms = dxs.trace_ms;
 				c->tm.reduce_ms = c->tm.total_ms - fill_ms - dxs.locate_ms - dxs.trace_ms; if (c->tm.reduce_ms < 0) c->tm.reduce_ms = 0;
-				free(dxs.hs); free(dxs.hvq); free(dxs.hvt); free(dxs.hpo);
 				if (cigar_pool) { *cigar_pool = pool; pool = 0; }
 				if (cigar_words) *cigar_words = pool_words;
 				rc = 0;
