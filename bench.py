@@ -471,6 +471,8 @@ def bench_dna(args, world, rank, local_rank, dist):
                                    "launch_ms": round(launch_ms, 3), "launches": int(acc["fill_launches"]),
                                    "algorithmic_bytes_per_alignment": int(bytes_per_aln),
                                    "note": "HBM is not the binding resource of this path (see roofline)"}
+            out["roofline"]["traffic"] = traffic      # (HBM GB/s of the same kernel from the PMC passes: the contract's key; details in roofline_hbm)
+            out["roofline"]["traffic_unit"] = "GB/s of HBM traffic (FETCH_SIZE + WRITE_SIZE), see roofline_hbm"
             # PCIe-inclusive rate: one more step with the reads uploaded (and freed) inside it
             if world == 1 and not args.quiet:
                 t1 = time.perf_counter()
@@ -608,6 +610,7 @@ def bench_db(args, world, rank, local_rank, dist):
                                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "launch_ms": round(launch_ms, 3), "launches": int(launches), "algorithmic_bytes_per_alignment": round(bytes_per_aln, 1),
                                "note": "HBM is not the binding resource of this path (see roofline)"}
+        hbm_traffic = traffic
         ops = tm["fill_ops_per_row"]
         achieved_valu = fill_cells * ops / 2.0 / (fill_ms * 1e-3) if fill_ms > 0 else 0.0
         real = cells * args.steps * ops / 2.0 / (fill_ms * 1e-3) if fill_ms > 0 else 0.0
@@ -621,7 +624,8 @@ def bench_db(args, world, rank, local_rank, dist):
                                         "ISA ideal %.1f cycles per pair-row); best-cell tracking and the fused reduction are overhead on top; `achieved` counts readLen x refLen cells, "
                                         "`frac_with_padding_and_halo` every evaluated cell" % (ops, CYCLES_PER_PAIR_ROW_ISA_IDEAL),
                            "fill_gcups_padded": round(fill_cells / (fill_ms * 1e-3) / 1e9, 1) if fill_ms > 0 else 0.0,
-                           "counters": measured_issue("config5") if is_preset else None}
+                           "counters": measured_issue("config5") if is_preset else None,
+                           "traffic": hbm_traffic, "traffic_unit": "GB/s of HBM traffic (FETCH_SIZE + WRITE_SIZE), see roofline_hbm"}
         if True:
             par = {}
             fix = os.path.join(FULL, "config5_block0.npz")
