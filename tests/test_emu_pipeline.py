@@ -390,6 +390,20 @@ def test_mixed_read_lengths_buckets_side_by_side_and_one_after_the_other(ectx, m
         Q.free(); T.free()
 
 
+def test_mixed_read_lengths_grids_of_both_forms(ectx, monkeypatch):
+    """one multi-bucket grid per (register class, form of the recurrence): with match 100 the buckets of long reads leave the column frame's
+    range (plain int16 form) while the short ones stay in it -- both kinds of grids in one call; the plain form everywhere; the frame
+    renormalised every 16 columns"""
+    import workloads as W
+    ref, reads, _ = W.mixed_config(0, reads=36, ref_len=5000)
+    for match, mis, gO, gE, env in ((100, 90, 7, 2, {}), (2, 2, 3, 1, {"SSW_GPU_FILL_FORM": "0"}), (2, 2, 3, 1, {"SSW_GPU_FRAME_K": "16"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        _run(ectx, reads, [ref], dna_matrix(match, mis), 5, gO, gE, flag=2)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_long_reads_of_different_padded_lengths_share_a_launch(ectx):
     """single-strip long reads (385..768 residues) are bucketed by rows per lane, not by padded length: the two queries of a pair may
     have different padded lengths (rows below a query's own padded length are dead for its half), padded and unpadded lengths
