@@ -84,6 +84,7 @@ struct ssw_gpu_ctx {
 	int budget_shrunk;                  /* an allocation failed once: the device is shared, the budget was cut (SSW_ALLOC_RETRY) */
 	ssw_knobs kn;                       /* environment hooks of the running call (knobs_load) */
 	int dev_cus, dev_wave_slots;        /* compute units and resident wavefront slots of the device (hipGetDeviceProperties) */
+	int device_share;                   /* > 1: that many single-pair calls of this process are in flight right now (ssw_align): a small call sizes its tiles for its share of the device */
 	int queue_used;                     /* a work-queue launch of this call may have raised the error word (c->qerr): checked before results are handed out */
 	void* hits_d[2]; void* hits_h[2]; size_t hits_cap;     /* streamed database search: two device + two page-locked host buffers, kept between calls */
 };
@@ -175,9 +176,7 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
 	if (!c) { fail(0, "out of host memory%s", ""); return 0; }
 	c->device = device;
 	c->stream = ssw_shim_stream_create();
-	c->stream2 = ssw_shim_stream_create();
-	int ok = c->stream && c->stream2;
-	for (int i = 0; i < SSW_TSTREAMS; ++i) { c->tstream[i] = ssw_shim_stream_create(); c->tev[i] = ssw_shim_event_create(); ok = ok && c->tstream[i] && c->tev[i]; }
+	int ok = c->stream != 0;      /* (the side streams come with the first call that is more than one pair: ctx_side_streams) */
 	for (int i = 0; i < 2; ++i) { c->ev_fill[i] = ssw_shim_event_create(); c->ev_red[i] = ssw_shim_event_create(); ok = ok && c->ev_fill[i] && c->ev_red[i]; }
 	c->ev_t0 = ssw_shim_event_create(); c->ev_a = ssw_shim_event_create(); c->ev_b = ssw_shim_event_create();
 	c->ev_c = ssw_shim_event_create(); c->ev_d = ssw_shim_event_create(); c->ev_db = ssw_shim_event_create();
@@ -200,6 +199,19 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
 	c->cm_budget = e ? (size_t)atoll(e) << 20 : (size_t)64 << 30;
 	if (!e) { size_t fr = ssw_shim_mem_free_bytes(); if (fr && c->cm_budget > fr / 2) c->cm_budget = fr / 2; }
 	return c;
+}
+
+/* The side streams (reductions beside fills, buckets / size classes / traceback classes side by side) are created by the first call that can
+   use them.  A context that only ever serves single-pair ssw_align calls keeps ONE stream: the runtime maps streams onto four hardware queues
+   in creation order, and with eight streams per context the main streams of all caller threads' contexts landed on the SAME queue -- their
+   calls ran one after the other however many threads called (scripts/probes/dropin_threads.c, profiles/round4_dropin_threads.txt). */
+static int ctx_side_streams(ssw_gpu_ctx* c)
+{
+	if (c->stream2) return 0;
+	c->stream2 = ssw_shim_stream_create();
+	int ok = c->stream2 != 0;
+	for (int i = 0; i < SSW_TSTREAMS; ++i) { c->tstream[i] = ssw_shim_stream_create(); c->tev[i] = ssw_shim_event_create(); ok = ok && c->tstream[i] && c->tev[i]; }
+	return ok ? 0 : fail(c, "stream/event creation failed: %s", ssw_shim_last_error());
 }
 
 const char* ssw_gpu_strerror(int rc)
@@ -1261,6 +1273,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 	const int literal = prm->gapO <= prm->gapE;   /* layout-dependent regime of the reference: lane-model kernel (k_literal) */
 	ssw_shim_set_device(c->device);
 	knobs_load(&c->kn);
+	if ((Q->count > 1 || tcount > 1 || ds) && ctx_side_streams(c)) return -1;      /* (one pair never leaves the main stream) */
 	if (cigar_pool) *cigar_pool = 0;
 	if (cigar_words) *cigar_words = 0;
 	const int32_t nq = Q->count, n = prm->n;
@@ -1530,7 +1543,8 @@ plan_again:
 					   halo columns in sequence: then the tiles go down to half the halo (at least 64 columns) as long as all chains of the
 					   call still fit the device at once; the recomputed halos run on compute units that would idle.  One 150-bp read against a
 					   10-kb target: 736 steps instead of 10 000 (2.3 -> 0.x ms per ssw_align call, profiles/round4_latency.txt). */
-					const int64_t slots = use_x ? (int64_t)c->dev_wave_slots : (int64_t)c->dev_cus * 96;      /* chains the device holds at once */
+					int64_t slots = use_x ? (int64_t)c->dev_wave_slots : (int64_t)c->dev_cus * 96;      /* chains the device holds at once */
+					if (c->device_share > 1) { slots /= c->device_share; if (slots < 256) slots = 256; }      /* other caller threads' pairs are on the device too */
 					const int64_t all_pairs = npairs_total > 0 ? npairs_total : 1;
 					if (all_pairs * want < slots && halo_full < refLen) {
 						const int64_t mint = halo_full / 2 > 64 ? halo_full / 2 : 64;
@@ -2067,6 +2081,7 @@ typedef struct {
 	unsigned char* stage; size_t stage_cap;           /* host staging of one upload (offsets + codes) */
 } implicit_ctx;
 
+static int g_single_inflight;      /* ssw_align calls of this process inside the library right now */
 static pthread_key_t g_ictx_key;
 static pthread_once_t g_ictx_once = PTHREAD_ONCE_INIT;
 static int g_next_device = 0;
@@ -2090,6 +2105,11 @@ static implicit_ctx* implicit_get(void)
 	pthread_once(&g_ictx_once, implicit_key_init);
 	implicit_ctx* ic = (implicit_ctx*)pthread_getspecific(g_ictx_key);
 	if (ic) return ic;
+	/* Caller threads' calls overlap on the device only as far as the runtime has hardware queues for their streams: ROCm's default is four
+	   per process.  If nobody chose otherwise and the runtime is not up yet (this is typically the process's first HIP call), ask for eight:
+	   8 caller threads 6 085 -> 8 146 calls per second (profiles/round4_dropin_threads.txt).  Without effect in a process that initialised
+	   HIP before; a user's own GPU_MAX_HW_QUEUES is left alone. */
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	const int ndev = ssw_shim_device_count();
 	const char* e = getenv("SSW_GPU_DEVICE");
 	const int dev = e ? atoi(e) : (ndev > 0 ? __atomic_fetch_add(&g_next_device, 1, __ATOMIC_RELAXED) % ndev : 0);
@@ -2187,7 +2207,13 @@ s_align* ssw_align(const s_profile* prof, const int8_t* ref, int32_t refLen, con
 		prm.mat = prof->mat; prm.n = prof->n; prm.gapO = weight_gapO; prm.gapE = weight_gapE; prm.flag = flag;
 		prm.filters = filters; prm.filterd = filterd; prm.maskLen = maskLen < 0 ? 0 : maskLen; prm.score_size = prof->score_size; prm.mark_mismatch = 0;
 		ssw_gpu_result r; uint32_t* pool = 0; int64_t words = 0;
-		if (ssw_gpu_align_batch(c, &ic->q, &ic->t, 0, 1, &prm, &r, &pool, &words) == 0) {
+		/* how many caller threads are in here at once: alone, a call spreads its one pair over the whole device (tiles of half a halo,
+		   lowest latency); with company it takes its share, fewer and longer tiles with less recomputed halo */
+		c->device_share = __atomic_add_fetch(&g_single_inflight, 1, __ATOMIC_RELAXED);
+		const int brc = ssw_gpu_align_batch(c, &ic->q, &ic->t, 0, 1, &prm, &r, &pool, &words);
+		__atomic_sub_fetch(&g_single_inflight, 1, __ATOMIC_RELAXED);
+		c->device_share = 0;
+		if (brc == 0) {
 			if (r.status == 1)
 				fprintf(stderr, "Please set 2 to the score_size parameter of the function ssw_init, otherwise the alignment results will be incorrect.\n");
 			else {

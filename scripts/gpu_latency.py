@@ -37,4 +37,25 @@ for ref_len in (10_000, 1_000_000):
             ts = np.array(ts[20:]) * 1e3      # the first calls create the implicit context and size its buffers
             out["read %d x target %d, flag %d" % (rl, ref_len, flag)] = {"median_ms": round(float(np.median(ts)), 3), "p90_ms": round(float(np.percentile(ts, 90)), 3),
                                                                           "gcups_of_a_caller_loop": round(rl * ref_len / float(np.median(ts)) / 1e6, 1)}
+# the same loop from several caller threads (every thread gets its own implicit context, include/ssw_gpu.h "Threads"; ctypes releases the GIL
+# inside the calls): what an unmodified multi-threaded caller of ssw_align gets
+import threading
+ref = random_ref(1_000_000, 1, 4)
+reads = [np.ascontiguousarray(r) for r in sample_reads(ref, 256, 150, seed=6)]
+for nth in (4, 16):
+    for flag in (0, 2):
+        def work(k):
+            for i in range(k, len(reads), nth):
+                r = reads[i]
+                p = lib.ssw_init(r.ctypes.data_as(i8p), len(r), mat.ctypes.data_as(i8p), 5, 2)
+                a = lib.ssw_align(p, ref.ctypes.data_as(i8p), len(ref), 3, 1, flag, 0, 0, 75)
+                lib.align_destroy(a); lib.init_destroy(p)
+        for rep in range(2):      # (the first round creates the threads' contexts)
+            ths = [threading.Thread(target=work, args=(k,)) for k in range(nth)]
+            t0 = time.perf_counter()
+            for t in ths: t.start()
+            for t in ths: t.join()
+            dt = time.perf_counter() - t0
+        out["%d caller threads, read 150 x target 1000000, flag %d" % (nth, flag)] = {"calls_per_s": round(len(reads) / dt), "ms_per_call_aggregate": round(dt / len(reads) * 1e3, 3),
+                                                                                      "gcups": round(len(reads) * 150 * 1e6 / dt / 1e9, 1)}
 print(json.dumps(out))
