@@ -145,4 +145,6 @@ def test_flagged_database_search_vs_reference_gpu(gpu_ctx, reflib, flag, filters
     finally:
         Q.free(); T.free()
     n_cig = check_against_reference(res, cig, exp, exph, "flag %d filters %d filterd %d" % (flag, filters, filterd))
-    assert "k_filldb" in tm["fill_kernel"] and n_cig > 0
+    assert n_cig > 0
+    if os.environ.get("SSW_GPU_NO_DBX") != "1":                     # (the suite is also run with the per-target loop forced: same records)
+        assert "k_filldb" in tm["fill_kernel"]
