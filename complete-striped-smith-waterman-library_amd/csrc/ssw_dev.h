@@ -249,6 +249,7 @@ typedef struct {
 	int32_t whole_jobs;      /* 1: a ticket is a whole job (its strips in sequence on one wavefront); 0: a ticket is one strip */
 	ssw_vmap vm;             /* capture mode only */
 	int32_t banded;          /* capture mode, k_chainq, capped reverse pass: strips walk a diagonal band of the window (accepted only with cap_half_finish's proof) */
+	int32_t tail_R;          /* fill mode, k_chainq: > 0: the LAST of the `strips` strips has tail_R (1, 2 or 4) rows per lane instead of R (all jobs of the launch have the same padded length) */
 } ssw_chainx_args;
 
 /*

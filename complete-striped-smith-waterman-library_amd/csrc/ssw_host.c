@@ -58,6 +58,7 @@ typedef struct {
 	int trace_unblocked;    /* SSW_GPU_TRACE_BLOCKED=0: teams with one cell per thread */
 	int serial_buckets;     /* SSW_GPU_SERIAL_BUCKETS=1: geometry buckets one after the other on the main stream (the form before round 4) */
 	int no_dbx;             /* SSW_GPU_NO_DBX=1: flagged batches against many targets take the per-target loop (the form before round 4) */
+	int no_tail;            /* SSW_GPU_NO_TAIL=1: equal strips for long queries (no short last strip of the strip kernel: the form before the end of round 4) */
 	int no_band;            /* SSW_GPU_NO_BAND=1: the capped reverse pass of the strip kernel visits whole windows (the form before round 4) */
 	int call_trace;         /* SSW_GPU_CALL_TRACE=1: host timestamps of the phases of every batch call on stderr */
 	int db_tsub, dbx_slab;  /* SSW_GPU_DB_TSUB / SSW_GPU_DBX_SLAB: targets per chunk of the database search / survivors per traceback slab (tests: force
@@ -131,6 +132,7 @@ static void knobs_load(ssw_knobs* k)
 	k->no_dbx = env_is("SSW_GPU_NO_DBX", '1');
 	k->call_trace = env_is("SSW_GPU_CALL_TRACE", '1');
 	k->no_band = env_is("SSW_GPU_NO_BAND", '1');
+	k->no_tail = env_is("SSW_GPU_NO_TAIL", '1');
 	{ const int v = env_int("SSW_GPU_DB_TSUB", 0); k->db_tsub = v > 0 ? v : 0; }
 	{ const int v = env_int("SSW_GPU_DBX_SLAB", 0); k->dbx_slab = v > 0 ? v : 0; }
 }
@@ -413,7 +415,7 @@ static void* next_event(ssw_gpu_ctx* c)
 /* queries that share a chain geometry: short queries (<= 384 residues) by R = ceil(len/16) rows per lane, one strip;
    longer ones by their padded length P16, cut into `strips` row strips of lanes*R rows (k_chainx; lanes = 64: the
    wavefront is one chain, 16: four chains per wavefront) */
-typedef struct { int32_t R, strips, P16, lanes, use_x; int32_t first_pair, npairs; int32_t first_q, nq; } bucket;
+typedef struct { int32_t R, strips, P16, lanes, use_x; int32_t first_pair, npairs; int32_t first_q, nq; int32_t tailR; /* k_chainq: rows per lane of the last strip (0: R) */ } bucket;
 /* tile geometry and scratch of one bucket against the current target (planned before anything is launched: buckets whose launches all
    fit the budget together run side by side on the side streams, each in its own slice of the scratch buffers) */
 typedef struct {
@@ -587,7 +589,7 @@ static int align_db(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_gpu_seqs* T
 			for (int32_t q = 0; q < nq; ++q) if (qdone[q]) { const int64_t L = Q->h_off[q + 1] - Q->h_off[q]; if (L > 16 * SSW_RMAX && L <= 640) { mk[k].key = (int32_t)L; mk[k].sub = 0; mk[k].q = q; ++k; } }
 			qsort(mk, (size_t)nm, sizeof(keyed), keyed_cmp);
 			for (int cls = SSW_RMAX + 1; cls <= 40; ++cls) {
-				bucket b; b.R = cls; b.strips = 1; b.P16 = 16 * cls; b.lanes = 16; b.use_x = 0; b.first_pair = np; b.first_q = 0; b.nq = 0;
+				bucket b; b.tailR = 0; b.R = cls; b.strips = 1; b.P16 = 16 * cls; b.lanes = 16; b.use_x = 0; b.first_pair = np; b.first_q = 0; b.nq = 0;
 				for (int32_t i = 0; i < nm; ++i) {      /* sorted by length: the queries of a class are contiguous; neighbours share a chain */
 					if ((mk[i].key + 15) / 16 != cls) continue;
 					midpairs[np].qa = mk[i].q; midpairs[np].qb = -1; ++b.nq;
@@ -1352,7 +1354,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		bucket* nbk = (bucket*)realloc(bk, sizeof(bucket) * (size_t)(nb + 1));
 		if (!nbk) { free(bk); free(order); free(pairs); free(keys); free(qdone); return fail(c, "out of host memory%s", ""); }
 		bk = nbk;
-		bucket b;
+		bucket b; b.tailR = 0;
 		if (keys[i].key <= SSW_RMAX) { b.R = keys[i].key; b.strips = 1; b.P16 = 16 * b.R; b.lanes = 16; b.use_x = 0; }
 		else {
 			b.P16 = keys[j - 1].sub;       /* the longest of the bucket (sorted by padded length) */
@@ -1360,6 +1362,13 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 			const int32_t rows = b.lanes * (b.lanes == 64 ? xrmax : SSW_RMAX);
 			b.strips = (b.P16 + rows - 1) / rows;
 			b.R = (b.P16 + b.lanes * b.strips - 1) / (b.lanes * b.strips);        /* balanced strips */
+			/* ... unless full strips and a SHORT last one (1, 2 or 4 rows per lane) compute fewer rows: 10 000 rows are 13 strips of 768 and one
+			   of 64 (10 048 rows) instead of 14 of 768 (10 752).  The last strip pays a step's fixed part (boundary records, hand-offs) again,
+			   which is what a strip of 12 rows per lane pays too. */
+			if (b.lanes == 64 && b.strips > 1 && xrmax > 4 && !c->kn.no_tail) {
+				const int32_t rem = b.P16 - (b.strips - 1) * 64 * xrmax, need = (rem + 63) / 64, tr = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 0;
+				if (rem > 0 && tr > 0 && xrmax * (b.strips - 1) + tr < b.R * b.strips) { b.R = xrmax; b.tailR = tr; }
+			}
 		}
 		b.first_q = i; b.nq = j - i; b.first_pair = npairs_total;
 		for (int32_t k = i; k < j; ++k) order[k] = keys[k].q;
@@ -1711,9 +1720,9 @@ plan_again:
 							const int qgrid = chainq_grid(c, B->R, 0, n);
 							if (conc ? chainq_setup(c, &xa, B->strips, (int64_t)np * ntiles, qgrid, base_q + P->q_off, base_cs + P->cs_off, st)
 							         : chainq_prepare(c, &xa, B->strips, (int64_t)np * ntiles, qgrid)) goto done;
-							xa.form = xform; xa.fr_base = xfr_base; xa.fr_kmask = xfr_kmask;
-							if (c->kn.debug) fprintf(stderr, "[ssw_gpu] chainq fill: R %d, %d jobs x %d strips, %d wavefronts, %s tickets, form %d\n",
-							                                     B->R, np * ntiles, B->strips, qgrid, xa.whole_jobs ? "job" : "strip", xa.form);
+							xa.form = xform; xa.fr_base = xfr_base; xa.fr_kmask = xfr_kmask; xa.tail_R = B->tailR;
+							if (c->kn.debug) fprintf(stderr, "[ssw_gpu] chainq fill: R %d (last strip %d), %d jobs x %d strips, %d wavefronts, %s tickets, form %d\n",
+							                                     B->R, B->tailR ? B->tailR : B->R, np * ntiles, B->strips, qgrid, xa.whole_jobs ? "job" : "strip", xa.form);
 							if (ssw_shim_launch_chainq(B->R, 0, &xa, qgrid, st)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
 							if (c->kn.debug) { const int src = ssw_shim_stream_sync(st); fprintf(stderr, "[ssw_gpu] chainq fill done (sync rc %d: %s)\n", src, src ? ssw_shim_last_error() : "ok"); }
 						} else
@@ -1731,10 +1740,11 @@ plan_again:
 							int64_t cf = lo - halo > 0 ? lo - halo : 0;
 							cols += hi - cf;
 						}
-						const int64_t lc = cols * (int64_t)(B->lanes * B->R * B->strips) * 2 * np;
+						const int64_t lc = cols * (int64_t)(B->lanes * (B->tailR ? B->R * (B->strips - 1) + B->tailR : B->R * B->strips)) * 2 * np;
 						c->tm.fill_cells += lc;
-						char nm[48];
+						char nm[64];
 						if (!use_x) snprintf(nm, sizeof nm, "k_fill<%d,%s>", B->R, fa.form == 3 ? "frame" : "int16");
+						else if (B->lanes == 64 && B->tailR) snprintf(nm, sizeof nm, "k_chainq<%d,%s> x %d strips + 1 of %d", B->R, xform == 3 ? "frame" : "int16", B->strips - 1, B->tailR);
 						else if (B->lanes == 64) snprintf(nm, sizeof nm, "k_chainq<%d,%s> x %d strips", B->R, xform == 3 ? "frame" : "int16", B->strips);
 						else snprintf(nm, sizeof nm, "k_chainx<%d,16 lanes> x %d strips", B->R, B->strips);
 						note_fill_kernel(c, lc, &best_fill_cells, nm, !use_x ? (fa.form == 3 ? 6.5 : 9.0) : (B->lanes == 64 && xform == 3 ? 6.5 : 9.0), B->R, B->strips);

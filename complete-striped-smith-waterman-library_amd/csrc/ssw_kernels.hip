@@ -1666,6 +1666,7 @@ __global__ void __launch_bounds__(64) k_chainx(ssw_chainx_args a)
  * before.  LDS is trimmed (one target ring in fill mode, 32-entry boundary-out ring, reduction scratch aliased) so that
  * 12 rows per lane leave room for 8 wavefronts per CU.  FORM 3: column-frame form of the fill (run_strip<..., FR>), 0: plain int16.
  * ================================================================================================ */
+template <int V> struct IntTag { static constexpr int value = V; };
 template <int R, bool CAPTURE> struct QueueGeom {
 	static constexpr int C = (R + 3) / 4;
 	static constexpr u32 PSTRIDE = (u32)C * 1024u;
@@ -1742,7 +1743,11 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 			for (int h = 0; h < 2; ++h) { x.ncols2[h] = ch[h].active ? ch[h].ncols : 0; x.c_edge2[h] = ch[h].c_edge; }
 			x.ncols = x.ncols2[0] > x.ncols2[1] ? x.ncols2[0] : x.ncols2[1];
 		}
-		const int Sjob = active ? (rows_total + GL * R - 1) / (GL * R) : 0;
+		/* fill jobs of a launch with a.tail_R > 0 (all of the same padded length): S - 1 strips of R rows per lane and a LAST strip of
+		   a.tail_R <= 4 rows per lane that takes the remainder (10 000 rows = 13 x 768 + 16: a fourteenth strip of 12 rows per lane
+		   would compute 752 dead rows -- 7 % of the fill) */
+		const bool tail_mode = !CAPTURE && a.tail_R > 0;
+		const int Sjob = !active ? 0 : tail_mode ? S : (rows_total + GL * R - 1) / (GL * R);
 		if (sidx >= Sjob) {   /* this job has fewer strips than the launch's S (window passes of short prefixes): nothing to do */
 			if (tid == 0) dev_flag_set(my_flag);
 			continue;
@@ -1789,7 +1794,10 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 			const int32_t* pc = a.cand_strip + ((int64_t)job * S + sidx - 1) * 8;
 			for (int h = 0; h < 2; ++h) { cv[h] = pc[4 * h]; cc[h] = pc[4 * h + 1]; cr[h] = pc[4 * h + 2]; }
 		}
-		ChainState<R> st;
+		auto strip_body = [&](auto rr_tag) {
+		constexpr int RR = decltype(rr_tag)::value;
+		x.nulloff = (u32)a.n * StripGeom<RR, GL>::PSTRIDE;
+		ChainState<RR> st;
 		for (int h = 0; h < 2; ++h) {
 			st.best[h] = CAPTURE ? cv[h] : 0; st.btc[h] = CAPTURE ? cc[h] : 0x7fffffff; st.brow[h] = CAPTURE ? cr[h] : 0;
 			st.tv[h] = 0; st.ttc[h] = 0x7fffffff; st.trow[h] = 0x7fffffff;
@@ -1806,22 +1814,22 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 				if (floorv > st.best[h]) { st.best[h] = floorv; st.btc[h] = 0x7fffffff; st.brow[h] = 0; }
 			}
 		}
-		build_profile_strip<R, GL, FORM == 3 ? (CAPTURE ? 3 : 2) : 0>(lds, x.prof, l16, GL, a.mat, a.n, qa, lena, rev, rowsa, qb, lenb, rev, rowsb, x.row0, (int)(a.gapE2 & 0xffffu));
-		u32 m8[R];
+		build_profile_strip<RR, GL, FORM == 3 ? (CAPTURE ? 3 : 2) : 0>(lds, x.prof, l16, GL, a.mat, a.n, qa, lena, rev, rowsa, qb, lenb, rev, rowsb, x.row0, (int)(a.gapE2 & 0xffffu));
+		u32 m8[RR];
 		bool need_mask = false;
 		if (!CAPTURE) {
 			need_mask = x.last && (p8a < rows_total || p8b < rows_total);
 #pragma unroll
-			for (int q = 0; q < R; ++q) {
-				const int row = x.row0 + l16 * R + q;
+			for (int q = 0; q < RR; ++q) {
+				const int row = x.row0 + l16 * RR + q;
 				m8[q] = (row < p8a ? 0xffffu : 0u) | (row < p8b ? 0xffff0000u : 0u);
 			}
 		} else {
 #pragma unroll
-			for (int q = 0; q < R; ++q) m8[q] = 0;
+			for (int q = 0; q < RR; ++q) m8[q] = 0;
 		}
-		if (!CAPTURE && need_mask) run_strip<R, CAPTURE, true, GL, false, FORM == 3>(lds, x, st, m8);
-		else run_strip<R, CAPTURE, false, GL, FORM == 3, FORM == 3>(lds, x, st, m8);
+		if (!CAPTURE && need_mask) run_strip<RR, CAPTURE, true, GL, false, FORM == 3>(lds, x, st, m8);
+		else run_strip<RR, CAPTURE, false, GL, FORM == 3, FORM == 3>(lds, x, st, m8);
 
 		/* chain-wide winner of this strip merged with the strips above: value, then first column, then smallest row */
 		for (int h = 0; h < 2; ++h) {
@@ -1844,6 +1852,13 @@ __global__ void __launch_bounds__(64) k_chainq(ssw_chainx_args a)
 			}
 			wave_lds_fence();
 		}
+		};      /* strip_body */
+		if constexpr (!CAPTURE && R > 4) {
+			if (tail_mode && x.last && a.tail_R == 1) strip_body(IntTag<1>());
+			else if (tail_mode && x.last && a.tail_R == 2) strip_body(IntTag<2>());
+			else if (tail_mode && x.last && a.tail_R <= 4) strip_body(IntTag<4>());
+			else strip_body(IntTag<R>());
+		} else strip_body(IntTag<R>());
 		dev_fence();
 		if (tid == 0) dev_flag_set(my_flag);
 		}

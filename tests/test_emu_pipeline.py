@@ -475,3 +475,19 @@ def test_banded_reverse_pass_of_long_reads(ectx, monkeypatch):
         assert all((res[f] == res2[f]).all() for f in res.dtype.names) and (cig == cig2).all()
     finally:
         Q.free(); T.free()
+
+
+@pytest.mark.parametrize("env", [{}, {"SSW_GPU_NO_TAIL": "1"}, {"SSW_GPU_QUEUE": "strips"}])
+def test_long_queries_short_last_strip(ectx, env, monkeypatch):
+    """long queries whose rows are a few more than whole strips of 64 x 12: full strips and a LAST strip of 1, 2 or 4 rows per lane
+    (k_chainq's tail_R) instead of equal strips -- 777 / 784 rows: 768 + 64; 1640: 2 x 768 + 128; 1744: 2 x 768 + 256 -- next to
+    lengths that keep equal strips (1000, 1600), with begin positions and CIGARs, tiled target, both padding rules"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(84)
+    ref = random_ref(2600, 23, 4, 0.005)
+    lens = [777, 784, 1640, 1744, 1000, 1600, 779]
+    reads = make_reads(rng, ref, len(lens), lens, 4, sub=0.03, ins=0.01, dele=0.01, frac_random=0.0)
+    reads[6] = rng.integers(0, 4, size=779, dtype=np.int8)          # unrelated read: low scores, the 8-bit rule's column maxima decide
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
+    _run(ectx, reads[:4], [ref[:1900].copy()], dna_matrix(1, 3), 5, gapO=5, gapE=2, flag=0, maskLen=15)
