@@ -986,7 +986,7 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 					ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n; ta.vm = ti->vm;
 					ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = sstride; ta.soff = 0;
 					ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;     /* CIGAR slots are indexed by query */
-					ta.resume = d_resume; ta.unblocked = trace_unblocked; ta.waves = 1; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)ssw_shim_trace_lds_need(16, 1);
+					ta.resume = d_resume; ta.unblocked = trace_unblocked; ta.waves = 1; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)ssw_shim_trace_lds_need(64, 1);      /* (the round's scratch admits bands up to 48 at the longest read: all of them walk their rows in LDS) */
 					/* (the job list is already on the device when the caller's list IS the ids and one launch takes them all; need and band come
 					   back in one copy: need[0 .. cnt), band[cnt .. 2 cnt)) */
 					const int list_ready = ti->list_on_device && q0 == 0 && cnt_l == npend;
@@ -1742,7 +1742,7 @@ plan_again:
 						}
 						const int64_t lc = cols * (int64_t)(B->lanes * (B->tailR ? B->R * (B->strips - 1) + B->tailR : B->R * B->strips)) * 2 * np;
 						c->tm.fill_cells += lc;
-						char nm[64];
+						char nm[48];
 						if (!use_x) snprintf(nm, sizeof nm, "k_fill<%d,%s>", B->R, fa.form == 3 ? "frame" : "int16");
 						else if (B->lanes == 64 && B->tailR) snprintf(nm, sizeof nm, "k_chainq<%d,%s> x %d strips + 1 of %d", B->R, xform == 3 ? "frame" : "int16", B->strips - 1, B->tailR);
 						else if (B->lanes == 64) snprintf(nm, sizeof nm, "k_chainq<%d,%s> x %d strips", B->R, xform == 3 ? "frame" : "int16", B->strips);

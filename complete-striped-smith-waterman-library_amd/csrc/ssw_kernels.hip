@@ -2208,8 +2208,8 @@ SSW_HD u32 trace_ring_size(int band_width, int nthreads) { u32 r = 256; while (r
 SSW_HD int64_t trace_lds_need(int band_width, int nthreads)
 {
 	const int64_t rowbytes = (((int64_t)(band_width * 2 + 3) + 1) * 4 + 15) & ~(int64_t)15;
-	/* teams (several wavefronts per alignment) also keep one (h, F) slot per thread: trace_band_blocked */
-	return TRACE_LDS_FIXED + (nthreads > 64 ? 8192 : 0) + 3 * rowbytes + (int64_t)trace_ring_size(band_width, nthreads);
+	/* one (h, F) slot per thread: trace_band_blocked */
+	return TRACE_LDS_FIXED + 8 * (int64_t)nthreads + 3 * rowbytes + (int64_t)trace_ring_size(band_width, nthreads);
 }
 
 /* row storage: LDS offsets (L) or the scratch arrays in HBM */
@@ -2386,10 +2386,15 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
  * rows per alignment) were bound by barrier latency, not by arithmetic.
  * ------------------------------------------------------------------------------------------------ */
 #define TRACE_CPT_MAX 12
-#define TX_SLOT 1536u      /* blocked form: per-thread (h, F) of its last cell: 1024 threads x 8 bytes, placed after the fixed area */
-#define TRACE_LDS_FIXED_BLOCKED (TX_SLOT + 8192u)
+#define TX_SLOT 1536u      /* blocked form: per-thread (h, F) of its last cell: 8 bytes per thread, placed after the fixed area */
+SSW_HD u32 trace_lds_fixed_blocked(int nthreads) { return TX_SLOT + 8u * (u32)nthreads; }
 
-template <int NW>
+/* CPT = cells per thread (2, 4, 8 or 12: the smallest that covers the row; threads beyond the row idle).  Everything a thread reads of the
+   previous row -- H at up-1 .. up+CPT-1, E at up .. up+CPT-1, the target codes of its cells -- is requested in ONE batch with clamped
+   addresses and no branch, then the scores: two LDS round trips per row.  (The first form of this function walked its cells under
+   `if (k < cnt)`: hipcc made each an exec-masked block with its own three dependent round trips -- 12 x 3 per row, 7 us per row of a
+   4096-cell band, the whole traceback tail of config 4.)  NW = 1: the team is one wavefront, the barriers are LDS fences. */
+template <int NW, int CPT>
 SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, const int8_t* ref, const int8_t* read, int refLen, int readLen,
                                 int gapO, int gapE, int band_width, int n, int8_t* dir, u32 oring, u32 ring_mask, TraceBest& tb, int tid)
 {
@@ -2398,13 +2403,13 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 	const int m = gapO < gapE ? gapO : gapE;
 	const int lane = tid & 63, wv = tid >> 6;
 	const int width = band_width * 2 + 3, width_d = band_width * 2 + 1;
-	const int cpt = (width_d + NT - 1) / NT;          /* cells per thread (<= TRACE_CPT_MAX, checked by the caller) */
-	const int D = cpt * m;                            /* decay of the scan from one thread's last cell to the next one's */
+	const int D = CPT * m;                            /* decay of the scan from one thread's last cell to the next one's */
 	for (int j = tid; j < width; j += NT) { lds_st32(lds, oh0 + 4u * (u32)j, 0u); lds_st32(lds, oh1 + 4u * (u32)j, 0u); lds_st32(lds, oeb + 4u * (u32)j, (u32)NEG); }
 	int staged = 0;
 	int lb = tb.best, li = 0, lj = 0;
-	__syncthreads();
+	trace_sync<true, NW>();
 	int rd = read[0];
+	const int u0 = tid * CPT + 1;
 	for (int i = 0; i < readLen; ++i) {
 		const int rdn = i + 1 < readLen ? read[i + 1] : 0;
 		const int xi = i - band_width > 0 ? i - band_width : 0;
@@ -2421,32 +2426,48 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 			int64_t hi = (int64_t)i + band_width + 65; if (hi > refLen) hi = refLen;
 			for (int j = staged + tid; j < (int)hi; j += NT) lds_st8(lds, oring + ((u32)j & ring_mask), (u32)(unsigned char)ref[j]);
 			if ((int)hi > staged) staged = (int)hi;
-			__syncthreads();
+			trace_sync<true, NW>();
 		}
 		/* ---- this thread's cells: u0 .. u0 + cnt - 1 */
-		const int u0 = tid * cpt + 1;
-		const int cnt = u0 > ncell ? 0 : (ncell - u0 + 1 < cpt ? ncell - u0 + 1 : cpt);
-		int e[TRACE_CPT_MAX], dia[TRACE_CPT_MAX], sl[TRACE_CPT_MAX];
+		const int cnt = u0 > ncell ? 0 : (ncell - u0 + 1 < CPT ? ncell - u0 + 1 : CPT);
+		int e[CPT], dia[CPT], sl[CPT];
 		u32 deb = 0;                                   /* bit k: E of cell k was opened (direction 3) */
 		int run = NEG;
+		{
+			const int up0 = u0 + sft;
+			constexpr int KB = CPT < 4 ? CPT : 4;       /* cells per batch of loads (register budget: 128 per thread in a team of 1024) */
+			int hprev = (int)lds_ld32(lds, hp + 4u * (u32)(up0 - 1 < width - 1 ? up0 - 1 : width - 1));
 #pragma unroll
-		for (int k = 0; k < TRACE_CPT_MAX; ++k) {
-			e[k] = NEG; dia[k] = NEG; sl[k] = NEG;
-			if (k < cnt) {
-				const int u = u0 + k, up = u + sft, j = beg + u - 1;
-				const int open = i == 0 ? -gapO : (int)lds_ld32(lds, hp + 4u * (u32)up) - gapO;
-				const int ext = i == 0 ? NEG : (int)lds_ld32(lds, oeb + 4u * (u32)up) - gapE;
-				e[k] = open > ext ? open : ext;
-				if (open > ext) deb |= 1u << k;
-				const int sc = lds_ld8s(lds, (u32)((int)lds_ld8s(lds, oring + ((u32)j & ring_mask)) * n + rd));
-				dia[k] = (int)lds_ld32(lds, hp + 4u * (u32)(up - 1)) + sc;
-				int A = e[k] > dia[k] ? e[k] : dia[k]; if (A < 0) A = 0;
-				run = run - m > A ? run - m : A;         /* inclusive max-plus scan inside the thread */
-				sl[k] = run;
+			for (int kb = 0; kb < CPT; kb += KB) {
+				int hv[KB], ev[KB], cd[KB], sc[KB];
+#pragma unroll
+				for (int k = 0; k < KB; ++k) {
+					const int x = up0 + kb + k, xc = x < width - 1 ? x : width - 1;
+					hv[k] = (int)lds_ld32(lds, hp + 4u * (u32)xc);
+					ev[k] = (int)lds_ld32(lds, oeb + 4u * (u32)xc);
+					cd[k] = lds_ld8s(lds, oring + ((u32)(beg + u0 + kb + k - 1) & ring_mask));
+				}
+#pragma unroll
+				for (int k = 0; k < KB; ++k) sc[k] = lds_ld8s(lds, (u32)((kb + k < cnt ? cd[k] : 0) * n + rd));
+#pragma unroll
+				for (int k = 0; k < KB; ++k) {
+					const bool valid = kb + k < cnt;
+					const int open = i == 0 ? -gapO : hv[k] - gapO;
+					const int ext = i == 0 ? NEG : ev[k] - gapE;
+					const int ek = open > ext ? open : ext;
+					const int dk = hprev + sc[k];
+					hprev = hv[k];
+					int A = ek > dk ? ek : dk; if (A < 0) A = 0;
+					const int rn = run - m > A ? run - m : A;      /* inclusive max-plus scan inside the thread */
+					run = valid ? rn : run;
+					e[kb + k] = valid ? ek : NEG; dia[kb + k] = valid ? dk : NEG; sl[kb + k] = valid ? rn : NEG;
+					deb |= (valid && open > ext) ? 1u << (kb + k) : 0u;
+				}
+				sched_fence();
 			}
 		}
 		/* ---- scan of the threads' totals: V = S at the thread's last cell (threads without cells carry -inf: nothing follows them) */
-		int V = cnt == cpt ? run : (cnt > 0 ? run - (cpt - cnt) * m : NEG);      /* (a partial last thread: value as if decayed to a full block's end) */
+		int V = cnt == CPT ? run : (cnt > 0 ? run - (CPT - cnt) * m : NEG);      /* (a partial last thread: value as if decayed to a full block's end) */
 		{
 			int o;
 			o = (int)xl_row_shr_keep<1>((u32)NEG, (u32)V) - D; V = o > V ? o : V;
@@ -2456,10 +2477,10 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 			o = (int)xl_row_bcast15_keep((u32)NEG, (u32)V) - ((lane & 15) + 1) * D; V = o > V ? o : V;
 			o = (int)xl_row_bcast31_keep((u32)NEG, (u32)V) - ((lane & 31) + 1) * D; V = o > V ? o : V;
 		}
-		if (lane == 63) lds_st32(lds, TX_T + 4u * (u32)wv, (u32)V);
-		__syncthreads();                                /* barrier 1: wave totals; every phase-1 read of the previous row is done */
 		int Pw = wv == 0 ? 0 : NEG;                   /* S at the cell before this wavefront's first one; cell 0 of the row holds h_c[0] = 0 */
-		{
+		if (NW > 1) {
+			if (lane == 63) lds_st32(lds, TX_T + 4u * (u32)wv, (u32)V);
+			__syncthreads();                                /* barrier 1: wave totals; every phase-1 read of the previous row is done */
 			int t = lane < NW ? (int)lds_ld32(lds, TX_T + 4u * (u32)lane) : NEG, o;
 			if (lane == 0) { const int z = 0 - 64 * D; t = z > t ? z : t; }      /* the row's cell 0 decayed to the end of wavefront 0 */
 			o = (int)xl_row_shr_keep<1>((u32)NEG, (u32)t) - 64 * D; t = o > t ? o : t;
@@ -2469,40 +2490,42 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 				o = (int)xl_row_shr_keep<8>((u32)NEG, (u32)t) - 512 * D; t = o > t ? o : t;
 			}
 			if (wv > 0) Pw = (int)xl_readlane((u32)t, wv - 1);
-		}
+		} else wave_lds_fence();                          /* (one wavefront: its reads of the previous row are issued before the writes below) */
 		{ const int sp = Pw - (lane + 1) * D; V = sp > V ? sp : V; }
 		const int P = (int)xl_wave_shr1_keep((u32)Pw, (u32)V);      /* S at the cell before this thread's first one */
 		/* ---- finish the cells */
 		int hl = 0, Fl = NEG;                          /* h and F of the cell to the left (cell 0: h_c[0] = 0, no F); a thread's first cell learns them after barrier 2 */
-		int h_first = 0, F_first = NEG; u32 byte_first = 0;
+		u32 byte_first = 0;
 		int Sprev = P;
 #pragma unroll
-		for (int k = 0; k < TRACE_CPT_MAX; ++k) {
-			if (k < cnt) {
-				const int u = u0 + k, j = beg + u - 1;
-				const int F = Sprev - gapO;
-				const int sfin = P - (k + 1) * m > sl[k] ? P - (k + 1) * m : sl[k];
-				Sprev = sfin;
-				const int e1 = e[k] > 0 ? e[k] : 0, f1 = F > 0 ? F : 0;
-				const int gap = e1 > f1 ? e1 : f1;
-				const int h = gap > dia[k] ? gap : dia[k];
-				const int de3 = (int)((deb >> k) & 1u);
-				if (k == 0) { h_first = h; F_first = F; byte_first = (u32)de3 | (gap <= dia[k] ? 4u : (e1 > f1 ? (u32)((2 + de3) << 2) : 0x80u)); }     /* 0x80: H's source is F, direction known after barrier 2 */
-				else {
-					const int df5 = (hl - gapO) > (Fl - gapE) ? 1 : 0;
-					const int dh = gap <= dia[k] ? 1 : (e1 > f1 ? 2 + de3 : 4 + df5);
-					line[u - 1] = (int8_t)(de3 | (df5 << 1) | (dh << 2));
-				}
+		for (int k = 0; k < CPT; ++k) {
+			const int F = Sprev - gapO;
+			const int sfin = P - (k + 1) * m > sl[k] ? P - (k + 1) * m : sl[k];
+			Sprev = sfin;
+			const int e1 = e[k] > 0 ? e[k] : 0, f1 = F > 0 ? F : 0;
+			const int gap = e1 > f1 ? e1 : f1;
+			const int h = gap > dia[k] ? gap : dia[k];
+			const int de3 = (int)((deb >> k) & 1u);
+			u32 byte = 0;
+			if (k == 0) byte_first = (u32)de3 | (gap <= dia[k] ? 4u : (e1 > f1 ? (u32)((2 + de3) << 2) : 0x80u));     /* 0x80: H's source is F, direction known after barrier 2 */
+			else {
+				const int df5 = (hl - gapO) > (Fl - gapE) ? 1 : 0;
+				const int dh = gap <= dia[k] ? 1 : (e1 > f1 ? 2 + de3 : 4 + df5);
+				byte = (u32)(de3 | (df5 << 1) | (dh << 2));
+			}
+			if (k < cnt) {      /* (stores and moves only: nothing in here waits) */
+				const int u = u0 + k;
+				if (k > 0) line[u - 1] = (int8_t)byte;
 				/* the row as the next one will read it: its forced index holds 0 / -inf whatever was computed there */
 				lds_st32(lds, oeb + 4u * (u32)u, (u32)(u == edgen ? NEG : e[k]));
 				lds_st32(lds, hcur + 4u * (u32)u, (u32)(u == edgen ? 0 : h));
-				if (h > lb) { lb = h; li = i; lj = j; }
+				if (h > lb) { lb = h; li = i; lj = beg + u - 1; }
 				hl = h; Fl = F;
 			}
 		}
 		if (cnt > 0) { lds_st32(lds, TX_SLOT + 8u * (u32)tid, (u32)hl); lds_st32(lds, TX_SLOT + 8u * (u32)tid + 4, (u32)Fl); }
 		if (tid == 0 && edgen > ncell) { lds_st32(lds, oeb + 4u * (u32)edgen, (u32)NEG); lds_st32(lds, hcur + 4u * (u32)edgen, 0u); }
-		__syncthreads();                                /* barrier 2: the row is written; neighbours' last cells are in the slots */
+		trace_sync<true, NW>();                         /* barrier 2: the row is written; neighbours' last cells are in the slots */
 		if (cnt > 0) {
 			int hleft = 0, Fleft = NEG;
 			if (tid > 0) { hleft = (int)lds_ld32(lds, TX_SLOT + 8u * (u32)(tid - 1)); Fleft = (int)lds_ld32(lds, TX_SLOT + 8u * (u32)(tid - 1) + 4); }
@@ -2510,7 +2533,6 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 			const u32 b = (byte_first & 0x80u) ? ((byte_first & 1u) | ((u32)(4 + df5) << 2)) : byte_first;
 			line[u0 - 1] = (int8_t)(b | ((u32)df5 << 1));
 		}
-		(void)h_first; (void)F_first;
 		rd = rdn;
 	}
 	/* the scalar walk's best cell: highest h above the carried best; among equals the first in row-major order */
@@ -2520,14 +2542,16 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 		const int oh = wave_bcast(lb, lane ^ d), oi = wave_bcast(li, lane ^ d), oj = wave_bcast(lj, lane ^ d);
 		if (oh > lb || (oh == lb && (oi < li || (oi == li && oj < lj)))) { lb = oh; li = oi; lj = oj; }
 	}
-	__syncthreads();
-	if (lane == 0) { lds_st32(lds, TX_BEST + 12u * (u32)wv, (u32)lb); lds_st32(lds, TX_BEST + 12u * (u32)wv + 4, (u32)li); lds_st32(lds, TX_BEST + 12u * (u32)wv + 8, (u32)lj); }
-	__syncthreads();
-	for (int v = 0; v < NW; ++v) {
-		const int oh = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v), oi = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v + 4), oj = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v + 8);
-		if (oh > lb || (oh == lb && (oi < li || (oi == li && oj < lj)))) { lb = oh; li = oi; lj = oj; }
-	}
-	__syncthreads();
+	if (NW > 1) {
+		__syncthreads();
+		if (lane == 0) { lds_st32(lds, TX_BEST + 12u * (u32)wv, (u32)lb); lds_st32(lds, TX_BEST + 12u * (u32)wv + 4, (u32)li); lds_st32(lds, TX_BEST + 12u * (u32)wv + 8, (u32)lj); }
+		__syncthreads();
+		for (int v = 0; v < NW; ++v) {
+			const int oh = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v), oi = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v + 4), oj = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v + 8);
+			if (oh > lb || (oh == lb && (oi < li || (oi == li && oj < lj)))) { lb = oh; li = oi; lj = oj; }
+		}
+		__syncthreads();
+	} else wave_lds_fence();
 	if (lb > tb.best) { tb.best = lb; tb.i = li; tb.j = lj; }
 }
 
@@ -2558,9 +2582,17 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 		const int64_t want = 3 * rowbytes + (int64_t)width_d * readLen + 16;
 		if (want > cap) { *need = want; *band_io = band_width; return -2; }
 		dir = (int8_t*)(scratch + 3 * rowbytes);
-		if (NW > 1 && trace_lds_need(band_width, 64 * NW) <= lds_cap && (width_d + 64 * NW - 1) / (64 * NW) <= TRACE_CPT_MAX && !trace_unblocked) {
-			const u32 oh0 = TRACE_LDS_FIXED_BLOCKED, oh1 = oh0 + (u32)rowbytes, oeb = oh1 + (u32)rowbytes, oring = oeb + (u32)rowbytes;
-			trace_band_blocked<NW>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, trace_ring_size(band_width, 64 * NW) - 1, tb, tid);
+		/* (8 and 12 cells per thread only for the teams of 16 wavefronts: the register budget of the smaller teams' kernels stays at 128 either way) */
+		if (trace_lds_need(band_width, 64 * NW) <= lds_cap && (width_d + 64 * NW - 1) / (64 * NW) <= (NW >= 16 ? TRACE_CPT_MAX : 4) && !trace_unblocked) {
+			const u32 oh0 = trace_lds_fixed_blocked(64 * NW), oh1 = oh0 + (u32)rowbytes, oeb = oh1 + (u32)rowbytes, oring = oeb + (u32)rowbytes;
+			const u32 rmask = trace_ring_size(band_width, 64 * NW) - 1;
+			const int cpt = (width_d + 64 * NW - 1) / (64 * NW);
+			if (cpt <= 2) trace_band_blocked<NW, 2>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
+			else if (cpt <= 4) trace_band_blocked<NW, 4>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
+			else if constexpr (NW >= 16) {
+				if (cpt <= 8) trace_band_blocked<NW, 8>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
+				else trace_band_blocked<NW, 12>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
+			}
 		} else
 		if (trace_lds_need(band_width, 64 * NW) <= lds_cap) {
 			TraceRows<true> R; R.lds = lds; R.ohb = TRACE_LDS_FIXED; R.oeb = TRACE_LDS_FIXED + (u32)rowbytes; R.ohc = TRACE_LDS_FIXED + 2 * (u32)rowbytes;
@@ -2612,7 +2644,7 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 /* one team of NW wavefronts (one workgroup) per alignment; same contract as k_trace.  a.resume[q] = {band, best, best_i,
    best_j, stage} carries an alignment that ran out of scratch to the next negotiation round. */
 template <int NW>
-__global__ void __launch_bounds__(64 * NW) k_trace_wave(ssw_trace_args a)
+__global__ void __launch_bounds__(64 * NW) SSW_WAVES_PER_EU(4, 8) k_trace_wave(ssw_trace_args a)
 {
 	SSW_DYN_LDS(lds);
 	const int job = (int)blockIdx.x, tid = (int)threadIdx.x;

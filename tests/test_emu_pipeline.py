@@ -358,7 +358,7 @@ def team_traceback_cases(scale):
     return (c(reads), ref), (c(reads2), short)
 
 
-@pytest.mark.parametrize("teams,blocked", [("4", "1"), ("16", "1"), ("4", "0")])
+@pytest.mark.parametrize("teams,blocked", [("4", "1"), ("16", "1"), ("4", "0"), ("1", "1"), ("1", "0")])
 def test_team_traceback_many_cells_per_thread(ectx, teams, blocked, monkeypatch):
     monkeypatch.setenv("SSW_GPU_TRACE_WAVE", "1")
     monkeypatch.setenv("SSW_GPU_TRACE_WAVES", teams)

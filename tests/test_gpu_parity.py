@@ -369,7 +369,7 @@ def test_wide_alphabets_route_window_passes_by_lds_need(gpu_ctx, n):
         _run(gpu_ctx, reads, [ref], mat, n, 9, 2, flag=flag)
 
 
-@pytest.mark.parametrize("env", [{}, {"SSW_GPU_TRACE_WAVES": "4"}, {"SSW_GPU_TRACE_BLOCKED": "0"}])
+@pytest.mark.parametrize("env", [{}, {"SSW_GPU_TRACE_WAVES": "4"}, {"SSW_GPU_TRACE_BLOCKED": "0"}, {"SSW_GPU_TRACE_WAVES": "1"}])
 def test_team_traceback_many_cells_per_thread(gpu_ctx, env, monkeypatch):
     """wide bands on traceback teams: several cells per thread, two barriers per row (trace_band_blocked) -- 10-kb-scale reads with
     kilobase insertions / deletions, an unrelated read, band covering the whole target; and the one-cell-per-thread form as control"""
