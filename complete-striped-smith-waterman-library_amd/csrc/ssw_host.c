@@ -944,7 +944,7 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 		int32_t* d_need = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * 2 * (size_t)nq);
 		int32_t* d_resume = (int32_t*)ensure(c, &c->tresume, sizeof(int32_t) * 8 * (size_t)nq);
 		if (!d_cig || !d_need || !d_resume) return -1;      /* (the teams' resume state is zeroed before the first team launch) */
-		int64_t sstride = ((int64_t)3 * (2 * 16 + 8) * 4 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;
+		int64_t sstride = ((int64_t)3 * 720 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;      /* three rows of a band of 48 (padded: ssw_kernels.hip trace_rowbytes) + 99 direction bytes per row */
 		/* long reads: one wavefront per alignment (wide bands, 10^4 rows); short reads: one thread per alignment */
 		/* Which kernel walks a band.  Rounds 1-3 gave short reads ONE THREAD per alignment (k_trace) and only reads above 1 kb a TEAM of wavefronts
 		   (k_trace_wave: band rows in LDS, a row's cells in parallel, direction bytes packed).  Measured in round 4, the team kernel wins
@@ -1038,9 +1038,10 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 								const int32_t b2 = pend[g1].key > (1 << 20) ? (1 << 21) : 2 * pend[g1].key;
 								int wv = b2 <= 96 ? 1 : b2 <= 256 ? 4 : 16;
 								if (trace_waves_env > 0) wv = trace_waves_env;
-								/* few LDS classes (16 KiB, 64 KiB, 128 KiB): only a handful of hardware queues run side by side */
+								/* few LDS classes (16, 64, 128, 160 KiB): only a handful of hardware queues run side by side */
 								int64_t l = ssw_shim_trace_lds_need(b2, wv), cls = 16384;
 								while (cls < l && cls < 131072) cls <<= (cls == 16384 ? 2 : 1);
+								if (cls < l && l <= SSW_LDS_LIMIT) cls = SSW_LDS_LIMIT;      /* (the widest bands that still fit a compute unit's LDS) */
 								if (g1 > g0 && (cls != lds_l || wv != waves_l)) break;     /* pending alignments are sorted by band: classes are contiguous */
 								lds_l = cls; waves_l = wv;
 							}

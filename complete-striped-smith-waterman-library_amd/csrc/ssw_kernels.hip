@@ -2205,9 +2205,25 @@ SSW_DEV int wave_bcast(int v, int src) { return (int)xl_shfl((u32)v, src); }
 /* LDS of the wavefront / workgroup traceback: [matrix 1024][exchange 512][h_b][e_b][h_c][target window ring] */
 #define TRACE_LDS_FIXED 1536u
 SSW_HD u32 trace_ring_size(int band_width, int nthreads) { u32 r = 256; while (r < (u32)(2 * band_width + 2 * nthreads + 2)) r <<= 1; return r; }
+/* cells per thread of trace_band_blocked for a row of width_d cells on nthreads threads (0: the row takes the other form) */
+SSW_HD int trace_cpt_class(int width_d, int nthreads)
+{
+	const int cpt = (width_d + nthreads - 1) / nthreads;
+	return cpt <= 2 ? 2 : cpt <= 4 ? 4 : nthreads < 1024 ? 0 : cpt <= 8 ? 8 : cpt <= 12 ? 12 : 0;
+}
+/* One band row in LDS.  trace_band_blocked keeps a thread's C cells C + 1 entries apart (entry of cell u >= 1: u + 1 + (u - 1) / C; cell 0
+   at entry 0): the threads of a wavefront read and write their k-th cells at a stride of C + 1 dwords -- odd, hence one LDS bank each; at a
+   stride of C = 8 dwords 32 lanes share four banks and every access costs eight LDS cycles (which, not the arithmetic, bounded a row).
+   + 12 cells: a thread reads up to 11 cells past its last one. */
+SSW_HD int64_t trace_rowbytes(int band_width, int nthreads)
+{
+	const int64_t cells = (int64_t)(band_width * 2 + 3) + 1 + 12;
+	const int C = trace_cpt_class(band_width * 2 + 1, nthreads);
+	return ((cells + (C > 0 ? cells / C + 3 : 0)) * 4 + 15) & ~(int64_t)15;
+}
 SSW_HD int64_t trace_lds_need(int band_width, int nthreads)
 {
-	const int64_t rowbytes = (((int64_t)(band_width * 2 + 3) + 1) * 4 + 15) & ~(int64_t)15;
+	const int64_t rowbytes = trace_rowbytes(band_width, nthreads);
 	/* one (h, F) slot per thread: trace_band_blocked */
 	return TRACE_LDS_FIXED + 8 * (int64_t)nthreads + 3 * rowbytes + (int64_t)trace_ring_size(band_width, nthreads);
 }
@@ -2404,7 +2420,12 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 	const int lane = tid & 63, wv = tid >> 6;
 	const int width = band_width * 2 + 3, width_d = band_width * 2 + 1;
 	const int D = CPT * m;                            /* decay of the scan from one thread's last cell to the next one's */
-	for (int j = tid; j < width; j += NT) { lds_st32(lds, oh0 + 4u * (u32)j, 0u); lds_st32(lds, oh1 + 4u * (u32)j, 0u); lds_st32(lds, oeb + 4u * (u32)j, (u32)NEG); }
+	/* rows start as the reference's do before row 0 (H = 0; E = -inf makes `open` win: ssw.c:644-646), padding included; the target ring
+	   starts as code 0, so that a cell past the row's end looks up a real score (nothing of it is kept) */
+	constexpr u32 BS = CPT + 1;                        /* entries between two threads' cells (see trace_rowbytes) */
+	auto entry = [](int u) -> u32 { return u <= 0 ? 0u : (u32)(u + 1 + (u - 1) / CPT); };
+	for (u32 j = (u32)tid; j <= entry(width + 12); j += NT) { lds_st32(lds, oh0 + 4u * j, 0u); lds_st32(lds, oh1 + 4u * j, 0u); lds_st32(lds, oeb + 4u * j, (u32)NEG); }
+	for (u32 j = 4u * (u32)tid; j <= ring_mask; j += 4u * NT) lds_st32(lds, oring + j, 0u);
 	int staged = 0;
 	int lb = tb.best, li = 0, lj = 0;
 	trace_sync<true, NW>();
@@ -2434,40 +2455,45 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 		u32 deb = 0;                                   /* bit k: E of cell k was opened (direction 3) */
 		int run = NEG;
 		{
-			const int up0 = u0 + sft;
+			/* Cells past the row's end (k >= cnt) are evaluated like the others -- on the rows' padding or, for a thread with no cell at all, on
+			   the row's first entries -- with A forced to -inf: the scan then decays over them exactly as the total V wants, and nothing else of
+			   them is stored.  Row 0 needs no case of its own: the rows start as H = 0 / E = -inf. */
+			/* cell up0 - 1 + c of the previous row, c = 0 .. CPT + 1 (up0 = u0 + sft = tid CPT + 1 + sft): entry tid (CPT + 1) + off(c + sft), off(0) = 0,
+			   off(x) = x + 1 for 1 <= x <= CPT, off(CPT + 1) = CPT + 3 -- uniform offsets on a per-thread base */
+			const u32 base4 = cnt > 0 ? 4u * BS * (u32)tid : 0u;
+			auto off4 = [](int x) -> u32 { return 4u * (u32)(x <= 0 ? 0 : x <= CPT ? x + 1 : x + 2); };
 			constexpr int KB = CPT < 4 ? CPT : 4;       /* cells per batch of loads (register budget: 128 per thread in a team of 1024) */
-			int hprev = (int)lds_ld32(lds, hp + 4u * (u32)(up0 - 1 < width - 1 ? up0 - 1 : width - 1));
+			int hprev = (int)lds_ld32(lds, hp + base4 + off4(sft));
 #pragma unroll
 			for (int kb = 0; kb < CPT; kb += KB) {
 				int hv[KB], ev[KB], cd[KB], sc[KB];
 #pragma unroll
 				for (int k = 0; k < KB; ++k) {
-					const int x = up0 + kb + k, xc = x < width - 1 ? x : width - 1;
-					hv[k] = (int)lds_ld32(lds, hp + 4u * (u32)xc);
-					ev[k] = (int)lds_ld32(lds, oeb + 4u * (u32)xc);
+					const u32 x4 = base4 + off4(kb + k + 1 + sft);
+					hv[k] = (int)lds_ld32(lds, hp + x4);
+					ev[k] = (int)lds_ld32(lds, oeb + x4);
 					cd[k] = lds_ld8s(lds, oring + ((u32)(beg + u0 + kb + k - 1) & ring_mask));
 				}
 #pragma unroll
-				for (int k = 0; k < KB; ++k) sc[k] = lds_ld8s(lds, (u32)((kb + k < cnt ? cd[k] : 0) * n + rd));
+				for (int k = 0; k < KB; ++k) sc[k] = lds_ld8s(lds, (u32)(cd[k] * n + rd));
 #pragma unroll
 				for (int k = 0; k < KB; ++k) {
-					const bool valid = kb + k < cnt;
-					const int open = i == 0 ? -gapO : hv[k] - gapO;
-					const int ext = i == 0 ? NEG : ev[k] - gapE;
+					const int open = hv[k] - gapO;
+					const int ext = ev[k] - gapE;
 					const int ek = open > ext ? open : ext;
 					const int dk = hprev + sc[k];
 					hprev = hv[k];
 					int A = ek > dk ? ek : dk; if (A < 0) A = 0;
-					const int rn = run - m > A ? run - m : A;      /* inclusive max-plus scan inside the thread */
-					run = valid ? rn : run;
-					e[kb + k] = valid ? ek : NEG; dia[kb + k] = valid ? dk : NEG; sl[kb + k] = valid ? rn : NEG;
-					deb |= (valid && open > ext) ? 1u << (kb + k) : 0u;
+					if (kb + k >= cnt) A = NEG;
+					run = run - m > A ? run - m : A;               /* inclusive max-plus scan inside the thread */
+					e[kb + k] = ek; dia[kb + k] = dk; sl[kb + k] = run;
+					deb |= open > ext ? 1u << (kb + k) : 0u;
 				}
 				sched_fence();
 			}
 		}
 		/* ---- scan of the threads' totals: V = S at the thread's last cell (threads without cells carry -inf: nothing follows them) */
-		int V = cnt == CPT ? run : (cnt > 0 ? run - (CPT - cnt) * m : NEG);      /* (a partial last thread: value as if decayed to a full block's end) */
+		int V = cnt > 0 ? run : NEG;                   /* (a partial last thread: decayed to a full block's end by its cells past the row) */
 		{
 			int o;
 			o = (int)xl_row_shr_keep<1>((u32)NEG, (u32)V) - D; V = o > V ? o : V;
@@ -2497,6 +2523,7 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 		int hl = 0, Fl = NEG;                          /* h and F of the cell to the left (cell 0: h_c[0] = 0, no F); a thread's first cell learns them after barrier 2 */
 		u32 byte_first = 0;
 		int Sprev = P;
+		int hm = 0;                                    /* highest h of this thread's cells in this row */
 #pragma unroll
 		for (int k = 0; k < CPT; ++k) {
 			const int F = Sprev - gapO;
@@ -2516,19 +2543,25 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 			if (k < cnt) {      /* (stores and moves only: nothing in here waits) */
 				const int u = u0 + k;
 				if (k > 0) line[u - 1] = (int8_t)byte;
-				/* the row as the next one will read it: its forced index holds 0 / -inf whatever was computed there */
-				lds_st32(lds, oeb + 4u * (u32)u, (u32)(u == edgen ? NEG : e[k]));
-				lds_st32(lds, hcur + 4u * (u32)u, (u32)(u == edgen ? 0 : h));
-				if (h > lb) { lb = h; li = i; lj = beg + u - 1; }
+				lds_st32(lds, oeb + 4u * (BS * (u32)tid + (u32)k + 2u), (u32)e[k]);      /* = entry(u) */
+				lds_st32(lds, hcur + 4u * (BS * (u32)tid + (u32)k + 2u), (u32)h);
+				hm = h > hm ? h : hm;
 				hl = h; Fl = F;
 			}
 		}
-		if (cnt > 0) { lds_st32(lds, TX_SLOT + 8u * (u32)tid, (u32)hl); lds_st32(lds, TX_SLOT + 8u * (u32)tid + 4, (u32)Fl); }
-		if (tid == 0 && edgen > ncell) { lds_st32(lds, oeb + 4u * (u32)edgen, (u32)NEG); lds_st32(lds, hcur + 4u * (u32)edgen, 0u); }
+		if (hm > lb) {      /* a new best cell (rare: bests of narrower bands carry over): the first of this thread's cells that holds it */
+			int kk = -1;
+			for (int k = 0; k < cnt; ++k) if (kk < 0 && (int)lds_ld32(lds, hcur + 4u * (BS * (u32)tid + (u32)k + 2u)) == hm) kk = k;
+			lb = hm; li = i; lj = beg + u0 + kk - 1;
+		}
+		/* the row as the next one will read it: its forced index holds 0 / -inf whatever was computed there (after the lookup above) */
+		if (edgen >= u0 && edgen < u0 + cnt) { lds_st32(lds, oeb + 4u * entry(edgen), (u32)NEG); lds_st32(lds, hcur + 4u * entry(edgen), 0u); }
+		if (cnt > 0) { lds_st32(lds, TX_SLOT + 4u * (u32)tid, (u32)hl); lds_st32(lds, TX_SLOT + 4u * (u32)(NT + tid), (u32)Fl); }
+		if (tid == 0 && edgen > ncell) { lds_st32(lds, oeb + 4u * entry(edgen), (u32)NEG); lds_st32(lds, hcur + 4u * entry(edgen), 0u); }
 		trace_sync<true, NW>();                         /* barrier 2: the row is written; neighbours' last cells are in the slots */
 		if (cnt > 0) {
 			int hleft = 0, Fleft = NEG;
-			if (tid > 0) { hleft = (int)lds_ld32(lds, TX_SLOT + 8u * (u32)(tid - 1)); Fleft = (int)lds_ld32(lds, TX_SLOT + 8u * (u32)(tid - 1) + 4); }
+			if (tid > 0) { hleft = (int)lds_ld32(lds, TX_SLOT + 4u * (u32)(tid - 1)); Fleft = (int)lds_ld32(lds, TX_SLOT + 4u * (u32)(NT + tid - 1)); }
 			const int df5 = (hleft - gapO) > (Fleft - gapE) ? 1 : 0;
 			const u32 b = (byte_first & 0x80u) ? ((byte_first & 1u) | ((u32)(4 + df5) << 2)) : byte_first;
 			line[u0 - 1] = (int8_t)(b | ((u32)df5 << 1));
@@ -2578,15 +2611,15 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 	int8_t* dir;
 	do {
 		const int width = band_width * 2 + 3; width_d = band_width * 2 + 1;
-		const int64_t rowbytes = (((int64_t)width + 1) * 4 + 15) & ~(int64_t)15;
+		const int64_t rowbytes = trace_rowbytes(band_width, 64 * NW);
 		const int64_t want = 3 * rowbytes + (int64_t)width_d * readLen + 16;
 		if (want > cap) { *need = want; *band_io = band_width; return -2; }
 		dir = (int8_t*)(scratch + 3 * rowbytes);
 		/* (8 and 12 cells per thread only for the teams of 16 wavefronts: the register budget of the smaller teams' kernels stays at 128 either way) */
-		if (trace_lds_need(band_width, 64 * NW) <= lds_cap && (width_d + 64 * NW - 1) / (64 * NW) <= (NW >= 16 ? TRACE_CPT_MAX : 4) && !trace_unblocked) {
+		const int cpt = trace_cpt_class(width_d, 64 * NW);
+		if (trace_lds_need(band_width, 64 * NW) <= lds_cap && cpt > 0 && !trace_unblocked && (NW > 1 || width_d > 64)) {      /* (one wavefront walks a row of up to 64 cells as one chunk of the other form) */
 			const u32 oh0 = trace_lds_fixed_blocked(64 * NW), oh1 = oh0 + (u32)rowbytes, oeb = oh1 + (u32)rowbytes, oring = oeb + (u32)rowbytes;
 			const u32 rmask = trace_ring_size(band_width, 64 * NW) - 1;
-			const int cpt = (width_d + 64 * NW - 1) / (64 * NW);
 			if (cpt <= 2) trace_band_blocked<NW, 2>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
 			else if (cpt <= 4) trace_band_blocked<NW, 4>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
 			else if constexpr (NW >= 16) {
