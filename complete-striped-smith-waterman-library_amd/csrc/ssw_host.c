@@ -1060,7 +1060,10 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 					/* widest bands first: they take longest, and only a few hardware queues run side by side */
 					for (int gx = 0; gx < ngrp && trace_ok; ++gx) {
 						const int gi = ngrp - 1 - gx;
-						void* st = gx == 0 ? c->stream : c->tstream[(gx - 1) % SSW_TSTREAMS];
+						/* (the runtime hands the context's streams to FOUR hardware queues in creation order -- main 1, second 2, side streams 3 4 4 3 2 1 --
+						   and launches on one queue run one after the other: the first four launches of a round go to four different queues) */
+						static const int side_of[SSW_TSTREAMS] = { 0, 1, 4, 2, 3, 5 };
+						void* st = gx == 0 ? c->stream : c->tstream[side_of[(gx - 1) % SSW_TSTREAMS]];
 						const int32_t cnt_l = grp[gi].g1 - grp[gi].g0;
 						ssw_trace_args ta;
 						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist + grp[gi].g0; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n; ta.vm = ti->vm;
