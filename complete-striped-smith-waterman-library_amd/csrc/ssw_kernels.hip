@@ -2677,7 +2677,7 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 /* one team of NW wavefronts (one workgroup) per alignment; same contract as k_trace.  a.resume[q] = {band, best, best_i,
    best_j, stage} carries an alignment that ran out of scratch to the next negotiation round. */
 template <int NW>
-__global__ void __launch_bounds__(64 * NW) SSW_WAVES_PER_EU(4, 8) k_trace_wave(ssw_trace_args a)
+__global__ void __launch_bounds__(64 * NW) SSW_WAVES_PER_EU(NW == 1 ? 5 : 4, 8) k_trace_wave(ssw_trace_args a)
 {
 	SSW_DYN_LDS(lds);
 	const int job = (int)blockIdx.x, tid = (int)threadIdx.x;

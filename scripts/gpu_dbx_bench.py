@@ -69,6 +69,7 @@ same = all((r_loop[f] == res2[f][:, :sl]).all() for f in ("score1", "score2", "r
 out["per_target_loop_before_round4"]["same_records_as_one_call"] = bool(same)
 # all pairs through the reverse pass and the traceback (filters 0) on a slice: the throughput of those phases, not a use case
 sl2 = min(nt, 256)
+ctx.align_batch(Q, T, mat, 24, 3, 1, 2, 0, 0, -1, 2, target_first=0, target_count=sl2)      # (allocation warm-up: the traceback of 5e5 wide-band alignments takes ~100 GB of scratch once)
 t0 = time.perf_counter()
 r_all, c_all = ctx.align_batch(Q, T, mat, 24, 3, 1, 2, 0, 0, -1, 2, target_first=0, target_count=sl2)
 dt = time.perf_counter() - t0
