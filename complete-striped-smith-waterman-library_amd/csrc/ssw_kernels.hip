@@ -2209,6 +2209,7 @@ SSW_HD u32 trace_ring_size(int band_width, int nthreads) { u32 r = 256; while (r
 SSW_HD int trace_cpt_class(int width_d, int nthreads)
 {
 	const int cpt = (width_d + nthreads - 1) / nthreads;
+	if (cpt <= 1 && nthreads == 64) return 1;        /* one wavefront, one cell per lane (rows need no padding: the stride between lanes is one dword) */
 	return cpt <= 2 ? 2 : cpt <= 4 ? 4 : nthreads < 1024 ? 0 : cpt <= 8 ? 8 : cpt <= 12 ? 12 : 0;
 }
 /* One band row in LDS.  trace_band_blocked keeps a thread's C cells C + 1 entries apart (entry of cell u >= 1: u + 1 + (u - 1) / C; cell 0
@@ -2219,7 +2220,7 @@ SSW_HD int64_t trace_rowbytes(int band_width, int nthreads)
 {
 	const int64_t cells = (int64_t)(band_width * 2 + 3) + 1 + 12;
 	const int C = trace_cpt_class(band_width * 2 + 1, nthreads);
-	return ((cells + (C > 0 ? cells / C + 3 : 0)) * 4 + 15) & ~(int64_t)15;
+	return ((cells + (C > 1 ? cells / C + 3 : 0)) * 4 + 15) & ~(int64_t)15;
 }
 SSW_HD int64_t trace_lds_need(int band_width, int nthreads)
 {
@@ -2422,8 +2423,9 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 	const int D = CPT * m;                            /* decay of the scan from one thread's last cell to the next one's */
 	/* rows start as the reference's do before row 0 (H = 0; E = -inf makes `open` win: ssw.c:644-646), padding included; the target ring
 	   starts as code 0, so that a cell past the row's end looks up a real score (nothing of it is kept) */
-	constexpr u32 BS = CPT + 1;                        /* entries between two threads' cells (see trace_rowbytes) */
-	auto entry = [](int u) -> u32 { return u <= 0 ? 0u : (u32)(u + 1 + (u - 1) / CPT); };
+	constexpr bool PAD = CPT > 1;
+	constexpr u32 BS = PAD ? CPT + 1 : 1;              /* entries between two threads' cells (see trace_rowbytes) */
+	auto entry = [](int u) -> u32 { return u <= 0 ? 0u : PAD ? (u32)(u + 1 + (u - 1) / CPT) : (u32)u; };
 	for (u32 j = (u32)tid; j <= entry(width + 12); j += NT) { lds_st32(lds, oh0 + 4u * j, 0u); lds_st32(lds, oh1 + 4u * j, 0u); lds_st32(lds, oeb + 4u * j, (u32)NEG); }
 	for (u32 j = 4u * (u32)tid; j <= ring_mask; j += 4u * NT) lds_st32(lds, oring + j, 0u);
 	int staged = 0;
@@ -2461,7 +2463,7 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 			/* cell up0 - 1 + c of the previous row, c = 0 .. CPT + 1 (up0 = u0 + sft = tid CPT + 1 + sft): entry tid (CPT + 1) + off(c + sft), off(0) = 0,
 			   off(x) = x + 1 for 1 <= x <= CPT, off(CPT + 1) = CPT + 3 -- uniform offsets on a per-thread base */
 			const u32 base4 = cnt > 0 ? 4u * BS * (u32)tid : 0u;
-			auto off4 = [](int x) -> u32 { return 4u * (u32)(x <= 0 ? 0 : x <= CPT ? x + 1 : x + 2); };
+			auto off4 = [](int x) -> u32 { return 4u * (u32)(x <= 0 ? 0 : !PAD ? x : x <= CPT ? x + 1 : x + 2); };
 			constexpr int KB = CPT < 4 ? CPT : 4;       /* cells per batch of loads (register budget: 128 per thread in a team of 1024) */
 			int hprev = (int)lds_ld32(lds, hp + base4 + off4(sft));
 #pragma unroll
@@ -2543,25 +2545,26 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 			if (k < cnt) {      /* (stores and moves only: nothing in here waits) */
 				const int u = u0 + k;
 				if (k > 0) line[u - 1] = (int8_t)byte;
-				lds_st32(lds, oeb + 4u * (BS * (u32)tid + (u32)k + 2u), (u32)e[k]);      /* = entry(u) */
-				lds_st32(lds, hcur + 4u * (BS * (u32)tid + (u32)k + 2u), (u32)h);
+				lds_st32(lds, oeb + 4u * (BS * (u32)tid + (u32)k + (PAD ? 2u : 1u)), (u32)e[k]);      /* = entry(u) */
+				lds_st32(lds, hcur + 4u * (BS * (u32)tid + (u32)k + (PAD ? 2u : 1u)), (u32)h);
 				hm = h > hm ? h : hm;
 				hl = h; Fl = F;
 			}
 		}
 		if (hm > lb) {      /* a new best cell (rare: bests of narrower bands carry over): the first of this thread's cells that holds it */
 			int kk = -1;
-			for (int k = 0; k < cnt; ++k) if (kk < 0 && (int)lds_ld32(lds, hcur + 4u * (BS * (u32)tid + (u32)k + 2u)) == hm) kk = k;
+			for (int k = 0; k < cnt; ++k) if (kk < 0 && (int)lds_ld32(lds, hcur + 4u * (BS * (u32)tid + (u32)k + (PAD ? 2u : 1u))) == hm) kk = k;
 			lb = hm; li = i; lj = beg + u0 + kk - 1;
 		}
 		/* the row as the next one will read it: its forced index holds 0 / -inf whatever was computed there (after the lookup above) */
 		if (edgen >= u0 && edgen < u0 + cnt) { lds_st32(lds, oeb + 4u * entry(edgen), (u32)NEG); lds_st32(lds, hcur + 4u * entry(edgen), 0u); }
-		if (cnt > 0) { lds_st32(lds, TX_SLOT + 4u * (u32)tid, (u32)hl); lds_st32(lds, TX_SLOT + 4u * (u32)(NT + tid), (u32)Fl); }
+		if (NW > 1 && cnt > 0) { lds_st32(lds, TX_SLOT + 4u * (u32)tid, (u32)hl); lds_st32(lds, TX_SLOT + 4u * (u32)(NT + tid), (u32)Fl); }
 		if (tid == 0 && edgen > ncell) { lds_st32(lds, oeb + 4u * entry(edgen), (u32)NEG); lds_st32(lds, hcur + 4u * entry(edgen), 0u); }
 		trace_sync<true, NW>();                         /* barrier 2: the row is written; neighbours' last cells are in the slots */
+		int hleft = 0, Fleft = NEG;
+		if (NW == 1) { hleft = (int)xl_wave_shr1_keep(0u, (u32)hl); Fleft = (int)xl_wave_shr1_keep((u32)NEG, (u32)Fl); }      /* (one wavefront: the neighbour's last cell by DPP) */
 		if (cnt > 0) {
-			int hleft = 0, Fleft = NEG;
-			if (tid > 0) { hleft = (int)lds_ld32(lds, TX_SLOT + 4u * (u32)(tid - 1)); Fleft = (int)lds_ld32(lds, TX_SLOT + 4u * (u32)(NT + tid - 1)); }
+			if (NW > 1 && tid > 0) { hleft = (int)lds_ld32(lds, TX_SLOT + 4u * (u32)(tid - 1)); Fleft = (int)lds_ld32(lds, TX_SLOT + 4u * (u32)(NT + tid - 1)); }
 			const int df5 = (hleft - gapO) > (Fleft - gapE) ? 1 : 0;
 			const u32 b = (byte_first & 0x80u) ? ((byte_first & 1u) | ((u32)(4 + df5) << 2)) : byte_first;
 			line[u0 - 1] = (int8_t)(b | ((u32)df5 << 1));
@@ -2617,10 +2620,11 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 		dir = (int8_t*)(scratch + 3 * rowbytes);
 		/* (8 and 12 cells per thread only for the teams of 16 wavefronts: the register budget of the smaller teams' kernels stays at 128 either way) */
 		const int cpt = trace_cpt_class(width_d, 64 * NW);
-		if (trace_lds_need(band_width, 64 * NW) <= lds_cap && cpt > 0 && !trace_unblocked && (NW > 1 || width_d > 64)) {      /* (one wavefront walks a row of up to 64 cells as one chunk of the other form) */
+		if (trace_lds_need(band_width, 64 * NW) <= lds_cap && cpt > 0 && !trace_unblocked) {
 			const u32 oh0 = trace_lds_fixed_blocked(64 * NW), oh1 = oh0 + (u32)rowbytes, oeb = oh1 + (u32)rowbytes, oring = oeb + (u32)rowbytes;
 			const u32 rmask = trace_ring_size(band_width, 64 * NW) - 1;
-			if (cpt <= 2) trace_band_blocked<NW, 2>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
+			if (cpt <= 1) { if constexpr (NW == 1) trace_band_blocked<NW, 1>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid); }
+			else if (cpt <= 2) trace_band_blocked<NW, 2>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
 			else if (cpt <= 4) trace_band_blocked<NW, 4>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
 			else if constexpr (NW >= 16) {
 				if (cpt <= 8) trace_band_blocked<NW, 8>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
