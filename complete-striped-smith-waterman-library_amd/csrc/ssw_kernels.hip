@@ -2453,10 +2453,13 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 		}
 		/* ---- this thread's cells: u0 .. u0 + cnt - 1 */
 		const int cnt = u0 > ncell ? 0 : (ncell - u0 + 1 < CPT ? ncell - u0 + 1 : CPT);
+		/* a wavefront whose 64 CPT cells all lie past the row's end (the class rounds the cells per thread up; a band's first and last rows are
+		   short) only keeps the barriers: its issue slots go to the wavefronts of its SIMD that have cells */
+		const bool has = NW == 1 || wv * 64 * CPT < ncell;
 		int e[CPT], dia[CPT], sl[CPT];
 		u32 deb = 0;                                   /* bit k: E of cell k was opened (direction 3) */
 		int run = NEG;
-		{
+		if (has) {
 			/* Cells past the row's end (k >= cnt) are evaluated like the others -- on the rows' padding or, for a thread with no cell at all, on
 			   the row's first entries -- with A forced to -inf: the scan then decays over them exactly as the total V wants, and nothing else of
 			   them is stored.  Row 0 needs no case of its own: the rows start as H = 0 / E = -inf. */
@@ -2496,7 +2499,7 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 		}
 		/* ---- scan of the threads' totals: V = S at the thread's last cell (threads without cells carry -inf: nothing follows them) */
 		int V = cnt > 0 ? run : NEG;                   /* (a partial last thread: decayed to a full block's end by its cells past the row) */
-		{
+		if (has) {
 			int o;
 			o = (int)xl_row_shr_keep<1>((u32)NEG, (u32)V) - D; V = o > V ? o : V;
 			o = (int)xl_row_shr_keep<2>((u32)NEG, (u32)V) - 2 * D; V = o > V ? o : V;
@@ -2509,6 +2512,7 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 		if (NW > 1) {
 			if (lane == 63) lds_st32(lds, TX_T + 4u * (u32)wv, (u32)V);
 			__syncthreads();                                /* barrier 1: wave totals; every phase-1 read of the previous row is done */
+			if (has) {
 			int t = lane < NW ? (int)lds_ld32(lds, TX_T + 4u * (u32)lane) : NEG, o;
 			if (lane == 0) { const int z = 0 - 64 * D; t = z > t ? z : t; }      /* the row's cell 0 decayed to the end of wavefront 0 */
 			o = (int)xl_row_shr_keep<1>((u32)NEG, (u32)t) - 64 * D; t = o > t ? o : t;
@@ -2518,12 +2522,14 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 				o = (int)xl_row_shr_keep<8>((u32)NEG, (u32)t) - 512 * D; t = o > t ? o : t;
 			}
 			if (wv > 0) Pw = (int)xl_readlane((u32)t, wv - 1);
+			}
 		} else wave_lds_fence();                          /* (one wavefront: its reads of the previous row are issued before the writes below) */
-		{ const int sp = Pw - (lane + 1) * D; V = sp > V ? sp : V; }
-		const int P = (int)xl_wave_shr1_keep((u32)Pw, (u32)V);      /* S at the cell before this thread's first one */
 		/* ---- finish the cells */
 		int hl = 0, Fl = NEG;                          /* h and F of the cell to the left (cell 0: h_c[0] = 0, no F); a thread's first cell learns them after barrier 2 */
 		u32 byte_first = 0;
+		if (has) {
+		{ const int sp = Pw - (lane + 1) * D; V = sp > V ? sp : V; }
+		const int P = (int)xl_wave_shr1_keep((u32)Pw, (u32)V);      /* S at the cell before this thread's first one */
 		int Sprev = P;
 		int hm = 0;                                    /* highest h of this thread's cells in this row */
 #pragma unroll
@@ -2558,6 +2564,7 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 		}
 		/* the row as the next one will read it: its forced index holds 0 / -inf whatever was computed there (after the lookup above) */
 		if (edgen >= u0 && edgen < u0 + cnt) { lds_st32(lds, oeb + 4u * entry(edgen), (u32)NEG); lds_st32(lds, hcur + 4u * entry(edgen), 0u); }
+		}      /* has */
 		if (NW > 1 && cnt > 0) { lds_st32(lds, TX_SLOT + 4u * (u32)tid, (u32)hl); lds_st32(lds, TX_SLOT + 4u * (u32)(NT + tid), (u32)Fl); }
 		if (tid == 0 && edgen > ncell) { lds_st32(lds, oeb + 4u * entry(edgen), (u32)NEG); lds_st32(lds, hcur + 4u * entry(edgen), 0u); }
 		trace_sync<true, NW>();                         /* barrier 2: the row is written; neighbours' last cells are in the slots */
