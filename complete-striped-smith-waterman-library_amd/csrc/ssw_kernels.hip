@@ -2210,7 +2210,7 @@ SSW_HD int trace_cpt_class(int width_d, int nthreads)
 {
 	const int cpt = (width_d + nthreads - 1) / nthreads;
 	if (cpt <= 1 && nthreads == 64) return 1;        /* one wavefront, one cell per lane (rows need no padding: the stride between lanes is one dword) */
-	return cpt <= 2 ? 2 : cpt <= 4 ? 4 : nthreads < 1024 ? 0 : cpt <= 8 ? 8 : cpt <= 12 ? 12 : 0;
+	return cpt <= 2 ? 2 : cpt <= 4 ? 4 : nthreads < 256 ? 0 : cpt <= 8 ? 8 : cpt <= 12 ? 12 : 0;
 }
 /* One band row in LDS.  trace_band_blocked keeps a thread's C cells C + 1 entries apart (entry of cell u >= 1: u + 1 + (u - 1) / C; cell 0
    at entry 0): the threads of a wavefront read and write their k-th cells at a stride of C + 1 dwords -- odd, hence one LDS bank each; at a
@@ -2625,7 +2625,7 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 		const int64_t want = 3 * rowbytes + (int64_t)width_d * readLen + 16;
 		if (want > cap) { *need = want; *band_io = band_width; return -2; }
 		dir = (int8_t*)(scratch + 3 * rowbytes);
-		/* (8 and 12 cells per thread only for the teams of 16 wavefronts: the register budget of the smaller teams' kernels stays at 128 either way) */
+		/* (8 and 12 cells per thread for the teams, not for single wavefronts: their kernel keeps five wavefronts per SIMD) */
 		const int cpt = trace_cpt_class(width_d, 64 * NW);
 		if (trace_lds_need(band_width, 64 * NW) <= lds_cap && cpt > 0 && !trace_unblocked) {
 			const u32 oh0 = trace_lds_fixed_blocked(64 * NW), oh1 = oh0 + (u32)rowbytes, oeb = oh1 + (u32)rowbytes, oring = oeb + (u32)rowbytes;
@@ -2633,7 +2633,7 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 			if (cpt <= 1) { if constexpr (NW == 1) trace_band_blocked<NW, 1>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid); }
 			else if (cpt <= 2) trace_band_blocked<NW, 2>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
 			else if (cpt <= 4) trace_band_blocked<NW, 4>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
-			else if constexpr (NW >= 16) {
+			else if constexpr (NW >= 4) {
 				if (cpt <= 8) trace_band_blocked<NW, 8>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
 				else trace_band_blocked<NW, 12>(lds, oh0, oh1, oeb, ref, read, refLen, readLen, gapO, gapE, band_width, n, dir, oring, rmask, tb, tid);
 			}
