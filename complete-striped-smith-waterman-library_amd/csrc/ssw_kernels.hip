@@ -2392,8 +2392,8 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 }
 
 /* ------------------------------------------------------------------------------------------------
- * trace_band_blocked: the same band fill for teams (NW > 1, rows in LDS), TWO workgroup barriers per row instead of two per
- * 64*NW cells.  Every thread owns CPT consecutive cells of the row: it evaluates E / diagonal / A for them, scans its own
+ * trace_band_blocked: the same band fill with rows in LDS and TWO workgroup barriers per row instead of two per 64*NW cells
+ * (NW = 1: fences).  Every thread owns CPT consecutive cells of the row: it evaluates E / diagonal / A for them, scans its own
  * cells serially, the threads' totals are scanned across the team (decay CPT*m per thread: DPP inside a wavefront, wave totals
  * through LDS -- barrier 1), then every thread finishes its cells (F, H, directions) and writes the row; the direction of F
  * in a thread's first cell needs h and F of the cell to its left, which the neighbour leaves in an LDS slot (barrier 2).
@@ -2402,15 +2402,15 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
  * directions and the row-major strict-> best cell are the scalar walk's: the long rows of wide bands (thousands of cells x 10^4
  * rows per alignment) were bound by barrier latency, not by arithmetic.
  * ------------------------------------------------------------------------------------------------ */
-#define TRACE_CPT_MAX 12
-#define TX_SLOT 1536u      /* blocked form: per-thread (h, F) of its last cell: 8 bytes per thread, placed after the fixed area */
+#define TX_SLOT 1536u      /* blocked form: h and F of every thread's last cell (two arrays of one dword per thread), placed after the fixed area */
 SSW_HD u32 trace_lds_fixed_blocked(int nthreads) { return TX_SLOT + 8u * (u32)nthreads; }
 
-/* CPT = cells per thread (2, 4, 8 or 12: the smallest that covers the row; threads beyond the row idle).  Everything a thread reads of the
-   previous row -- H at up-1 .. up+CPT-1, E at up .. up+CPT-1, the target codes of its cells -- is requested in ONE batch with clamped
-   addresses and no branch, then the scores: two LDS round trips per row.  (The first form of this function walked its cells under
-   `if (k < cnt)`: hipcc made each an exec-masked block with its own three dependent round trips -- 12 x 3 per row, 7 us per row of a
-   4096-cell band, the whole traceback tail of config 4.)  NW = 1: the team is one wavefront, the barriers are LDS fences. */
+/* CPT = cells per thread (trace_cpt_class: 1 for a single wavefront, 2, 4, and 8 or 12 for teams -- the smallest that covers the row;
+   threads beyond the row idle, wavefronts beyond it only keep the barriers).  What a thread reads of the previous row -- H at
+   up-1 .. up+CPT-1, E at up .. up+CPT-1, the target codes of its cells -- is requested in batches of four cells without a branch (cells
+   past the row's end read the rows' padding), then the scores: two LDS round trips per batch.  (The first form of this function walked
+   its cells under `if (k < cnt)`: hipcc made each an exec-masked block with its own three dependent round trips, 12 x 3 per row.)
+   The rows are laid out with CPT + 1 entries between two threads' cells (trace_rowbytes): one LDS bank per lane. */
 template <int NW, int CPT>
 SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, const int8_t* ref, const int8_t* read, int refLen, int readLen,
                                 int gapO, int gapE, int band_width, int n, int8_t* dir, u32 oring, u32 ring_mask, TraceBest& tb, int tid)
@@ -2688,6 +2688,8 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 /* one team of NW wavefronts (one workgroup) per alignment; same contract as k_trace.  a.resume[q] = {band, best, best_i,
    best_j, stage} carries an alignment that ran out of scratch to the next negotiation round. */
 template <int NW>
+/* (register budget: a single wavefront per alignment keeps five wavefronts per SIMD -- at 64 registers the row loop spills, at 128 config 4 loses 10 ms;
+   the teams have 128 each: four wavefronts per SIMD is a team of 1024 threads on one compute unit) */
 __global__ void __launch_bounds__(64 * NW) SSW_WAVES_PER_EU(NW == 1 ? 5 : 4, 8) k_trace_wave(ssw_trace_args a)
 {
 	SSW_DYN_LDS(lds);
