@@ -425,15 +425,15 @@ def test_allocation_failure_shrinks_the_budget_and_retries(emu_lib_path, monkeyp
     """SSW_ALLOC_RETRY: a device allocation that fails although it is within the budget (contexts of one process sharing a device) cuts
     the budget and plans the launches again.  The emulator's allocator refuses single allocations above SSW_EMU_MALLOC_LIMIT_MB."""
     rng = np.random.default_rng(12)
-    ref = random_ref(40000, 5, 4)
-    reads = make_reads(rng, ref, 96, [32], 4)                  # 48 pairs x 40 016 columns x 4 bytes = 7.7 MB per column-maximum array
+    ref = random_ref(30000, 5, 4)
+    reads = make_reads(rng, ref, 64, [32], 4)                  # 32 pairs x 30 016 columns x 4 bytes = 3.8 MB per column-maximum array
     mat = dna_matrix(2, 2)
     lib = ssw_amd.load(emu_lib_path)
     ctx = ssw_amd.Context(0, lib)
     try:
         Q = ctx.upload(reads); T = ctx.upload([ref])
         lib.ssw_gpu_set_budget(ctx.h, 256 << 20)
-        monkeypatch.setenv("SSW_EMU_MALLOC_LIMIT_MB", "3")
+        monkeypatch.setenv("SSW_EMU_MALLOC_LIMIT_MB", "2")
         res, cig = ctx.align_batch(Q, T, mat, 5, 3, 1, 0, 0, 0, -1, 2)
         assert ctx.timing()["fill_launches"] >= 3               # the bucket was cut into launches that fit
         assert lib.ssw_gpu_get_budget(ctx.h) < (256 << 20)      # ... because the budget was cut
@@ -455,7 +455,7 @@ def test_banded_reverse_pass_of_long_reads(ectx, monkeypatch):
     reference, and against the same call with whole windows (SSW_GPU_NO_BAND=1)."""
     from sswutil import mutate
     rng = np.random.default_rng(31)
-    ref = random_ref(9000, 17, 4)
+    ref = random_ref(6500, 17, 4)
     reads = []
     for L, sub, ind in ((1500, 0.01, 0.003), (2100, 0.02, 0.01), (2600, 0.005, 0.002), (1800, 0.10, 0.03), (3000, 0.01, 0.004)):
         o = int(rng.integers(0, len(ref) - L - 200))
