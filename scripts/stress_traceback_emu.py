@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Build container (no GPU): randomized stress of the traceback kernels on the SIMT emulator -- reads with random deletions / insertions /
+unrelated reads, random scoring, teams of 1 / 4 / 16 wavefronts -- every record and CIGAR against the unmodified reference (tests/parity.py).
+usage: stress_traceback_emu.py <seconds> <seed>     (end of round 4: 1 386 cases in 4 x 7 minutes, 0 mismatches)"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'complete-striped-smith-waterman-library_amd'))
+import ssw_amd
+from parity import compare_batch, make_reads
+from sswutil import dna_matrix, random_ref, blosum50
+lib = ssw_amd.load(os.path.join(ROOT, 'tests', 'emu', 'libssw_emu.so'))
+t_end = time.time() + float(sys.argv[1])
+seed = int(sys.argv[2]); it = 0; nbad = 0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed + it); it += 1
+    teams = rng.choice(["", "1", "4", "16"])
+    if teams: os.environ["SSW_GPU_TRACE_WAVES"] = teams
+    else: os.environ.pop("SSW_GPU_TRACE_WAVES", None)
+    ctx = ssw_amd.Context(0, lib)
+    L = int(rng.integers(300, 1800))
+    ref = random_ref(L + int(rng.integers(50, 1200)), int(rng.integers(1, 1000)), 4)
+    reads = []
+    for k in range(int(rng.integers(2, 6))):
+        kind = rng.integers(0, 4)
+        n = int(rng.integers(40, min(len(ref) - 10, 1500)))
+        o = int(rng.integers(0, len(ref) - n))
+        if kind == 0: r = ref[o:o + n].copy()
+        elif kind == 1:
+            cut = int(rng.integers(5, max(6, n // 2))); a = int(rng.integers(1, max(2, n - cut - 1)))
+            r = np.concatenate([ref[o:o + a], ref[o + a + cut:o + n]])            # deletion
+        elif kind == 2:
+            ins = int(rng.integers(5, 400)); a = int(rng.integers(1, n - 1))
+            r = np.concatenate([ref[o:o + a], rng.integers(0, 4, size=ins, dtype=np.int8), ref[o + a:o + n]])
+        else: r = rng.integers(0, 4, size=n, dtype=np.int8)
+        reads.append(np.ascontiguousarray(r, dtype=np.int8))
+    gO, gE = [(3, 1), (5, 2), (9, 2), (2, 1)][int(rng.integers(0, 4))]
+    mat = dna_matrix(int(rng.integers(1, 4)), int(rng.integers(1, 5)))
+    Q = ctx.upload(reads); T = ctx.upload([ref])
+    res, cig = ctx.align_batch(Q, T, mat, 5, gO, gE, 2, 0, 0, -1, 2)
+    bad = compare_batch(res, cig, reads, [ref], mat, 5, gO, gE, 2, 0, 0, -1, 2)
+    Q.free(); T.free(); ctx.close()
+    if bad:
+        nbad += 1; print("MISMATCH seed", seed + it - 1, teams, bad[:2]); break
+print("iterations", it, "mismatching", nbad)
