@@ -104,12 +104,21 @@ static __thread char g_open_err[512];   /* error of the last failed ssw_gpu_open
 /* SSW_GPU_CALL_TRACE=1: host wall-clock at the phases of a batch call (what a single-pair ssw_align spends where) */
 #define CALL_TRACE(what) do { if (c->kn.call_trace) fprintf(stderr, "[ssw_gpu call] %9.3f ms  %s\n", dbg_ms(), what); } while (0)
 
+#ifdef SSW_GPU_TEST_HOOKS
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e && e[0] ? atoi(e) : dflt; }
+#endif
 static int env_is(const char* name, char ch) { const char* e = getenv(name); return e && e[0] == ch; }
+/* The PRODUCT library (libssw.so) reads two diagnostics here -- SSW_GPU_DEBUG, SSW_GPU_CALL_TRACE -- and nothing that changes which kernel
+   form runs: the form-switching hooks below exist only in the build the test suite and the measurement scripts load
+   (-DSSW_GPU_TEST_HOOKS: libssw_hooks.so, tests/emu/libssw_emu.so; same kernels object, same host source). */
 static void knobs_load(ssw_knobs* k)
 {
 	memset(k, 0, sizeof *k);
 	k->debug = getenv("SSW_GPU_DEBUG") != 0;
+	k->call_trace = env_is("SSW_GPU_CALL_TRACE", '1');
+	k->db_chain_best = 1;
+	k->trace_wave = -1;
+#ifdef SSW_GPU_TEST_HOOKS
 	{ const int v = env_int("SSW_GPU_FRAME_K", 0); k->frame_k = v >= 16 ? v : 0; }
 	k->queue_mode = env_is("SSW_GPU_QUEUE", 'j') ? 1 : env_is("SSW_GPU_QUEUE", 's') ? 2 : 0;
 	{ const int v = env_int("SSW_GPU_QUEUE_WAVES", 0); k->queue_waves = v > 0 ? v : 0; }
@@ -130,11 +139,20 @@ static void knobs_load(ssw_knobs* k)
 	k->trace_unblocked = env_is("SSW_GPU_TRACE_BLOCKED", '0');
 	k->serial_buckets = env_is("SSW_GPU_SERIAL_BUCKETS", '1');
 	k->no_dbx = env_is("SSW_GPU_NO_DBX", '1');
-	k->call_trace = env_is("SSW_GPU_CALL_TRACE", '1');
 	k->no_band = env_is("SSW_GPU_NO_BAND", '1');
 	k->no_tail = env_is("SSW_GPU_NO_TAIL", '1');
 	{ const int v = env_int("SSW_GPU_DB_TSUB", 0); k->db_tsub = v > 0 ? v : 0; }
 	{ const int v = env_int("SSW_GPU_DBX_SLAB", 0); k->dbx_slab = v > 0 ? v : 0; }
+#endif
+}
+/* 1 when this build reads the form-switching SSW_GPU_* hooks (tests refuse to run their variants on a library that would ignore them) */
+int ssw_gpu_has_test_hooks(void)
+{
+#ifdef SSW_GPU_TEST_HOOKS
+	return 1;
+#else
+	return 0;
+#endif
 }
 
 #include <time.h>
@@ -970,7 +988,11 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 		const int64_t full = (int64_t)maxlen + ti->ref_span;
 		const int64_t worst = (3 * (2 * full + 8) * 4 + (2 * full + 1) * (int64_t)maxlen * 3 + 64 + 15) / 16 * 16;
 		int trace_ok = 1;
-		for (int round = 0; round < 10 && npend > 0 && trace_ok; ++round) {
+		/* Termination.  An alignment that comes back pending names the band that did not fit and the bytes that band wants; the next round grants
+		   at least that (see cap_i below), so the band is walked and the alignment either finishes or reports a band at least twice as wide.
+		   banded_sw walks bands <= max(refLen', readLen') only (src/ssw.c:679), the single retry at the full band (945-957) included: after at most
+		   log2(span) + 2 rounds nothing is pending.  64 is that bound for any 32-bit span, not a budget -- reaching it would be a bug. */
+		for (int round = 0; round < 64 && npend > 0 && trace_ok; ++round) {
 			tpend* nextp = (tpend*)malloc(sizeof(tpend) * (size_t)npend);
 			int32_t nnext = 0;
 			if (!nextp) { fail(c, "out of host memory%s", ""); trace_ok = 0; break; }
@@ -1031,7 +1053,7 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 						while (g1 < npend) {
 							const int64_t nb_ = (int64_t)pend[g1].need * 4096;
 							int64_t cap_i = (nb_ * (nb_ < ((int64_t)32 << 20) ? 4 : 2) + 65536 + 15) / 16 * 16;
-							if (cap_i > worst) cap_i = worst;
+							if (cap_i > worst) cap_i = worst > nb_ ? worst : nb_;      /* headroom up to the widest band there can be -- but never less than what was asked for */
 							if ((g1 > g0 || ngrp > 0) && batch_total + total + cap_i > budget) break;
 							if (use_wave) {
 								/* a band row of 2b+1 cells is walked in chunks of 64 cells per wavefront: wide bands get 4 or 16 wavefronts */
@@ -1058,12 +1080,15 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 						fail(c, "upload failed: %s", ssw_shim_last_error()); trace_ok = 0; break;
 					}
 					/* widest bands first: they take longest, and only a few hardware queues run side by side */
+					int tused[SSW_TSTREAMS];
+					for (int sx = 0; sx < SSW_TSTREAMS; ++sx) tused[sx] = 0;
 					for (int gx = 0; gx < ngrp && trace_ok; ++gx) {
 						const int gi = ngrp - 1 - gx;
 						/* (the runtime hands the context's streams to FOUR hardware queues in creation order -- main 1, second 2, side streams 3 4 4 3 2 1 --
 						   and launches on one queue run one after the other: the first four launches of a round go to four different queues) */
 						static const int side_of[SSW_TSTREAMS] = { 0, 1, 4, 2, 3, 5 };
-						void* st = gx == 0 ? c->stream : c->tstream[side_of[(gx - 1) % SSW_TSTREAMS]];
+						void* st = c->stream;
+						if (gx > 0) { const int sx = side_of[(gx - 1) % SSW_TSTREAMS]; st = c->tstream[sx]; tused[sx] = 1; }
 						const int32_t cnt_l = grp[gi].g1 - grp[gi].g0;
 						ssw_trace_args ta;
 						ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist + grp[gi].g0; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n; ta.vm = ti->vm;
@@ -1076,8 +1101,10 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 						if (c->kn.debug) fprintf(stderr, "[ssw_gpu] trace round %d: %d alignments, LDS %lld B x %d waves per alignment, scratch at %lld\n",
 						                                     round, cnt_l, (long long)grp[gi].lds, grp[gi].waves, (long long)grp[gi].base);
 					}
-					for (int gi = 1; gi < ngrp && gi <= SSW_TSTREAMS; ++gi)     /* the main stream continues after all of them */
-						if (ssw_shim_event_record(c->tev[gi - 1], c->tstream[gi - 1]) || ssw_shim_stream_wait_event(c->stream, c->tev[gi - 1])) trace_ok = 0;
+					for (int sx = 0; sx < SSW_TSTREAMS; ++sx)     /* the main stream continues after every side stream that was handed a launch */
+						if (tused[sx] && (ssw_shim_event_record(c->tev[sx], c->tstream[sx]) || ssw_shim_stream_wait_event(c->stream, c->tev[sx]))) {
+							fail(c, "stream join failed: %s", ssw_shim_last_error()); trace_ok = 0;
+						}
 					if (!trace_ok) break;
 					if (ssw_shim_d2h(hall + 2 * (int64_t)b0, d_need + 2 * (int64_t)b0, sizeof(int32_t) * 2 * (size_t)(g0 - b0), c->stream) ||
 					    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
@@ -1480,8 +1507,9 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 		const int32_t refLen = (int32_t)refLen64;
 		const int8_t* d_tgt = T->d_codes + T->h_off[t];
 		const int ev_first = c->nev;
-		/* (every non-empty query's record is written whole by the reduction; only empty queries and queries answered elsewhere rely on zeroes) */
-		if (nqa != nq || tcount > 1) { if (ssw_shim_memset(d_res, 0, sizeof(ssw_dres) * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; } }
+		/* (every non-empty query's record is written whole by the reduction; only empty queries, queries answered elsewhere and an EMPTY
+		   target -- no kernel runs at all: the reference's score-0 record, src/ssw.c:900-903 -- rely on zeroes) */
+		if (nqa != nq || tcount > 1 || refLen == 0) { if (ssw_shim_memset(d_res, 0, sizeof(ssw_dres) * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; } }
 
 		if (refLen > 0 && literal) {
 			/* scratch per alignment: 4 x [segments][16] int16 + codes + maxColumn (sized for the 16-bit kernel: 8 lanes) */
@@ -1520,7 +1548,7 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 #define ALIGN16(x) (((size_t)(x) + 15) / 16 * 16)
 			if (!bplans) bplans = (bplan*)calloc((size_t)nb, sizeof(bplan));
 			if (!bplans) { fail(c, "out of host memory%s", ""); goto done; }
-			int max_chunk, nact, conc;
+			int max_chunk, nact, conc, conc_refused = 0;
 plan_again:
 			max_chunk = 1; nact = 0;
 			size_t tot_cm = 0, tot_sg = 0, tot_bnd = 0, tot_cand = 0, tot_q = 0, tot_cs = 0;      /* all buckets side by side */
@@ -1617,9 +1645,10 @@ plan_again:
 			   of workgroups and the strip kernel's few long jobs leave most of the device idle.  When every bucket is ONE launch and all of
 			   them fit the budget together, each gets its own slice of the scratch buffers and its fill + reduction go to one of the side
 			   streams; the main stream continues after all of them.  SSW_GPU_SERIAL_BUCKETS=1 keeps the old order (tests compare). */
-			conc = nact > 1 && !c->kn.serial_buckets && !any_dbl && !any_chunked && 2 * tot_cm + 2 * tot_sg + tot_bnd + tot_cand <= c->cm_budget;
+			conc = nact > 1 && !conc_refused && !c->kn.serial_buckets && !c->kn.no_seg_reduce &&     /* (k_reducem reads group maxima only) */ !any_dbl && !any_chunked && 2 * tot_cm + 2 * tot_sg + tot_bnd + tot_cand <= c->cm_budget;
 			if (!conc) for (int b = 0; b < nb; ++b) { bplan* P = &bplans[b]; P->cm_off = P->sg_off = P->bnd_off = P->cand_off = 0; P->q_off = P->cs_off = 0; }
-#define SSW_ALLOC_RETRY() do { if (c->cm_budget > ((size_t)2 << 20) && max_chunk > 1) { c->cm_budget /= c->budget_shrunk ? 2 : 4; c->budget_shrunk = 1; c->err[0] = 0; goto plan_again; } goto done; } while (0)
+			/* (side by side the buffers are the SUM over the buckets: before the budget is cut, the buckets go one after the other -- the maximum) */
+#define SSW_ALLOC_RETRY() do { if (conc) { conc_refused = 1; c->err[0] = 0; goto plan_again; } if (c->cm_budget > ((size_t)2 << 20) && max_chunk > 1) { c->cm_budget /= c->budget_shrunk ? 2 : 4; c->budget_shrunk = 1; c->err[0] = 0; goto plan_again; } goto done; } while (0)
 			unsigned char *base_cm16 = 0, *base_cm8 = 0, *base_cmB16 = 0, *base_cmB8 = 0, *base_sg16 = 0, *base_sg8 = 0, *base_bnd = 0, *base_cand = 0;
 			int32_t *base_q = 0, *base_cs = 0;
 			if (nact > 0) {
@@ -1874,6 +1903,17 @@ plan_again:
 			tri.Q = Q; tri.prm = prm; tri.d_tgt = d_tgt; tri.d_mat = d_mat; tri.n = n; tri.d_res = d_res; tri.nslots = nq;
 			tri.ids = order; tri.nids = nqa; tri.d_list = d_qlist; tri.hneed = hneed; tri.maxlen = maxlen; tri.ref_span = halo_max < refLen ? halo_max : refLen;
 			tri.list_on_device = 1;
+			if (literal) {
+				/* gapO <= gapE: the halo argument (every gap base costs at least gapE) does not bound an alignment's reference span -- a gap base can
+				   cost gapO, and with gapO = 0 nothing at all: 33 read bases against 346 target bases is a legal answer of the reference.  This regime
+				   is not a throughput path: take the spans the window passes actually found (one download) instead of a bound.  CIGAR slots and the
+				   traceback's widest band are then exact for this batch. */
+				if (ssw_shim_d2h(hres, d_res, sizeof(ssw_dres) * (size_t)nq, c->stream) || ssw_shim_stream_sync(c->stream)) { fail(c, "result download failed: %s", ssw_shim_last_error()); goto done; }
+				int64_t rspan = 1;
+				for (int32_t q = 0; q < nq; ++q)
+					if (hres[q].want_cigar && hres[q].status == 0 && (int64_t)hres[q].ref_end1 - hres[q].ref_begin1 + 1 > rspan) rspan = (int64_t)hres[q].ref_end1 - hres[q].ref_begin1 + 1;
+				tri.ref_span = rspan;
+			}
 			if (trace_phase(c, &tri, &tro)) goto done;
 			if (tro.list_dirty && ti + 1 < tcount && ssw_shim_h2d(d_qlist, order, sizeof(int32_t) * (size_t)nqa, c->stream)) { fail(c, "upload failed: %s", ssw_shim_last_error()); goto done; }
 		}
@@ -2112,18 +2152,23 @@ static void implicit_destroy(void* p)
 	}
 	free(ic->tcopy); free(ic->stage); free(ic);
 }
-static void implicit_key_init(void) { pthread_key_create(&g_ictx_key, implicit_destroy); }
+/* Runs once per process, before the first implicit context exists (pthread_once), not from every first-calling thread.
+   Caller threads' calls overlap on the device only as far as the runtime has hardware queues for their streams: ROCm's default is four
+   per process.  If nobody chose otherwise and the runtime is not up yet (this is typically the process's first HIP call), ask for eight:
+   8 caller threads 6 085 -> 8 146 calls per second (profiles/round4_dropin_threads.txt).  Without effect in a process that initialised
+   HIP before; a user's own GPU_MAX_HW_QUEUES is left alone, and SSW_GPU_KEEP_ENV=1 makes the library leave the environment alone
+   altogether (an embedder whose other threads may be inside getenv at that moment: INTEGRATION.md). */
+static void implicit_key_init(void)
+{
+	pthread_key_create(&g_ictx_key, implicit_destroy);
+	if (!getenv("SSW_GPU_KEEP_ENV")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
 
 static implicit_ctx* implicit_get(void)
 {
 	pthread_once(&g_ictx_once, implicit_key_init);
 	implicit_ctx* ic = (implicit_ctx*)pthread_getspecific(g_ictx_key);
 	if (ic) return ic;
-	/* Caller threads' calls overlap on the device only as far as the runtime has hardware queues for their streams: ROCm's default is four
-	   per process.  If nobody chose otherwise and the runtime is not up yet (this is typically the process's first HIP call), ask for eight:
-	   8 caller threads 6 085 -> 8 146 calls per second (profiles/round4_dropin_threads.txt).  Without effect in a process that initialised
-	   HIP before; a user's own GPU_MAX_HW_QUEUES is left alone. */
-	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	const int ndev = ssw_shim_device_count();
 	const char* e = getenv("SSW_GPU_DEVICE");
 	const int dev = e ? atoi(e) : (ndev > 0 ? __atomic_fetch_add(&g_next_device, 1, __ATOMIC_RELAXED) % ndev : 0);

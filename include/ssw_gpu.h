@@ -197,6 +197,9 @@ void ssw_gpu_host_free(ssw_gpu_ctx* ctx, void* p);
    packed 16-bit VALU instructions in lane-operations per second (the compute roofline of this integer path). */
 int ssw_gpu_selftest_lanes(ssw_gpu_ctx* ctx, uint32_t* out1024);
 double ssw_gpu_valu_probe(ssw_gpu_ctx* ctx, int32_t blocks, int32_t iters);
+/* 1 when the library was built with -DSSW_GPU_TEST_HOOKS (libssw_hooks.so, the test emulator): only that build reads the form-switching
+   SSW_GPU_* environment hooks of INTEGRATION.md; libssw.so returns 0 and ignores them. */
+int ssw_gpu_has_test_hooks(void);
 
 /* Convert one batch record into a heap s_align (align_destroy()-compatible), copying its CIGAR. */
 s_align* ssw_gpu_result_to_align(const ssw_gpu_result* r, const uint32_t* cigar_pool);

@@ -9,6 +9,7 @@ seeded workloads of tests/workloads.py, and committed as compressed fixtures und
   config2_u8_block0.npz   (`20`) the 100 000 reads of config 2 under 1/-3/5/2 (pure 8-bit rules), flag 2
   config6_block0.npz  (`6`) the 1000 mixed-length reads of the README's benchmark shape vs the 4.94 Mb genome, defaults and -m1 -x3 -o5 -e2, flag 2
   config{2,3}_blocks_sample.npz  (`21`, `31`) a seeded 2 000-read sample of read blocks 0..7 (rank r of an N-GPU run works on block r), flag 2
+  config3_blocks_sample_8_49.npz (`32`) a seeded 500-read sample of read blocks 8..49: with blocks 0..7 above, all 50 blocks of config 3 at its stated size
   config5_block0.npz  first 2 048 queries of query block 0 against all 10 000 DB entries (2.05e7 alignments): one 64-bit
                       checksum per query over its 10 000 x (score1 score2 ref_end1 read_end1 ref_end2), full records of
                       the first 16 queries
@@ -76,15 +77,15 @@ def sample_indices(cfg, block, nreads, k=SAMPLE):
     return np.sort(np.random.default_rng(770_000 + 100 * cfg + block).choice(nreads, size=min(k, nreads), replace=False))
 
 
-def run_dna_blocks(R, cfg, blocks, threads):
-    """per-rank fixtures: rank r of `bench.py --gpus N` works on read block r; a seeded sample of SAMPLE reads of every block,
-    flag 2 (the five score / end fields also check the score-only run)"""
+def run_dna_blocks(R, cfg, blocks, threads, first=0, k=SAMPLE, tag=""):
+    """per-rank fixtures: rank r of `bench.py --gpus N` works on read block r; a seeded sample of `k` reads of every block
+    first .. blocks-1, flag 2 (the five score / end fields also check the score-only run)"""
     idxs, fields, hashes = [], [], []
     mat = dna_matrix(2, 2)
     t0 = time.time()
-    for b in range(blocks):
+    for b in range(first, blocks):
         ref, reads, p = W.dna_config(cfg, b)
-        idx = sample_indices(cfg, b, len(reads))
+        idx = sample_indices(cfg, b, len(reads), k)
         sub = np.ascontiguousarray(reads[idx])
         off = np.arange(len(idx) + 1, dtype=np.int64) * p["read_len"]
         res = np.zeros((len(idx), 10), dtype=np.int32)
@@ -94,8 +95,8 @@ def run_dna_blocks(R, cfg, blocks, threads):
         assert (res[:, 9] == 0).all()
         idxs.append(idx); fields.append(res[:, :9].copy()); hashes.append(hsh)
         print("config %d block %d: %d sampled reads done, %.0f s" % (cfg, b, len(idx), time.time() - t0), flush=True)
-    np.savez_compressed(os.path.join(OUT, "config%d_blocks_sample.npz" % cfg), idx=np.stack(idxs), fields=np.stack(fields), cigar_fnv=np.stack(hashes),
-                        meta=np.array([cfg, blocks, SAMPLE], dtype=np.int64))
+    np.savez_compressed(os.path.join(OUT, "config%d_blocks_sample%s.npz" % (cfg, tag)), idx=np.stack(idxs), fields=np.stack(fields), cigar_fnv=np.stack(hashes),
+                        meta=np.array([cfg, blocks, k, first], dtype=np.int64))
 
 
 def run_protein(R, nq, threads):
@@ -158,6 +159,8 @@ def main():
             run_dna_blocks(R, 2, 8, threads)
         elif cfg == 31:
             run_dna_blocks(R, 3, 8, threads)
+        elif cfg == 32:      # config 3 at its stated size (1M reads = 50 blocks of 20 000): a 500-read sample of blocks 8..49
+            run_dna_blocks(R, 3, 50, threads, first=8, k=500, tag="_8_49")
         elif cfg == 5:
             run_protein(R, 2048, threads)
         elif cfg == 50:

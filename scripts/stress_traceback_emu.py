@@ -1,17 +1,37 @@
 #!/usr/bin/env python3
 """Build container (no GPU): randomized stress of the traceback kernels on the SIMT emulator -- reads with random deletions / insertions /
 unrelated reads, random scoring, teams of 1 / 4 / 16 wavefronts -- every record and CIGAR against the unmodified reference (tests/parity.py).
-usage: stress_traceback_emu.py <seconds> <seed>     (end of round 4: 1 386 cases in 4 x 7 minutes, 0 mismatches)"""
+usage: stress_traceback_emu.py <seconds> <seed>     (end of round 4: 1 386 cases in 4 x 7 minutes, 0 mismatches)
+       stress_traceback_emu.py <seconds> <seed> --free-gap-open     the gapO = 0 regime with every CIGAR flag (tests/parity.py free_gap_open_case):
+                                                                    no call may fail, every record / CIGAR (mostly `flag 1`) as the reference's"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'complete-striped-smith-waterman-library_amd'))
 import ssw_amd
-from parity import compare_batch, make_reads
+from parity import compare_batch, free_gap_open_case, make_reads
 from sswutil import dna_matrix, random_ref, blosum50
 lib = ssw_amd.load(os.path.join(ROOT, 'tests', 'emu', 'libssw_emu.so'))
 t_end = time.time() + float(sys.argv[1])
 seed = int(sys.argv[2]); it = 0; nbad = 0
+if "--free-gap-open" in sys.argv:
+    ctx = ssw_amd.Context(0, lib)
+    rng = np.random.default_rng(seed); nal = nflag1 = nfail = 0
+    while time.time() < t_end:
+        reads, ref, mat, n, gapO, gapE, flag, filterd, maskLen = free_gap_open_case(rng); it += 1
+        Q = ctx.upload(reads); T = ctx.upload([ref])
+        try:
+            res, cig = ctx.align_batch(Q, T, mat, n, gapO, gapE, flag, 0, filterd, maskLen, 2)
+        except Exception as e:
+            nfail += 1; print("FAILED CALL", it, e); continue
+        finally:
+            Q.free(); T.free()
+        bad = compare_batch(res, cig, reads, [ref], mat, n, gapO, gapE, flag, 0, filterd, maskLen, 2)
+        nal += len(reads); nflag1 += int((res["flag"] == 1).sum())
+        if bad:
+            nbad += 1; print("MISMATCH call", it, bad[:2])
+    print("free gap open: calls", it, "alignments", nal, "with flag 1", nflag1, "failed calls", nfail, "mismatching calls", nbad)
+    sys.exit(1 if nbad or nfail else 0)
 while time.time() < t_end:
     rng = np.random.default_rng(seed + it); it += 1
     teams = rng.choice(["", "1", "4", "16"])

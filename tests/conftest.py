@@ -50,6 +50,27 @@ def product_lib_path():
 
 
 @pytest.fixture(scope="session")
+def hooks_lib_path(product_lib_path):
+    """libssw_hooks.so: the product's kernels object and host source, with the form-switching SSW_GPU_* test hooks compiled in
+    (-DSSW_GPU_TEST_HOOKS).  Tests that force a kernel form through the environment load THIS library; libssw.so ignores those hooks."""
+    path = os.path.join(PKG, "libssw_hooks.so")
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", PKG, "-s", "libssw_hooks.so"], check=True)
+    return path
+
+
+@pytest.fixture(scope="session")
+def gpu_hctx(hooks_lib_path):
+    import ssw_amd
+    lib = ssw_amd.load(hooks_lib_path)
+    assert lib.ssw_gpu_has_test_hooks() == 1
+    assert lib.ssw_gpu_device_count() > 0, "no HIP device: the GPU tests need a real MI355X"
+    ctx = ssw_amd.Context(0, lib)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="session")
 def gpu_ctx(product_lib_path):
     import ssw_amd
     lib = ssw_amd.load(product_lib_path)

@@ -51,3 +51,34 @@ def make_reads(rng, ref, nq, lens, nc, sub=0.06, ins=0.02, dele=0.02, frac_rando
             r = rng.integers(0, nc, size=rl, dtype=np.int8)
         reads.append(np.ascontiguousarray(r, dtype=np.int8))
     return reads
+
+
+def free_gap_open_case(rng):
+    """One batch of the `gapO = 0` regime (a legal argument of ssw.h:126-134; round-4 fuzz): opening a gap is free, so an alignment of a 33-base
+    read can span hundreds of target bases -- far beyond what the gap-extension argument bounds -- and banded_sw (src/ssw.c:590-783) mostly
+    gives up on it after the full-band retry (ssw.c:945-957): `cigar NULL, cigarLen 0, flag 1` is then the reference's answer.  Draws what
+    makes the spans long: sparse matrices (match 1-2, every mismatch negative) over alphabets up to 24 letters, reads unrelated to the target,
+    gapE 0-3, and every flag that asks for a CIGAR.  -> (reads, ref, mat, n, gapO, gapE, flag, filterd, maskLen)"""
+    n = int(rng.integers(4, 25)); nc = n - 1 if n > 4 else n
+    kind = rng.random()
+    if kind < 0.35:
+        mat = np.full((n, n), -int(rng.integers(1, 6)), dtype=np.int8)
+        for i in range(n):
+            mat[i, i] = int(rng.choice([1, 1, 2]))
+        mat = np.ascontiguousarray(mat.reshape(-1))
+    elif kind < 0.6:
+        hi = int(rng.choice([1, 1, 2, 8]))
+        mat = np.minimum(rng.integers(-8, 9, size=(n, n)), hi).astype(np.int8)
+        for i in range(n):
+            mat[i, i] = rng.integers(1, hi + 1)
+        mat = np.ascontiguousarray(mat.reshape(-1))
+    else:
+        from sswutil import dna_matrix
+        n, nc, mat = 5, 4, dna_matrix(int(rng.choice([1, 1, 2, 3])), int(rng.integers(1, 6)))
+    ref = rng.integers(0, nc, size=int(rng.integers(120, 701)), dtype=np.int8)
+    nq = int(rng.integers(1, 6))
+    reads = make_reads(rng, ref, nq, rng.integers(15, 71, size=nq), nc)
+    if rng.random() < 0.5:
+        reads = [rng.integers(0, nc, size=len(r), dtype=np.int8) for r in reads]
+    return (reads, ref, mat, n, 0, int(rng.choice([0, 1, 1, 2, 3])), int(rng.choice([1, 2, 9, 12, 15])),
+            int(rng.choice([0, 1000])), int(rng.choice([-1, 15, 40])))

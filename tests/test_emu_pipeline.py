@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import ssw_amd
-from parity import compare_batch, make_reads
+from parity import compare_batch, free_gap_open_case, make_reads
 from sswutil import blosum50, dna_matrix, random_ref
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -261,6 +261,59 @@ def test_layout_dependent_gap_regime(ectx):
     _run(ectx, make_reads(rng, ref, 3, [600, 150, 333], 4), [ref], dna_matrix(2, 2), 5, 1, 3, flag=1)
     ref = random_ref(420, 78, 4)
     _run(ectx, [np.ascontiguousarray(np.concatenate([ref, ref[::-1], ref, ref[::-1], ref, ref[:300]])), ref[:90].copy()], [ref], dna_matrix(1, 3), 5, 2, 2, flag=0)
+
+
+def test_free_gap_open_with_traceback(ectx):
+    """gapO = 0 with a CIGAR flag (round-4 verdict): alignments span many times their read length, banded_sw mostly fails after the full-band
+    retry -- the reference's `cigarLen 0, flag 1` -- and the traceback's scratch negotiation has to get every alignment to its widest band:
+    before round 5 it gave up after ten rounds against a bound that does not hold here and failed the WHOLE call.  Every call must return,
+    every record and CIGAR must equal the reference's.  (scripts/stress_traceback_emu.py --free-gap-open runs thousands of these.)"""
+    rng = np.random.default_rng(2)      # (calls 79, 126 and 139 of this stream aborted before the fix)
+    nflag1 = 0
+    for it in range(140):
+        reads, ref, mat, n, gapO, gapE, flag, filterd, maskLen = free_gap_open_case(rng)
+        if it % 4 and it not in (79, 126, 139):
+            continue      # (every draw advances the stream; a quarter of them and the three known aborts are run)
+        res = _run(ectx, reads, [ref], mat, n, gapO, gapE, flag=flag, filterd=filterd, maskLen=maskLen)
+        nflag1 += int((res["flag"] == 1).sum())
+    assert nflag1 > 20      # the regime was drawn: most tracebacks end as the reference's failure record
+
+
+def test_empty_target_after_a_flagged_call(ectx, emu_lib_path):
+    """round-4 advisor: a ONE-target batch against an EMPTY target runs no kernel; its records must still be the reference's score-0
+    records (src/ssw.c:900-903), not what the previous call left in the record buffer (a stale cigarLen > 0 used to send the CIGAR download
+    to a NULL pool).  Through the batch ABI and through ssw_align(prof, ref, 0, ...)."""
+    import ctypes as C
+    ref = random_ref(400, 21, 4)
+    rng = np.random.default_rng(21)
+    reads = make_reads(rng, ref, 2, [60, 90], 4, frac_random=0.0)
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=1)
+    res = _run(ectx, reads, [np.zeros(0, dtype=np.int8)], dna_matrix(2, 2), 5, flag=1)
+    assert (res["score1"] == 0).all() and (res["cigarLen"] == 0).all() and (res["ref_begin1"] == -1).all()
+    lib = ssw_amd.load(emu_lib_path)
+    i8p = C.POINTER(C.c_int8)
+    mat = dna_matrix(2, 2)
+    p = lib.ssw_init(reads[0].ctypes.data_as(i8p), len(reads[0]), mat.ctypes.data_as(i8p), 5, 2)
+    a = lib.ssw_align(p, ref.ctypes.data_as(i8p), len(ref), 3, 1, 1, 0, 0, 15)
+    assert a.contents.nScore > 0 and a.contents.nCigarLen > 0
+    lib.align_destroy(a)
+    a = lib.ssw_align(p, ref.ctypes.data_as(i8p), 0, 3, 1, 1, 0, 0, 15)
+    s = a.contents
+    assert (s.nScore, s.nScore2, s.nRefBeg, s.nRefEnd, s.nQryBeg, s.nQryEnd, s.nRefEnd2, s.nCigarLen, s.nFlag) == (0, 0, -1, 0, -1, 0, 0, 0, 0) and not s.sCigar
+    lib.align_destroy(a); lib.init_destroy(p)
+
+
+def test_column_reduction_with_mixed_lengths(ectx, monkeypatch):
+    """round-4 advisor: SSW_GPU_SEG_REDUCE=0 (k_reduce over the columns) with reads of several geometry buckets -- the
+    side-by-side form reduces over group maxima only, so this batch must take the buckets one after the other instead of
+    handing k_reducem a NULL group array."""
+    ref = random_ref(900, 22, 4)
+    rng = np.random.default_rng(22)
+    reads = make_reads(rng, ref, 4, [40, 75, 130, 200], 4)
+    monkeypatch.setenv("SSW_GPU_SEG_REDUCE", "0")
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
+    monkeypatch.delenv("SSW_GPU_SEG_REDUCE")
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
 
 
 def test_bad_arguments_fail_loudly(ectx):

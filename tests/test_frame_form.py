@@ -175,11 +175,12 @@ print("ok", frames)
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("K", ["16", "64"])
-def test_frame_renormalised_often_on_the_gpu(gpu_ctx, K, monkeypatch):
+def test_frame_renormalised_often_on_the_gpu(gpu_hctx, K, monkeypatch):
     """the default period is 1024 steps: tests on kilobase targets would never renormalise on the hardware.  Config 2's first 4000 reads
     against the 1 Mb target (k_fill), 600 long reads (strips + window passes) and a protein search with the frame renormalised every
     16 / 64 steps, against the full-size fixtures / the reference"""
     import workloads as W
+    gpu_ctx = gpu_hctx      # SSW_GPU_FRAME_K is a test hook: libssw_hooks.so (conftest.py)
     monkeypatch.setenv("SSW_GPU_FRAME_K", K)
     z = np.load(os.path.join(HERE, "golden", "full", "config2_block0.npz"))
     ref, reads, p = W.dna_config(2, 0)

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from parity import compare_batch, make_reads
+from parity import compare_batch, free_gap_open_case, make_reads
 from sswutil import RES_FIELDS, blosum50, dna_matrix, encode_dna, random_ref, sample_reads
 
 pytestmark = pytest.mark.gpu
@@ -93,11 +93,12 @@ def test_random_dna_all_flags(gpu_ctx, flag):
 
 
 @pytest.mark.parametrize("fill", ["f16", "int16"])
-def test_random_parameter_sweep(gpu_ctx, fill, monkeypatch):
+def test_random_parameter_sweep(gpu_ctx, gpu_hctx, fill, monkeypatch):
     """short queries take the f16 form of the recurrence when no score can reach 2048 (k_fill<R, true>); the int16 form
     (SSW_GPU_FILL_F16=0) must give the same records"""
     if fill == "int16":
         monkeypatch.setenv("SSW_GPU_FILL_F16", "0")
+        gpu_ctx = gpu_hctx      # (the product library ignores the form-switching hooks: libssw_hooks.so, same kernels object)
     rng = np.random.default_rng(7)
     for _ in range(30):
         kind = "dna" if rng.random() < 0.6 else "aa"
@@ -257,11 +258,12 @@ def test_long_queries_row_strips(gpu_ctx):
 
 @pytest.mark.parametrize("env", [{}, {"SSW_GPU_TRACE_WAVES": "4"}, {"SSW_GPU_TRACE_WAVES": "16"}, {"SSW_GPU_TRACE_LDS": "0"},
                                  {"SSW_GPU_XLANES": "16"}, {"SSW_GPU_XR": "5"}])
-def test_long_read_traceback_teams(gpu_ctx, env, monkeypatch):
+def test_long_read_traceback_teams(gpu_hctx, env, monkeypatch):
     """long reads whose band must grow through several doublings: long indels, and unrelated reads (with 2/-2/3/1 a random
     3-kb read still aligns over most of its length with hundreds of gaps: band rows of > 1000 cells).  Wavefront traceback
     with 1 / 4 / 16 wavefronts per alignment, rows in LDS or HBM, resuming across scratch-negotiation rounds; the strip
     kernel in its other geometries."""
+    gpu_ctx = gpu_hctx      # form-switching hooks: libssw_hooks.so (conftest.py)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     rng = np.random.default_rng(45)
@@ -341,9 +343,22 @@ def test_layout_dependent_gap_regime(gpu_ctx):
              maskLen=int(rng.choice([-1, -1, 15, 10, 40])), ss=int(rng.choice([2, 2, 2, 0, 1])))
 
 
+def test_free_gap_open_with_traceback(gpu_ctx):
+    """gapO = 0 with every flag that asks for a CIGAR (round-4 verdict; the emulator twin is tests/test_emu_pipeline.py): no call may fail,
+    every record and CIGAR -- mostly the reference's `cigarLen 0, flag 1` after the full-band retry -- equals the reference's."""
+    rng = np.random.default_rng(2)
+    nflag1 = nal = 0
+    for it in range(600):
+        reads, ref, mat, n, gapO, gapE, flag, filterd, maskLen = free_gap_open_case(rng)
+        res, _ = _run(gpu_ctx, reads, [ref], mat, n, gapO, gapE, flag=flag, filterd=filterd, maskLen=maskLen)
+        nflag1 += int((res["flag"] == 1).sum()); nal += len(reads)
+    assert nflag1 > nal // 4
+
+
 @pytest.mark.parametrize("wave", ["0", "1"])
-def test_traceback_kernels_and_band_growth(gpu_ctx, wave, monkeypatch):
+def test_traceback_kernels_and_band_growth(gpu_hctx, wave, monkeypatch):
     """per-thread and per-wavefront banded traceback, including alignments whose band must double many times"""
+    gpu_ctx = gpu_hctx      # form-switching hooks: libssw_hooks.so (conftest.py)
     monkeypatch.setenv("SSW_GPU_TRACE_WAVE", wave)
     rng = np.random.default_rng(51)
     ref = random_ref(20000, 52, 4)
@@ -370,9 +385,10 @@ def test_wide_alphabets_route_window_passes_by_lds_need(gpu_ctx, n):
 
 
 @pytest.mark.parametrize("env", [{}, {"SSW_GPU_TRACE_WAVES": "4"}, {"SSW_GPU_TRACE_BLOCKED": "0"}, {"SSW_GPU_TRACE_WAVES": "1"}])
-def test_team_traceback_many_cells_per_thread(gpu_ctx, env, monkeypatch):
+def test_team_traceback_many_cells_per_thread(gpu_hctx, env, monkeypatch):
     """wide bands on traceback teams: several cells per thread, two barriers per row (trace_band_blocked) -- 10-kb-scale reads with
     kilobase insertions / deletions, an unrelated read, band covering the whole target; and the one-cell-per-thread form as control"""
+    gpu_ctx = gpu_hctx      # form-switching hooks: libssw_hooks.so (conftest.py)
     from test_emu_pipeline import team_traceback_cases
     for k, v in env.items():
         monkeypatch.setenv(k, v)

@@ -125,8 +125,8 @@ def test_scores_around_2048_frame_and_int16_forms_emulated(ectx, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_scores_around_2048_frame_and_int16_forms_gpu(gpu_ctx, monkeypatch):
-    _around_2048_check(gpu_ctx, monkeypatch)
+def test_scores_around_2048_frame_and_int16_forms_gpu(gpu_hctx, monkeypatch):
+    _around_2048_check(gpu_hctx, monkeypatch)      # SSW_GPU_DB_FORM / SSW_GPU_FRAME_K: libssw_hooks.so (conftest.py)
 
 
 def _small_budget_check(ctx_factory, monkeypatch, nq):
