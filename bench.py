@@ -6,6 +6,7 @@ that rank r of an N-GPU run works on block r of ONE read set):
 
   2 (default)  100k x 150 bp DNA reads vs a 1 Mb target, 2/-2/3/1, score_size 2, score only            [the metric's config]
   3            150 bp reads vs a 5 Mb target, sharded by read block: 20k-read blocks (the stated subsample of the 1M reads)
+  3 --full     the same at its STATED size: all 50 blocks = 1M reads, 7.5e14 cells, divided over the ranks (strong scaling), per-block parity
   4            10k x 10 kb reads vs a 100 kb target, flag 2 (begin positions + CIGAR: banded traceback on the GPU), maskLen 5000
   5            50k protein queries (~300 aa) vs a 10k-entry DB, BLOSUM50 3/1, score only, results streamed (ssw_gpu_search_db)
 
@@ -142,12 +143,18 @@ def parse_args(argv=None):
     ap.add_argument("--also", default=None,
                     help="comma-separated other BASELINE configs run for 2 steps each AFTER the timed region and attached to the line as "
                          "`also` (default: 3,4,5 when the metric's config runs as stated on one GPU; 'none' to skip)")
+    ap.add_argument("--full", action="store_true",
+                    help="config 3 at its STATED size: the 1M reads = 50 read blocks of 20 000, all of them, divided over the ranks (block b on rank b mod N: "
+                         "strong scaling -- the 1/2/4/8-GPU lines are the same job); a step is one pass over all blocks")
+    ap.add_argument("--blocks", type=int, default=50, help="--full: read blocks of the job (default 50 = 1M reads)")
     ap.add_argument("--lib", default=None, help=argparse.SUPPRESS)   # tests point this at the emulated library
     a = ap.parse_args(argv)
     a.quiet = False
     a.custom = any(getattr(a, k) is not None for k in ("read_len", "ref_len", "sub", "indel")) or (a.match, a.mismatch, a.gap_open, a.gap_extend) != (2, 2, 3, 1)
+    if a.full and a.config != 3:
+        ap.error("--full is config 3 at its stated size (use --config 3 --full)")
     if a.steps is None:
-        a.steps = {2: 2, 3: 2, 4: 1, 5: 1, 6: 5}[a.config]
+        a.steps = 1 if a.full else {2: 2, 3: 2, 4: 1, 5: 1, 6: 5}[a.config]
     if a.warmup is None:
         a.warmup = 1
     return a
@@ -504,6 +511,197 @@ def bench_dna(args, world, rank, local_rank, dist):
     return out, res
 
 
+# ====================================================================================================== config 3 at its stated size
+def full_fixture(block):
+    """-> (read indices, reference records, CIGAR hashes) of the committed sample of read block `block` of config 3, or None:
+    blocks 0..7 carry 2 000 sampled reads each (config3_blocks_sample.npz), blocks 8..49 500 each (config3_blocks_sample_8_49.npz)"""
+    for name in ("config3_blocks_sample.npz", "config3_blocks_sample_8_49.npz"):
+        path = os.path.join(FULL, name)
+        if not os.path.exists(path):
+            continue
+        z = np.load(path)
+        first = int(z["meta"][3]) if len(z["meta"]) > 3 else 0
+        if first <= block < first + len(z["idx"]):
+            return z["idx"][block - first], z["fields"][block - first], z["cigar_fnv"][block - first], name
+    return None
+
+
+def bench_config3_full(args, world, rank, local_rank, dist):
+    """BASELINE config 3 as stated: 1M x 150 bp reads (50 seeded blocks of 20 000) against the 5 Mb target, score only.  The read blocks are
+    divided over the ranks (block b on rank b mod N), the target is replicated, there is no collective: total work is fixed, so the lines
+    of 1, 2, 4 and 8 GPUs are the same job (strong scaling).  A step = one pass over every block of the rank through ONE context.
+    `value`: the blocks resident in HBM when the timed region starts (the bench contract).  `value_with_h2d` (one GPU): the reads start on
+    the host and a feeder thread uploads block i + 1 while block i is being aligned (the streamed form of SURVEY 8d)."""
+    import ctypes as C
+    import threading
+    import ssw_amd
+    import workloads as W
+    from sswutil import dna_matrix, random_ref, ref_lib, _ptr, i8p, i32p, i64p
+    lib = ssw_amd.load(args.lib)
+    if lib.ssw_gpu_device_count() < 1:
+        raise RuntimeError("bench.py: no HIP device visible; libssw.so has no CPU path")
+    ndev = lib.ssw_gpu_device_count()
+    preset = dict(W.DNA_CONFIGS[3])
+    p = dict(preset)
+    for k, a in (("reads", args.reads), ("read_len", args.read_len), ("ref_len", args.ref_len)):
+        if a is not None:
+            p[k] = a
+    stated = all(p[k] == preset[k] for k in ("reads", "read_len", "ref_len")) and not args.custom and args.blocks == 50
+    nblocks, nreads, rlen = args.blocks, p["reads"], p["read_len"]
+    mine = [b for b in range(nblocks) if b % world == rank]
+    ref = random_ref(p["ref_len"], p["seed_ref"], 4)
+    mat = dna_matrix(args.match, args.mismatch)
+    off = np.arange(nreads + 1, dtype=np.int64) * rlen
+    host = {b: np.ascontiguousarray(W.make_reads_fast(ref, nreads, rlen, seed=p["seed_reads"] + b, sub=p["sub"], ins=p["indel"], dele=p["indel"]).reshape(-1))
+            for b in mine}
+    ctx = ssw_amd.Context(local_rank % ndev, lib)
+    budget = ctx.set_exclusive() if own_device(args, world, lib) else int(lib.ssw_gpu_get_budget(ctx.h))
+    T = ctx.upload([ref])
+
+    def upload(b):
+        qh = lib.ssw_gpu_seqs_upload(ctx.h, host[b].ctypes.data_as(C.POINTER(C.c_int8)), off.ctypes.data_as(C.POINTER(C.c_int64)), nreads)
+        if not qh:
+            raise RuntimeError(ctx.error())
+        Q = ssw_amd.Seqs.__new__(ssw_amd.Seqs); Q.ctx = ctx; Q.count = nreads; Q.h = qh
+        return Q
+
+    def align(Q):
+        return ctx.align_batch(Q, T, mat, 5, args.gap_open, args.gap_extend, 0, 0, 0, p["mask_len"], 2, want_cigar=False)[0]
+
+    resident = {b: upload(b) for b in mine}
+    for _ in range(args.warmup):      # one block, untimed: allocations, code objects
+        if mine:
+            align(resident[mine[0]])
+    if dist is not None:
+        dist.barrier()
+    acc = {"fill_ms": 0.0, "fill_launches": 0, "fill_cells": 0, "reduce_ms": 0.0, "locate_ms": 0.0, "trace_ms": 0.0, "total_ms": 0.0, "n_word": 0, "n_byte": 0}
+    results = {}
+    tm = None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for b in mine:
+            results[b] = align(resident[b])      # (returns with the records on the host)
+            tm = ctx.timing()
+            for k in acc:
+                acc[k] += tm[k]
+    if dist is not None:
+        dist.barrier()
+    dt = max_over_ranks(dist, time.perf_counter() - t0)
+    for Q in resident.values():
+        Q.free()
+    cells_job = float(nblocks) * nreads * rlen * p["ref_len"]
+    value = cells_job * args.steps / dt / 1e9
+
+    # ---- the streamed form (one GPU): reads on the host, block i + 1 uploaded by a feeder thread while block i is aligned
+    streamed = None
+    if world == 1 and not args.quiet and mine:
+        nxt = {}
+
+        def feed(b):
+            nxt[b] = upload(b)
+        t1 = time.perf_counter()
+        feed(mine[0])
+        for i, b in enumerate(mine):
+            th = None
+            if i + 1 < len(mine):
+                th = threading.Thread(target=feed, args=(mine[i + 1],)); th.start()
+            r = align(nxt[b])
+            if th is not None:
+                th.join()
+            nxt.pop(b).free()
+            if not (result_fields(r[:, 0]) == result_fields(results[b][:, 0])).all():
+                raise RuntimeError("bench.py: the streamed pass gave other records than the resident pass (block %d)" % b)
+        streamed = cells_job / (time.perf_counter() - t1) / 1e9
+
+    # ---- parity: every block of this rank against the committed reference sample of THAT block
+    checked = []
+    for b in mine:
+        fx = full_fixture(b) if stated else None
+        if fx is None:
+            continue
+        idx, exp, exph, name = fx
+        bad, what = compare_with_reference_records(results[b][idx, 0], None, exp, exph, 0)
+        checked.append({"block": b, "sample": int(len(idx)), "mismatching_alignments": bad, "against": name})
+    R = ref_lib()
+    cpu = None
+    if not stated and R is not None and args.cpu_sample != 0 and mine:      # a shape without fixtures (tests): the first reads of every block through the reference
+        for b in mine:
+            ns = min(nreads, 4)
+            cres = np.zeros((ns, 10), dtype=np.int32)
+            R.refwrap_bench(_ptr(host[b], i8p), _ptr(off, i64p), ns, _ptr(ref, i8p), len(ref), _ptr(mat, i8p), 5, args.gap_open, args.gap_extend,
+                            0, 0, 0, p["mask_len"], 1, _ptr(cres, i32p))
+            bad = int((result_fields(results[b][:ns, 0]) != cres[:, :9]).any(axis=1).sum())
+            checked.append({"block": b, "sample": ns, "mismatching_alignments": bad, "against": "the unmodified reference (oracle/_ref) run by this rank"})
+    if rank == 0 and R is not None and args.cpu_sample != 0 and mine:
+        cores = usable_cores()
+        b0 = mine[0]
+
+        def cpu_run(k, threads):
+            cres = np.zeros((k, 10), dtype=np.int32)
+            return R.refwrap_bench(_ptr(host[b0], i8p), _ptr(off, i64p), k, _ptr(ref, i8p), len(ref), _ptr(mat, i8p), 5, args.gap_open, args.gap_extend,
+                                   0, 0, 0, p["mask_len"], threads, _ptr(cres, i32p))
+        if args.cpu_sample > 0:
+            ns = min(args.cpu_sample, nreads)
+        else:
+            pilot = min(nreads, cores)
+            ns = int(min(nreads, max(pilot, pilot / max(cpu_run(pilot, cores), 1e-3) * 15.0)))
+        secs = cpu_run(ns, cores)
+        g = float(ns) * rlen * p["ref_len"] / secs / 1e9
+        cpu = {"value": round(g, 2), "unit": "GCUPS", "cores": cores, "kind": "reference", "per_core": round(g / cores, 2),
+               "sample": "first %d reads of block %d vs the same target, ssw_init(...,2)+ssw_align through the C API, reference ssw.c built -O2 "
+                         "(oracle/_ref), one thread per core, %.1f s; the whole job at this rate: %.1f h" % (ns, b0, secs, cells_job / (g * 1e9) / 3600.0)}
+    all_checked = [x for lst in gather_objects(dist, world, checked) for x in lst]
+    all_acc = gather_objects(dist, world, acc)
+    out = None
+    if rank == 0:
+        fill_s = sum(a["fill_ms"] for a in all_acc) * 1e-3 / world      # mean over the ranks (they work side by side)
+        launches = sum(a["fill_launches"] for a in all_acc)
+        ops = tm["fill_ops_per_row"] if tm else 6.5
+        real = cells_job * args.steps * ops / 2.0 / (fill_s * world) if fill_s > 0 else 0.0      # per GPU
+        launch_ms = sum(a["fill_ms"] for a in all_acc) / max(1, launches)
+        out = {"metric": "GCUPS", "value": round(value, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "int16x2 in a column frame (value + phi(column); 32-bit adds on the packed pair, three-input maxima on the bit patterns); reference u8/int16 semantics",
+               "data": "synthetic",
+               "config": {"workload": "%s: %d x %d bp reads (%d seeded blocks of %d) vs %.3g Mb target; %d/-%d/%d/%d, score_size 2, flag 0"
+                                      % ("BASELINE config 3 at its stated size" if stated else "config-3 generator, block job", nblocks * nreads, rlen, nblocks, nreads, p["ref_len"] / 1e6, args.match, args.mismatch, args.gap_open, args.gap_extend),
+                          "baseline_config": 3, "reads": nblocks * nreads, "read_blocks": nblocks, "reads_per_block": nreads, "read_len": rlen, "ref_len": p["ref_len"],
+                          "cells": cells_job, "blocks_per_gpu": [len([b for b in range(nblocks) if b % world == r]) for r in range(world)],
+                          "scratch_budget_gib": round(budget / 2.0 ** 30, 1),
+                          "sharding": "read block b on rank b mod N, target replicated, no collective; a step = one pass over all blocks (total work fixed)"},
+               "value_note": "whole-job rate with every read block resident in HBM when the timed region starts (the bench contract); value_with_h2d: reads on the "
+                             "host, block i+1 uploaded by a second thread on the context's upload stream while block i is aligned",
+               "mix": {"word_rules": int(sum(a["n_word"] for a in all_acc)), "byte_rules": int(sum(a["n_byte"] for a in all_acc))},
+               "phases_ms_per_step": {k2: round(sum(a[k1] for a in all_acc) / world / args.steps, 3) for k1, k2 in
+                                      (("fill_ms", "fill"), ("locate_ms", "locate"), ("trace_ms", "trace"), ("reduce_ms", "reduce_and_copies"))},
+               "roofline": {"bound": "valu-issue", "kernel": tm["fill_kernel"] if tm else None, "achieved": round(real / 1e12, 3), "peak": round(VALU_PEAK_LANEOPS / 1e12, 2),
+                            "unit": "T lane-op/s per GPU", "frac": round(real / VALU_PEAK_LANEOPS, 4),
+                            "frac_of_isa_ideal": round(real / VALU_PEAK_LANEOPS * (CYCLES_PER_PAIR_ROW_ISA_IDEAL / CYCLES_PER_PAIR_ROW_4CYCLE if ops == 6.5 else 1.0), 4),
+                            "ops_per_pair_row": ops, "launch_ms": round(launch_ms, 3), "launches": int(launches), "traffic": None,
+                            "peak_note": "VALU issue of the fill kernel's recurrence on readLen x refLen cells, as on the default line (DESIGN.md 4); traffic: see the "
+                                         "default line's roofline_hbm (same kernel, PMC passes in profiles/)"}}
+        if streamed is not None:
+            out["value_with_h2d"] = round(streamed, 2)
+        if all_checked:
+            out["parity"] = {"sample": int(sum(x["sample"] for x in all_checked)), "mismatching_alignments": int(sum(x["mismatching_alignments"] for x in all_checked)),
+                             "blocks_checked": len(all_checked), "blocks": nblocks,
+                             "fields": "score1 score2 ref_end1 read_end1 ref_end2 (+ begins -1, no CIGAR) vs the flag-2 reference records" if stated else "all record fields",
+                             "against": "tests/golden/full/config3_blocks_sample.npz (blocks 0..7, 2 000 sampled reads each) and config3_blocks_sample_8_49.npz "
+                                        "(blocks 8..49, 500 each): unmodified reference (oracle/_ref) on the same seeded reads" if stated else
+                                        "the unmodified reference (oracle/_ref) on the first reads of every block",
+                             "per_block": all_checked if not stated else [x for x in all_checked if x["mismatching_alignments"]]}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if not args.quiet:
+            print(json.dumps(out))
+            sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    T.free(); ctx.close()
+    return out, results
+
+
 # ====================================================================================================== config 5
 def bench_db(args, world, rank, local_rank, dist):
     """BASELINE config 5: every protein query against every DB entry, BLOSUM50, gaps 3/1, score only; the 5e8 records of the
@@ -756,6 +954,8 @@ def main(argv=None):
         self_launch(args, argv)
     if args.config == 5:
         return bench_db(args, world, rank, local_rank, dist)
+    if args.full:
+        return bench_config3_full(args, world, rank, local_rank, dist)
     return bench_dna(args, world, rank, local_rank, dist)
 
 

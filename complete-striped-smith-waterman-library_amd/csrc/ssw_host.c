@@ -72,6 +72,7 @@ struct ssw_gpu_ctx {
 	int device;
 	void* stream;
 	void* stream2;                      /* reductions of chunk i overlap the fill of chunk i+1 */
+	void* ustream;                      /* sequence uploads / translation (ssw_gpu_seqs_*): beside a running batch call, see upload_stream() */
 	void* tstream[SSW_TSTREAMS]; void* tev[SSW_TSTREAMS];   /* traceback classes of one negotiation round run side by side */
 	void *ev_fill[2], *ev_red[2];
 	char err[512];
@@ -288,10 +289,25 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
 	ssw_shim_event_destroy(c->ev_c); ssw_shim_event_destroy(c->ev_d); ssw_shim_event_destroy(c->ev_db);
 	for (int i = 0; i < 2; ++i) { ssw_shim_event_destroy(c->ev_fill[i]); ssw_shim_event_destroy(c->ev_red[i]); }
-	ssw_shim_stream_destroy(c->stream2);
+	ssw_shim_stream_destroy(c->stream2); ssw_shim_stream_destroy(c->ustream);
 	for (int i = 0; i < SSW_TSTREAMS; ++i) { ssw_shim_stream_destroy(c->tstream[i]); ssw_shim_event_destroy(c->tev[i]); }
 	ssw_shim_stream_destroy(c->stream);
 	free(c);
+}
+
+/* Sequence sets are uploaded (and translated / reverse-complemented) on a stream of their own, created with the first upload: ONE other
+   thread may prepare the next block of reads on a context while a batch call runs on it (streaming callers: bench.py --config 3 --full,
+   the three-stage ssw_test_gpu) and the copy does not queue behind that call's kernels.  Every ssw_gpu_seqs_* call returns with its stream
+   synchronised, so a later batch call on the main stream sees the data.  (The single-pair path never gets here: its contexts keep one
+   stream) */
+static void* upload_stream(ssw_gpu_ctx* c)
+{
+	if (!c->ustream) {
+		/* (after the side streams: the launch plans of a batch call know which hardware queue each of THOSE lands on by creation order) */
+		(void)ctx_side_streams(c);
+		c->ustream = ssw_shim_stream_create();
+	}
+	return c->ustream ? c->ustream : c->stream;
 }
 
 /* host-side shell of a sequence set + its two device arrays (codes, offsets); NULL with the error set on failure */
@@ -316,9 +332,10 @@ ssw_gpu_seqs* ssw_gpu_seqs_upload(ssw_gpu_ctx* c, const int8_t* codes, const int
 	ssw_shim_set_device(c->device);
 	ssw_gpu_seqs* s = seqs_new(c, offsets, count);
 	if (!s) return 0;
-	if (ssw_shim_h2d(s->d_codes, codes + offsets[0], (size_t)s->total, c->stream) ||
-	    ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * ((size_t)count + 1), c->stream) ||
-	    ssw_shim_stream_sync(c->stream)) {
+	void* const us = upload_stream(c);
+	if (ssw_shim_h2d(s->d_codes, codes + offsets[0], (size_t)s->total, us) ||
+	    ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * ((size_t)count + 1), us) ||
+	    ssw_shim_stream_sync(us)) {
 		fail(c, "upload failed: %s", ssw_shim_last_error()); ssw_gpu_seqs_free(s); return 0;
 	}
 	return s;
@@ -337,15 +354,16 @@ ssw_gpu_seqs* ssw_gpu_seqs_upload_ascii(ssw_gpu_ctx* c, const char* text, const 
 	ssw_shim_set_device(c->device);
 	ssw_gpu_seqs* s = seqs_new(c, offsets, count);
 	if (!s) return 0;
+	void* const us = upload_stream(c);
 	uint8_t* d_text = (uint8_t*)ssw_shim_malloc((size_t)s->total + 64);
 	int8_t* d_tab = (int8_t*)ssw_shim_malloc(128);
 	int ok = d_text && d_tab;
 	if (ok) {
 		ssw_prep_args pa; memset(&pa, 0, sizeof pa);
 		pa.text = d_text; pa.table = d_tab; pa.off = s->d_off; pa.count = count; pa.total = s->total; pa.out = s->d_codes; pa.mode = 0;
-		ok = !(ssw_shim_h2d(d_text, text + offsets[0], (size_t)s->total, c->stream) || ssw_shim_h2d(d_tab, table128, 128, c->stream) ||
-		       ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * ((size_t)count + 1), c->stream) ||
-		       ssw_shim_launch_prep(&pa, c->stream) || ssw_shim_stream_sync(c->stream));
+		ok = !(ssw_shim_h2d(d_text, text + offsets[0], (size_t)s->total, us) || ssw_shim_h2d(d_tab, table128, 128, us) ||
+		       ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * ((size_t)count + 1), us) ||
+		       ssw_shim_launch_prep(&pa, us) || ssw_shim_stream_sync(us));
 	}
 	ssw_shim_free(d_text); ssw_shim_free(d_tab);
 	if (!ok) { fail(c, "ascii upload failed: %s", ssw_shim_last_error()); ssw_gpu_seqs_free(s); return 0; }
@@ -358,10 +376,11 @@ ssw_gpu_seqs* ssw_gpu_seqs_revcomp(ssw_gpu_ctx* c, const ssw_gpu_seqs* in)
 	ssw_shim_set_device(c->device);
 	ssw_gpu_seqs* s = seqs_new(c, in->h_off, in->count);
 	if (!s) return 0;
+	void* const us = upload_stream(c);
 	ssw_prep_args pa; memset(&pa, 0, sizeof pa);
 	pa.codes_in = in->d_codes; pa.off = in->d_off; pa.count = in->count; pa.total = in->total; pa.out = s->d_codes; pa.mode = 1;
-	if (ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * ((size_t)in->count + 1), c->stream) ||
-	    ssw_shim_launch_prep(&pa, c->stream) || ssw_shim_stream_sync(c->stream)) {
+	if (ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * ((size_t)in->count + 1), us) ||
+	    ssw_shim_launch_prep(&pa, us) || ssw_shim_stream_sync(us)) {
 		fail(c, "revcomp failed: %s", ssw_shim_last_error()); ssw_gpu_seqs_free(s); return 0;
 	}
 	return s;

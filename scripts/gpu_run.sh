@@ -37,7 +37,7 @@ for step in "$@"; do
     bench:*) IFS=: read -r _ name args <<< "$step"; bench "$name" ${args//+/ } ;;
     config6)
       bench c6 --config 6
-      SSW_LIB=$PKG/libssw_hooks.so SSW_GPU_SERIAL_BUCKETS=1 bench c6_serial_buckets --config 6 --cpu-sample 0
+      SSW_LIB=$PWD/complete-striped-smith-waterman-library_amd/libssw_hooks.so SSW_GPU_SERIAL_BUCKETS=1 bench c6_serial_buckets --config 6 --cpu-sample 0
       bench c6_m1x3o5e2 --config 6 --match 1 --mismatch 3 --gap-open 5 --gap-extend 2
       bench c6_flag2 --config 6 --flag 2 --cpu-sample 0 ;;
     overlap4)

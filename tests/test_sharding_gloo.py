@@ -50,6 +50,42 @@ def test_two_rank_bench_over_gloo(emu_lib_path, tmp_path):
     assert seen[0] != seen[1]                   # the ranks really worked on different shards
 
 
+def test_eight_rank_strong_scaling_job_over_gloo(emu_lib_path):
+    """bench.py --config 3 --full at the node's size: 8 ranks over gloo, the job's read blocks divided over them (block b on rank b mod 8:
+    a fixed job, strong scaling), every block of every rank checked against the reference, one line from rank 0.  Toy shapes on the
+    emulator; the same code path as the 1M-read job on 1..8 MI355X."""
+    env = dict(os.environ, SSW_BENCH_BACKEND="gloo", SSW_EMU_DEVICES="8", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "3", "--full", "--blocks", "12",
+           "--steps", "1", "--warmup", "1", "--reads", "3", "--ref-len", "2500", "--read-len", "70", "--cpu-sample", "2", "--lib", emu_lib_path]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["metric"] == "GCUPS" and out["value"] >= 0
+    assert out["config"]["read_blocks"] == 12 and out["config"]["blocks_per_gpu"] == [2, 2, 2, 2, 1, 1, 1, 1] and out["config"]["reads"] == 36
+    assert out["config"]["cells"] == 12 * 3 * 70 * 2500
+    assert "value_with_h2d" not in out            # (the streamed pass is the one-GPU line's)
+    if "parity" in out:                           # (needs oracle/_ref)
+        assert out["parity"]["blocks_checked"] == 12 and out["parity"]["mismatching_alignments"] == 0
+        assert sorted(x["block"] for x in out["parity"]["per_block"]) == list(range(12))
+
+
+def test_full_job_on_one_rank_streams_its_blocks(emu_lib_path):
+    """the one-GPU line of the same job: all blocks through one context, then once more with the reads on the host and the next block
+    uploaded by a feeder thread while the current one is aligned (same records, checked inside bench.py)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--full", "--blocks", "5", "--steps", "1", "--warmup", "1", "--reads", "3",
+           "--ref-len", "2500", "--read-len", "70", "--cpu-sample", "2", "--lib", emu_lib_path]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["scaling"] == "strong" and out["config"]["blocks_per_gpu"] == [5] and out["value_with_h2d"] >= 0
+    assert out["roofline"]["bound"] == "valu-issue" and out["roofline"]["launches"] == 5
+    if "parity" in out:
+        assert out["parity"]["blocks_checked"] == 5 and out["parity"]["mismatching_alignments"] == 0
+
+
 def test_two_rank_database_search_over_gloo(emu_lib_path):
     """config-5 mode under two ranks: every rank streams its own query block against the replicated DB (no collective on the
     data path), rank 0 prints the one aggregated line"""

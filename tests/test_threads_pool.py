@@ -117,6 +117,14 @@ def test_pool_two_workers_emulated(emu_lib_path, monkeypatch):
     assert all(s["blocks"] > 0 for s in st)          # both queues did work
 
 
+def test_pool_eight_workers_emulated(emu_lib_path, monkeypatch):
+    """the per-GPU work queues at the node's size: 8 workers on 8 pretend-devices (an 8 x MI355X node), 40 blocks of reads"""
+    monkeypatch.setenv("SSW_EMU_DEVICES", "8")
+    st = _pool_vs_single(ssw_amd.load(emu_lib_path), None, nreads=80, reflen=500, block=2)
+    assert len(st) == 8 and [s["device"] for s in st] == list(range(8))
+    assert sum(1 for s in st if s["blocks"] > 0) >= 4      # the queues really spread the blocks (which worker wins a block is a race)
+
+
 def test_pool_rejects_bad_use(emu_lib_path):
     lib = ssw_amd.load(emu_lib_path)
     pool = ssw_amd.Pool([0], lib)
