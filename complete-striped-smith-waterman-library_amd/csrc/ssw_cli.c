@@ -3,8 +3,10 @@
  * reference's ssw_test (reference src/main.c:395-547; output formats of ssw_write, src/main.c:118-245), SURVEY 8f-1.
  *
  * What differs from the reference CLI is only the loop structure: the target file is parsed ONCE and stays resident
- * in HBM, reads are taken in batches, and each batch is one ssw_gpu_align_batch() call (two with -r) instead of
- * reads x targets synchronous ssw_align() calls.  Output order is the reference's: reads outer, targets inner.
+ * in HBM, reads are taken in batches, and each batch is ONE ssw_gpu_align_batch() call (with -r: both orientations as one
+ * batch of 2 N queries) instead of reads x targets synchronous ssw_align() calls.  Three stages run on three threads with two
+ * batches in flight between them: parse | upload + translate on the device + align | format + write, so the host work hides
+ * behind the device.  Output order is the reference's: reads outer, targets inner.
  *
  *   ssw_test_gpu [-m N] [-x N] [-o N] [-e N] [-p] [-a FILE] [-c] [-f N] [-r] [-s] [-h] <target.fa> <query.fa|fq>
  */
@@ -46,6 +48,12 @@ static const int8_t blosum50[24 * 24] = {
 };
 
 static int8_t aa_code[128], nt_code[128];
+
+/* SSW_CLI_TRACE=1: wall-clock of the run's milestones on stderr (where an end-to-end run spends its time beside the device) */
+static int cli_trace_on;
+static double cli_t0;
+static double cli_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+#define CLI_TRACE(...) do { if (cli_trace_on) { fprintf(stderr, "[ssw_test_gpu %8.3f s] ", cli_now() - cli_t0); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
 
 static void init_tables(void)
 {
@@ -232,6 +240,165 @@ static int load_matrix(const char* path, int8_t** mat, int32_t* n)
 	return 0;
 }
 
+/* ---------------------------------------------------------------- the three-stage pipeline */
+#include <pthread.h>
+/* one batch of reads on its way through the stages */
+typedef struct {
+	int32_t nr; int64_t total;
+	record* reads;               /* parsed records (names, ASCII sequences, qualities) */
+	int64_t* qoff;               /* nr + 1 offsets into qtext */
+	char* qtext;                 /* the reads' residues back to back: what is uploaded; translation to codes happens on the device */
+	ssw_gpu_result* res;         /* nr x nt records ('+' strand), with -r followed by nr x nt of the reverse complements */
+	uint32_t* pool; int64_t words;
+	int fatal;                   /* non-zero: the run ends with this exit code (message already printed) */
+} work;
+
+#define QUEUE_DEPTH 2            /* batches in flight between two stages */
+typedef struct { void* item[QUEUE_DEPTH]; int head, count, closed; pthread_mutex_t mu; pthread_cond_t cv; } queue;
+static void queue_init(queue* q) { memset(q, 0, sizeof *q); pthread_mutex_init(&q->mu, 0); pthread_cond_init(&q->cv, 0); }
+static void queue_push(queue* q, void* it)      /* it == NULL: no more items */
+{
+	pthread_mutex_lock(&q->mu);
+	if (!it) q->closed = 1;
+	else {
+		while (q->count == QUEUE_DEPTH) pthread_cond_wait(&q->cv, &q->mu);
+		q->item[(q->head + q->count++) % QUEUE_DEPTH] = it;
+	}
+	pthread_cond_broadcast(&q->cv);
+	pthread_mutex_unlock(&q->mu);
+}
+static void* queue_pop(queue* q)                /* NULL: closed and drained */
+{
+	pthread_mutex_lock(&q->mu);
+	while (q->count == 0 && !q->closed) pthread_cond_wait(&q->cv, &q->mu);
+	void* it = 0;
+	if (q->count > 0) { it = q->item[q->head]; q->head = (q->head + 1) % QUEUE_DEPTH; --q->count; }
+	pthread_cond_broadcast(&q->cv);
+	pthread_mutex_unlock(&q->mu);
+	return it;
+}
+
+typedef struct {
+	const char* qfile; int32_t batch; int reverse, reverse_fatal; const int8_t* table; int nt_table;
+	ssw_gpu_ctx* g; ssw_gpu_pool* gp; ssw_gpu_seqs* T; int32_t nt;
+	ssw_gpu_params prm;
+	queue parsed, aligned;
+} pipeline;
+
+static void free_work(work* w, int reverse)
+{
+	(void)reverse;
+	for (int32_t q = 0; q < w->nr; ++q) free_record(&w->reads[q]);
+	free(w->reads); free(w->qoff); free(w->qtext); free(w->res); free(w->pool); free(w);
+}
+
+/* stage 1: the query file -> batches of records + one ASCII block per batch.  The first batches are small so that the device starts
+   early (the parse of a full batch would otherwise stand in front of the whole run), then `batch` reads each. */
+static void* stage_parse(void* arg)
+{
+	pipeline* pl = (pipeline*)arg;
+	reader* qr = (reader*)xmalloc(sizeof(reader)); memset(qr, 0, sizeof *qr);
+	qr->f = gzopen(pl->qfile, "r");
+	if (!qr->f) { fprintf(stderr, "gzopen of '%s' failed.\n", pl->qfile); exit(EXIT_FAILURE); }
+	gzbuffer(qr->f, 1 << 20);
+	int32_t ramp = pl->batch < 4096 ? pl->batch : 4096;
+	for (int first = 1; ; first = 0) {
+		work* w = (work*)xmalloc(sizeof(work)); memset(w, 0, sizeof *w);
+		int32_t cap = ramp;
+		w->reads = (record*)xmalloc(sizeof(record) * (size_t)cap);
+		while (w->nr < cap && read_record(qr, &w->reads[w->nr])) { w->total += w->reads[w->nr].len; ++w->nr; }
+		if (w->nr == 0) { free(w->reads); free(w); break; }
+		if (first && pl->reverse_fatal) {      /* reference src/main.c:483-486: the run stops at the first read */
+			fprintf(stderr, "Reverse complement alignment is not available for protein sequences. \n");
+			w->fatal = 1; queue_push(&pl->parsed, w); break;
+		}
+		w->qoff = (int64_t*)xmalloc(sizeof(int64_t) * ((size_t)w->nr + 1));
+		w->qtext = (char*)xmalloc((size_t)w->total + 1);
+		w->qoff[0] = 0;
+		for (int32_t q = 0; q < w->nr; ++q) {
+			memcpy(w->qtext + w->qoff[q], w->reads[q].seq, (size_t)w->reads[q].len);
+			w->qoff[q + 1] = w->qoff[q] + w->reads[q].len;
+		}
+		CLI_TRACE("parsed a batch of %d reads", w->nr);
+		const int short_batch = w->nr < cap;      /* (w belongs to the next stage once it is pushed) */
+		queue_push(&pl->parsed, w);
+		if (short_batch) break;
+		if (ramp < pl->batch) ramp = (int64_t)ramp * 4 < pl->batch ? ramp * 4 : pl->batch;
+	}
+	queue_push(&pl->parsed, 0);
+	gzclose(qr->f); free(qr);
+	return 0;
+}
+
+/* stage 2: upload (ASCII: the translation to residue codes runs on the device), with -r the reverse complements on the device too and
+   both orientations as ONE batch of 2 N queries, then the batch call.  One thread is enough here: an upload is a fraction of a
+   millisecond per megabyte against seconds of alignment -- what has to overlap with the device are the two HOST stages. */
+static void* stage_device(void* arg)
+{
+	pipeline* pl = (pipeline*)arg;
+	const int32_t nt = pl->nt;
+	for (;;) {
+		work* w = (work*)queue_pop(&pl->parsed);
+		if (!w) break;
+		if (w->fatal) { queue_push(&pl->aligned, w); break; }
+		const int32_t nr = w->nr, sets = pl->reverse ? 2 : 1;
+		w->res = (ssw_gpu_result*)xmalloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1) * (size_t)sets);
+		if (pl->gp) {      /* -g N: reads stay on the host (codes: the workers upload the blocks they take); both orientations as one batch of 2 N */
+			int8_t* codes = (int8_t*)xmalloc((size_t)w->total * (size_t)sets + 1);
+			int64_t* off2 = (int64_t*)xmalloc(sizeof(int64_t) * ((size_t)nr * (size_t)sets + 1));
+			for (int64_t i = 0; i < w->total; ++i) codes[i] = pl->table[(int)w->qtext[i] & 127];
+			for (int32_t q = 0; q <= nr; ++q) off2[q] = w->qoff[q];
+			if (pl->reverse) {
+				char* tmp = 0; size_t cap = 0;
+				for (int32_t q = 0; q < nr; ++q) {
+					const int32_t len = w->reads[q].len;
+					if (cap < (size_t)len + 1) { cap = (size_t)len * 2 + 64; tmp = (char*)xrealloc(tmp, cap); }
+					reverse_complement(w->reads[q].seq, len, tmp);
+					for (int32_t i = 0; i < len; ++i) codes[w->total + w->qoff[q] + i] = pl->table[(int)tmp[i] & 127];
+					off2[nr + q + 1] = w->total + w->qoff[q + 1];
+				}
+				free(tmp);
+			}
+			if (ssw_gpu_pool_align(pl->gp, codes, off2, nr * sets, 0, 0, nt, &pl->prm, w->res, &w->pool, &w->words)) {
+				fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_pool_last_error(pl->gp)); exit(EXIT_FAILURE);
+			}
+			free(codes); free(off2);
+		} else {
+			ssw_gpu_seqs* Qs = ssw_gpu_seqs_upload_ascii(pl->g, w->qtext, w->qoff, nr, pl->table);
+			ssw_gpu_seqs* Qa = Qs;
+			if (Qs && pl->reverse) {
+				if (pl->nt_table) Qa = ssw_gpu_seqs_with_revcomp(pl->g, Qs);
+				else {      /* a matrix file's own letter table: the complement is taken on the text (reference src/main.c:95-116), both orientations uploaded as text */
+					char* text2 = (char*)xmalloc((size_t)w->total * 2 + 1);
+					int64_t* off2 = (int64_t*)xmalloc(sizeof(int64_t) * ((size_t)nr * 2 + 1));
+					memcpy(text2, w->qtext, (size_t)w->total);
+					for (int32_t q = 0; q <= nr; ++q) off2[q] = w->qoff[q];
+					char* tmp = 0; size_t cap = 0;
+					for (int32_t q = 0; q < nr; ++q) {
+						const int32_t len = w->reads[q].len;
+						if (cap < (size_t)len + 1) { cap = (size_t)len * 2 + 64; tmp = (char*)xrealloc(tmp, cap); }
+						reverse_complement(w->reads[q].seq, len, tmp);
+						memcpy(text2 + w->total + w->qoff[q], tmp, (size_t)len);
+						off2[nr + q + 1] = w->total + w->qoff[q + 1];
+					}
+					free(tmp);
+					Qa = ssw_gpu_seqs_upload_ascii(pl->g, text2, off2, 2 * nr, pl->table);
+					free(text2); free(off2);
+				}
+			}
+			if (!Qs || !Qa || ssw_gpu_align_batch(pl->g, Qa, pl->T, 0, nt, &pl->prm, w->res, &w->pool, &w->words)) {
+				fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(pl->g)); exit(EXIT_FAILURE);
+			}
+			if (Qa != Qs) ssw_gpu_seqs_free(Qa);
+			ssw_gpu_seqs_free(Qs);
+		}
+		CLI_TRACE("aligned a batch of %d reads", nr);
+		queue_push(&pl->aligned, w);
+	}
+	queue_push(&pl->aligned, 0);
+	return 0;
+}
+
 static void usage(void)
 {
 	fprintf(stderr, "\nUsage: ssw_test_gpu [options] ... <target.fasta> <query.fasta>(or <query.fastq>)\n"
@@ -275,6 +442,7 @@ int main(int argc, char* const argv[])
 	}
 	if (nfiles < 2) { usage(); return 1; }
 	if (batch < 1) batch = 1;
+	cli_trace_on = getenv("SSW_CLI_TRACE") != 0; cli_t0 = cli_now();
 	init_tables();
 
 	int8_t dna[25]; int32_t k = 0;
@@ -298,6 +466,7 @@ int main(int argc, char* const argv[])
 		targets[nt++] = rec;
 	}
 	gzclose(tr.f);
+	CLI_TRACE("target file parsed: %d sequences", nt);
 	if (sam && header && path) {
 		fprintf(stdout, "@HD\tVN:1.4\tSO:queryname\n");
 		for (int32_t t = 0; t < nt; ++t) fprintf(stdout, "@SQ\tSN:%s\tLN:%d\n", targets[t].name, targets[t].len);
@@ -313,8 +482,16 @@ int main(int argc, char* const argv[])
 
 	ssw_gpu_ctx* g = ssw_gpu_open(getenv("SSW_GPU_DEVICE") ? atoi(getenv("SSW_GPU_DEVICE")) : 0);
 	if (!g) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(0)); return EXIT_FAILURE; }
+	CLI_TRACE("device context open");
+	/* Scratch budget of a command-line run: 16 GiB unless SSW_GPU_CM_BUDGET_MB says otherwise.  A run pays for its allocations itself: the
+	   whole-HBM budget of ssw_gpu_set_budget_exclusive buys 1.5 % in steady state over the library's default 64 GiB and 4.5 % over 16 GiB
+	   (10 397 / 10 236 / 9 947 GCUPS on config 2), but its first allocation costs 3.7 s, and right after another process released tens of
+	   gigabytes even 2 x 30 GB can take seconds (the driver hands out scrubbed memory): profiles/round5_budget_sweep_config2.txt,
+	   round5_cli_end_to_end.json. */
+	if (!getenv("SSW_GPU_CM_BUDGET_MB")) ssw_gpu_set_budget(g, (size_t)16 << 30);
 	ssw_gpu_seqs* T = ssw_gpu_seqs_upload(g, tcodes, toff, nt);
 	if (!T) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
+	CLI_TRACE("targets resident");
 	/* -g N: the per-GPU work queues of the library (ssw_gpu_pool): the target set is replicated, read blocks are pulled by N workers */
 	ssw_gpu_pool* gp = 0;
 	if (gpus > 0) {
@@ -327,86 +504,75 @@ int main(int argc, char* const argv[])
 		if (ssw_gpu_pool_set_targets(gp, tcodes, toff, nt)) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_pool_last_error(gp)); return EXIT_FAILURE; }
 	}
 
-	reader qr; memset(&qr, 0, sizeof qr);
-	qr.f = gzopen(files[1], "r");
-	if (!qr.f) { fprintf(stderr, "gzopen of '%s' failed.\n", files[1]); exit(EXIT_FAILURE); }
+	/* ---- three stages on three threads, two batches in flight between each pair of them (reference loop: src/main.c:462-526):
+	       parse (file -> records + one ASCII block)  ->  device (upload + translation + alignment)  ->  format + write (this thread) */
+	pipeline pl; memset(&pl, 0, sizeof pl);
+	pl.qfile = files[1]; pl.batch = batch; pl.reverse = reverse; pl.reverse_fatal = reverse_fatal; pl.table = table; pl.nt_table = table == nt_code;
+	pl.g = g; pl.gp = gp; pl.T = T; pl.nt = nt;
+	pl.prm.mat = mat; pl.prm.n = n; pl.prm.gapO = (uint8_t)gap_open; pl.prm.gapE = (uint8_t)gap_ext; pl.prm.flag = path ? 2 : 0; pl.prm.filters = (uint16_t)filter;
+	pl.prm.filterd = 0; pl.prm.maskLen = -1; pl.prm.score_size = 2; pl.prm.mark_mismatch = sam ? 1 : 0;
+	queue_init(&pl.parsed); queue_init(&pl.aligned);
 	const clock_t t_start = clock();
-	record* reads = (record*)xmalloc(sizeof(record) * (size_t)batch);
+	pthread_t th_parse, th_dev;
+	if (pthread_create(&th_parse, 0, stage_parse, &pl) || pthread_create(&th_dev, 0, stage_device, &pl)) { fprintf(stderr, "ssw_test_gpu: cannot start the pipeline threads\n"); return EXIT_FAILURE; }
+	static char obuf[1 << 22];
+	setvbuf(stdout, obuf, _IOFBF, sizeof obuf);
+	int rc_main = 0;
 	for (;;) {
-		int32_t nr = 0; int64_t total = 0;
-		while (nr < batch && read_record(&qr, &reads[nr])) { total += reads[nr].len; ++nr; }
-		if (nr == 0) break;
-		if (reverse_fatal) { fprintf(stderr, "Reverse complement alignment is not available for protein sequences. \n"); return 1; }
-		int64_t* qoff = (int64_t*)xmalloc(sizeof(int64_t) * ((size_t)nr + 1));
-		int8_t* qcodes = (int8_t*)xmalloc((size_t)total + 1);
-		int8_t* rcodes = reverse ? (int8_t*)xmalloc((size_t)total + 1) : 0;
-		char** rcseq = reverse ? (char**)xmalloc(sizeof(char*) * (size_t)nr) : 0;
-		qoff[0] = 0;
+		work* w = (work*)queue_pop(&pl.aligned);
+		if (!w) break;                                  /* end of input */
+		if (w->fatal) { rc_main = w->fatal; free_work(w, reverse); break; }      /* (message already on stderr) */
+		const int32_t nr = w->nr;
+		const ssw_gpu_result* res = w->res; const ssw_gpu_result* res_rc = reverse ? w->res + (int64_t)nr * nt : 0;
+		char* rcseq = 0; size_t rccap = 0;                /* reverse-complement text / codes of the read being printed: only reads whose '-' alignment wins need them */
+		int8_t* codes = 0; size_t ccap = 0;
 		for (int32_t q = 0; q < nr; ++q) {
-			qoff[q + 1] = qoff[q] + reads[q].len;
-			for (int32_t i = 0; i < reads[q].len; ++i) qcodes[qoff[q] + i] = table[(int)reads[q].seq[i] & 127];
-			if (reverse) {
-				rcseq[q] = (char*)xmalloc((size_t)reads[q].len + 1);
-				reverse_complement(reads[q].seq, reads[q].len, rcseq[q]);
-				for (int32_t i = 0; i < reads[q].len; ++i) rcodes[qoff[q] + i] = table[(int)rcseq[q][i] & 127];
-			}
-		}
-		ssw_gpu_params p;
-		p.mat = mat; p.n = n; p.gapO = (uint8_t)gap_open; p.gapE = (uint8_t)gap_ext; p.flag = path ? 2 : 0; p.filters = (uint16_t)filter;
-		p.filterd = 0; p.maskLen = -1; p.score_size = 2; p.mark_mismatch = sam ? 1 : 0;
-		ssw_gpu_result* res = (ssw_gpu_result*)xmalloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1));
-		ssw_gpu_result* res_rc = reverse ? (ssw_gpu_result*)xmalloc(sizeof(ssw_gpu_result) * (size_t)nr * (size_t)(nt ? nt : 1)) : 0;
-		uint32_t *pool = 0, *pool_rc = 0; int64_t words = 0;
-		if (gp) {   /* reads stay on the host; every worker uploads the blocks it takes */
-			if (ssw_gpu_pool_align(gp, qcodes, qoff, nr, 0, 0, nt, &p, res, &pool, &words) ||
-			    (reverse && ssw_gpu_pool_align(gp, rcodes, qoff, nr, 0, 0, nt, &p, res_rc, &pool_rc, &words))) {
-				fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_pool_last_error(gp)); return EXIT_FAILURE;
-			}
-		} else {
-			/* residue translation and (with -r) the reverse complement run on the device; the host copies made
-			   above are only used for printing (SAM needs the codes for mark_mismatch) */
-			char* qtext = (char*)xmalloc((size_t)total + 1);
-			for (int32_t q = 0; q < nr; ++q) memcpy(qtext + qoff[q], reads[q].seq, (size_t)reads[q].len);
-			ssw_gpu_seqs* Qs = ssw_gpu_seqs_upload_ascii(g, qtext, qoff, nr, table);
-			free(qtext);
-			if (!Qs || ssw_gpu_align_batch(g, Qs, T, 0, nt, &p, res, &pool, &words)) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
-			if (reverse) {
-				/* (the device reverse complement works on nucleotide codes; with a matrix file the table is the file's own) */
-				ssw_gpu_seqs* Qr = table == nt_code ? ssw_gpu_seqs_revcomp(g, Qs) : ssw_gpu_seqs_upload(g, rcodes, qoff, nr);
-				if (!Qr || ssw_gpu_align_batch(g, Qr, T, 0, nt, &p, res_rc, &pool_rc, &words)) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
-				ssw_gpu_seqs_free(Qr);
-			}
-			ssw_gpu_seqs_free(Qs);
-		}
-		for (int32_t q = 0; q < nr; ++q)
+			const record* rd = &w->reads[q];
+			int have_rc = 0;
 			for (int32_t t = 0; t < nt; ++t) {
 				const ssw_gpu_result* r = &res[(int64_t)q * nt + t];
 				const ssw_gpu_result* rr = reverse ? &res_rc[(int64_t)q * nt + t] : 0;
 				if (r->status != 0) {
-					fprintf(stderr, "Warning: Alignment between the following sequences is failed.\nref_name: %s\nread_name: %s\n\n", targets[t].name, reads[q].name);
+					fprintf(stderr, "Warning: Alignment between the following sequences is failed.\nref_name: %s\nread_name: %s\n\n", targets[t].name, rd->name);
 					continue;
 				}
-				if (rr && rr->status == 0 && rr->score1 > r->score1 && rr->score1 >= filter) {
-					s_align* a = ssw_gpu_result_to_align(rr, pool_rc);
-					if (a->flag == 2) fprintf(stderr, "Warning: The reverse compliment alignment of the following sequences may miss a small part.\nref_seq: %s\nread_seq: %s\n\n", targets[t].name, reads[q].name);
-					write_alignment(a, &targets[t], &reads[q], rcseq[q], tcodes + toff[t], rcodes + qoff[q], table, 1, sam, sam && rr->cigarLen > 0 ? rr->edit_distance : -1);
-					align_destroy(a);
-				} else if (r->score1 > 0 && r->score1 >= filter) {
-					s_align* a = ssw_gpu_result_to_align(r, pool);
-					if (a->flag == 2) fprintf(stderr, "Warning: The alignment of the following sequences may miss a small part.\nref_seq: %s\nread_seq: %s\n\n", targets[t].name, reads[q].name);
-					write_alignment(a, &targets[t], &reads[q], reads[q].seq, tcodes + toff[t], qcodes + qoff[q], table, 0, sam, sam && r->cigarLen > 0 ? r->edit_distance : -1);
-					align_destroy(a);
-				} else if (r->score1 <= 0) {
-					fprintf(stderr, "There is no identical residue between the following reference and read seqeunces.\nref_name: %s\nread_name: %s\n\n", targets[t].name, reads[q].name);
+				const int minus = rr && rr->status == 0 && rr->score1 > r->score1 && rr->score1 >= filter;
+				const ssw_gpu_result* win = minus ? rr : r;
+				if (!minus && !(r->score1 > 0 && r->score1 >= filter)) {
+					if (r->score1 <= 0) fprintf(stderr, "There is no identical residue between the following reference and read seqeunces.\nref_name: %s\nread_name: %s\n\n", targets[t].name, rd->name);
+					continue;
 				}
+				const char* seq = rd->seq;
+				if (minus) {
+					if (!have_rc) {
+						if (rccap < (size_t)rd->len + 1) { rccap = (size_t)rd->len * 2 + 64; rcseq = (char*)xrealloc(rcseq, rccap); }
+						reverse_complement(rd->seq, rd->len, rcseq); have_rc = 1;
+					}
+					seq = rcseq;
+				}
+				s_align* a = ssw_gpu_result_to_align(win, w->pool);
+				if (a->flag == 2) fprintf(stderr, minus ? "Warning: The reverse compliment alignment of the following sequences may miss a small part.\nref_seq: %s\nread_seq: %s\n\n"
+				                                        : "Warning: The alignment of the following sequences may miss a small part.\nref_seq: %s\nread_seq: %s\n\n", targets[t].name, rd->name);
+				const int32_t nm_dev = sam && win->cigarLen > 0 ? win->edit_distance : -1;
+				const int8_t* read_num = 0;
+				if (sam && nm_dev < 0) {      /* (a traceback the reference gives up on: its mark_mismatch runs on the empty CIGAR and wants the codes) */
+					if (ccap < (size_t)rd->len + 1) { ccap = (size_t)rd->len * 2 + 64; codes = (int8_t*)xrealloc(codes, ccap); }
+					for (int32_t i = 0; i < rd->len; ++i) codes[i] = table[(int)seq[i] & 127];
+					read_num = codes;
+				}
+				write_alignment(a, &targets[t], rd, seq, tcodes + toff[t], read_num, table, minus, sam, nm_dev);
+				align_destroy(a);
 			}
-		free(pool); free(pool_rc); free(res); free(res_rc); free(qoff); free(qcodes); free(rcodes);
-		for (int32_t q = 0; q < nr; ++q) { if (reverse) free(rcseq[q]); free_record(&reads[q]); }
-		free(rcseq);
+		}
+		free(rcseq); free(codes);
+		CLI_TRACE("wrote a batch of %d reads", nr);
+		free_work(w, reverse);
 	}
+	fflush(stdout);
+	CLI_TRACE("stdout flushed");
+	if (rc_main) exit(rc_main);      /* (the other stages may be blocked on a full queue: the process ends here, as the reference's does) */
+	pthread_join(th_parse, 0); pthread_join(th_dev, 0);
 	fprintf(stderr, "CPU time: %f seconds\n", ((float)(clock() - t_start)) / CLOCKS_PER_SEC);
-	gzclose(qr.f);
-	free(reads);
 	ssw_gpu_seqs_free(T);
 	ssw_gpu_pool_close(gp);
 	ssw_gpu_close(g);

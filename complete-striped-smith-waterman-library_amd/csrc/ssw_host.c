@@ -386,6 +386,30 @@ ssw_gpu_seqs* ssw_gpu_seqs_revcomp(ssw_gpu_ctx* c, const ssw_gpu_seqs* in)
 	return s;
 }
 
+/* `in` (N sequences) followed by the reverse complement of every one of them: ONE set of 2 N sequences, sequence N + i = revcomp(sequence i).
+   `ssw_test -r` aligns every read in both orientations (reference src/main.c:478-481, 507-519): with this set that is one batch call of
+   2 N queries instead of two of N. */
+ssw_gpu_seqs* ssw_gpu_seqs_with_revcomp(ssw_gpu_ctx* c, const ssw_gpu_seqs* in)
+{
+	if (!c || !in || in->ctx != c || in->count > 0x3fffffff) { fail(c, "seqs_with_revcomp: bad arguments%s", ""); return 0; }
+	ssw_shim_set_device(c->device);
+	const int32_t n = in->count;
+	int64_t* off2 = (int64_t*)malloc(sizeof(int64_t) * (2 * (size_t)n + 1));
+	if (!off2) { fail(c, "out of host memory%s", ""); return 0; }
+	for (int32_t i = 0; i <= n; ++i) { off2[i] = in->h_off[i]; off2[n + i] = in->total + in->h_off[i]; }
+	ssw_gpu_seqs* s = seqs_new(c, off2, 2 * n);
+	free(off2);
+	if (!s) return 0;
+	void* const us = upload_stream(c);
+	ssw_prep_args pa; memset(&pa, 0, sizeof pa);
+	pa.codes_in = in->d_codes; pa.off = in->d_off; pa.count = n; pa.total = in->total; pa.out = s->d_codes; pa.mode = 2;
+	if (ssw_shim_h2d(s->d_off, s->h_off, sizeof(int64_t) * (2 * (size_t)n + 1), us) ||
+	    ssw_shim_launch_prep(&pa, us) || ssw_shim_stream_sync(us)) {
+		fail(c, "revcomp failed: %s", ssw_shim_last_error()); ssw_gpu_seqs_free(s); return 0;
+	}
+	return s;
+}
+
 /* copies the residue codes of a device-resident set back to the host (tests, debugging) */
 int ssw_gpu_seqs_download(ssw_gpu_ctx* c, const ssw_gpu_seqs* s, int8_t* codes_out)
 {

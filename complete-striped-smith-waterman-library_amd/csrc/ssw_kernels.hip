@@ -2779,7 +2779,8 @@ __global__ void __launch_bounds__(64) k_trace(ssw_trace_args a)
 
 /* sequence preparation (reference src/main.c:84-116, 476-481, 504): mode 0 translates ASCII through the caller's
    128-entry table; mode 1 writes the reverse complement of every code sequence (codes 0..3 -> 3 - code, others unchanged:
-   what the reference's rc_table + nt_table produce together) */
+   what the reference's rc_table + nt_table produce together); mode 2 writes the sequences AND, behind them, their reverse
+   complements (one set of 2 x count sequences: `ssw_test -r` as one batch) */
 __global__ void __launch_bounds__(256) k_prep(ssw_prep_args a)
 {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2789,6 +2790,7 @@ __global__ void __launch_bounds__(256) k_prep(ssw_prep_args a)
 	while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.off[mid] <= i) lo = mid; else hi = mid; }
 	const int64_t b = a.off[lo], e = a.off[lo + 1];
 	const int8_t c = a.codes_in[i];
+	if (a.mode == 2) { a.out[i] = c; a.out[a.total + b + (e - 1 - i)] = (c >= 0 && c < 4) ? (int8_t)(3 - c) : c; return; }      /* originals, then their reverse complements */
 	a.out[b + (e - 1 - i)] = (c >= 0 && c < 4) ? (int8_t)(3 - c) : c;
 }
 

@@ -96,6 +96,9 @@ ssw_gpu_seqs* ssw_gpu_seqs_upload_ascii(ssw_gpu_ctx* ctx, const char* text, cons
 /* Reverse complement of every sequence of a DNA code set (0..3 -> 3 - code, other codes kept), computed on the device:
    what `ssw_test -r` builds per read on the host (reference src/main.c:95-116, 478-481). */
 ssw_gpu_seqs* ssw_gpu_seqs_revcomp(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* s);
+/* The sequences of `s` followed by their reverse complements: one set of 2 x count sequences (sequence count + i is the reverse
+   complement of sequence i) -- `ssw_test -r` as ONE batch call of 2 N queries (reference src/main.c:478-481, 507-519). */
+ssw_gpu_seqs* ssw_gpu_seqs_with_revcomp(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* s);
 int ssw_gpu_seqs_download(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* s, int8_t* codes_out);
 void ssw_gpu_seqs_free(ssw_gpu_seqs* s);
 int32_t ssw_gpu_seqs_count(const ssw_gpu_seqs* s);
@@ -162,6 +165,10 @@ int ssw_gpu_search_db(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* queries, const ssw_g
  * devices -- are independent and may be driven from different threads concurrently.  The single-pair functions of ssw.h
  * use an implicit context per calling thread (devices assigned round-robin, or SSW_GPU_DEVICE), so concurrent ssw_align
  * calls on one const s_profile* are legal, as with the reference (src/ssw.c has no mutable global state).
+ * Streaming callers: while a batch call runs on a context, ONE other thread may prepare the next block on the same context with the
+ * ssw_gpu_seqs_* calls (upload, ASCII translation, reverse complement) and free finished sets; those run on the context's upload stream
+ * and do not queue behind the batch call's kernels (ssw_test_gpu's three stages, bench.py --config 3 --full).  The first such call of a
+ * context must have returned before the first batch call starts.
  */
 
 /*
