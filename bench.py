@@ -51,7 +51,7 @@ VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9    # packed 16-bit (VOP3P) instructions
 FULL = os.path.join(ROOT, "tests", "golden", "full")
 CSRC = os.path.join(ROOT, "complete-striped-smith-waterman-library_amd", "csrc")
 KERNEL_SRCS = [os.path.join(CSRC, f) for f in ("ssw_kernels.hip", "lanes.h", "ssw_dev.h")]      # everything the device code is made of
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round4_traffic.json")                         # written by scripts/gpu_profile.sh
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round5_traffic.json")                         # written by scripts/gpu_profile.sh
 # VALU issue, two yardsticks: every instruction of the recurrence charged a 4-cycle slot -- what the kernels' mix actually costs
 # (profiles/round3_mix_issue_probe.txt) -- and the ISA ideal in which the three 32-bit adds of a row issue in 2.2 cycles as in a pure stream
 CYCLES_PER_PAIR_ROW_4CYCLE = 6.5 * 4.0
@@ -465,6 +465,7 @@ def bench_dna(args, world, rank, local_rank, dist):
             # boundary records between strips (16 B per column and pair, written once and read once)
             aln_per_launch = nreads * args.steps / max(1, acc["fill_launches"])
             bytes_per_aln = p["ref_len"] + rlen + 25 + 40 + 4 * p["ref_len"] + p["ref_len"] // 4      # (+ the 16-column group maxima: two u32 streams per pair / 16)
+            survey_bytes = p["ref_len"] + rlen + 25 + 40 + 4 * p["ref_len"]      # SURVEY 8d's own formula: target + read + matrix + record + maxColumn written and re-read
             if tm["fill_strips"] > 1:
                 bytes_per_aln += 16 * p["ref_len"] * (tm["fill_strips"] - 1)
             achieved = aln_per_launch * bytes_per_aln / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
@@ -477,6 +478,11 @@ def bench_dna(args, world, rank, local_rank, dist):
                                                    "no PMC pass of this kernel source committed (scripts/gpu_profile.sh writes %s)" % os.path.relpath(TRAFFIC_JSON, ROOT),
                                    "launch_ms": round(launch_ms, 3), "launches": int(acc["fill_launches"]),
                                    "algorithmic_bytes_per_alignment": int(bytes_per_aln),
+                                   "survey_8d_bytes_per_alignment": int(survey_bytes),
+                                   "design_over_survey_8d": round(bytes_per_aln / float(survey_bytes), 2),
+                                   "traffic_over_survey_8d": round(tr["hbm_bytes_per_alignment"] / float(survey_bytes), 2) if tr else None,
+                                   "bytes_note": "algorithmic_bytes_per_alignment is what THIS design moves by construction (long queries: + the strip boundary records, 16 B per "
+                                                 "column and strip boundary, written once and read once); survey_8d_bytes_per_alignment is SURVEY 8d's formula for an ideal single-pass kernel",
                                    "note": "HBM is not the binding resource of this path (see roofline)"}
             out["roofline"]["traffic"] = traffic      # (HBM GB/s of the same kernel from the PMC passes: the contract's key; details in roofline_hbm)
             out["roofline"]["traffic_unit"] = "GB/s of HBM traffic (FETCH_SIZE + WRITE_SIZE), see roofline_hbm"

@@ -11,7 +11,7 @@ import os
 import sqlite3
 import sys
 
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "round4"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "round5"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -78,6 +78,44 @@ for cfg, k in ((2, "k_fill<10, 3>"), (4, "k_chainq<12, false, 3>"), (5, "k_filld
         issue["config%d" % cfg] = {"kernel": k, "SQ_INSTS_VALU_per_dispatch": valu, "GRBM_GUI_ACTIVE_per_dispatch": gui, "dispatch_ms": ns / 1e6,
                                   "effective_clock_GHz": round(gui / 8.0 / ns, 3), "cycles_per_valu_instruction": round(gui / 8.0 * 1024.0 / valu, 3),
                                   "issue_slot_occupancy_at_4_cycles": round(4.0 * valu / (gui / 8.0 * 1024.0), 3)}
+# LDS / VALU utilisation per kernel (round 5: the counters the contract names).  Per kernel and pass the per-dispatch averages:
+#   LDS bank-conflict rate = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (extra LDS-array cycles / all LDS-array cycles, MI355X_MICROARCH.md LDS section)
+#   VALU busy              = 4 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)   (share of the 4-cycle issue slots; gfx94x's VALUBusy uses SQ_ACTIVE_INST_VALU the same way)
+#   LDS busy               = SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE / 8)       (share of the cycles in which a CU's LDS array works)
+util = {}
+WATCH = {2: ["k_fill<10, 3>"], 4: ["k_chainq<12, false, 3>", "k_chainq<8, true, 3>", "k_trace_wave<16>", "k_trace_wave<4>", "k_trace_wave<1>"], 5: ["k_filldb<20, 16, true>", "k_filldb<19, 16, true>"]}
+for cfg, names in WATCH.items():
+    for k in names:
+        d = {}
+        for r in rows:
+            if r[0].startswith("pmc%d" % cfg) and k in r[1]:
+                d[r[2]] = (float(r[4]), float(r[5]), float(r[6]), int(r[3]))      # sum, avg per dispatch, avg ns, dispatches
+        if not d:
+            continue
+        e = {"dispatches_per_pass": d[next(iter(d))][3]}
+        for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_INST_CYCLES_VMEM", "SQ_WAIT_INST_LDS",
+                  "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+            if c in d:
+                e[c] = d[c][0]
+        gui = e.get("GRBM_GUI_ACTIVE")
+        if "SQ_LDS_BANK_CONFLICT" in e and e.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_bank_conflict_rate"] = round(e["SQ_LDS_BANK_CONFLICT"] / e["SQ_LDS_IDX_ACTIVE"], 4)
+        if gui and "SQ_INSTS_VALU" in e:
+            e["valu_busy_4cycle_slots"] = round(4.0 * e["SQ_INSTS_VALU"] / (1024.0 * gui / 8.0), 4)
+        if gui and "SQ_LDS_IDX_ACTIVE" in e:
+            e["lds_busy"] = round(e["SQ_LDS_IDX_ACTIVE"] / (256.0 * gui / 8.0), 4)
+        if "SQ_WAVE_CYCLES" in e and "SQ_WAIT_INST_ANY" in e:
+            e["issue_stall_share_of_wave_cycles"] = round(e["SQ_WAIT_INST_ANY"] / e["SQ_WAVE_CYCLES"], 4)
+        util["config%d %s" % (cfg, k)] = e
+traffic["utilisation"] = util
+traffic["utilisation_note"] = ("sums over all dispatches of the kernel in its PMC passes (separate passes per counter group: the same command every time); "
+                               "lds_bank_conflict_rate = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; valu_busy = 4 SQ_INSTS_VALU / (1024 GRBM_GUI_ACTIVE / 8); "
+                               "lds_busy = SQ_LDS_IDX_ACTIVE / (256 GRBM_GUI_ACTIVE / 8)")
+with open(os.path.join(out_dir, ROUND + "_utilisation.txt"), "w") as f:
+    f.write("# LDS / VALU utilisation of the hot kernels, rocprofv3 PMC passes of scripts/gpu_profile.sh (%s); kernel source %s\n" % (ROUND, traffic["kernel_source_sha16"]))
+    f.write("%-44s %10s %10s %12s %12s\n" % ("kernel (config)", "VALU busy", "LDS busy", "LDS conflict", "issue stall"))
+    for k, e in util.items():
+        f.write("%-44s %10s %10s %12s %12s\n" % (k, e.get("valu_busy_4cycle_slots", "-"), e.get("lds_busy", "-"), e.get("lds_bank_conflict_rate", "-"), e.get("issue_stall_share_of_wave_cycles", "-")))
 issue["note"] = ("SQ_INSTS_VALU and GRBM_GUI_ACTIVE (summed over the 8 XCDs) of the dominant fill kernel, separate PMC passes (<round>_pmc.csv): "
                  "SIMD-cycles per VALU instruction = 1024 SIMDs x GRBM_GUI_ACTIVE / 8 / SQ_INSTS_VALU; above 1.0 occupancy = some 2-cycle adds pair up")
 traffic["valu_issue"] = issue
