@@ -62,6 +62,9 @@ SSW_DEV u32 xl_wave_shr1_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_up
    every row to the lanes of the next row (rows 1 and 3 take it), lane 31 to rows 2 and 3 -- the two cross-row steps of a
    wavefront-wide prefix scan; lanes outside the row mask keep `keep` */
 template <int N> SSW_DEV u32 xl_row_shr_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x110 + N, 0xf, 0xf, false); }
+/* row_shl:1 (0x101) / wave_shl:1 (0x130): lane i reads lane i+1 inside its row of 16 / across the wavefront; the last lane keeps `keep` */
+SSW_DEV u32 xl_row_shl1_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x101, 0xf, 0xf, false); }
+SSW_DEV u32 xl_wave_shl1_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x130, 0xf, 0xf, false); }
 SSW_DEV u32 xl_row_bcast15_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x142, 0xa, 0xf, false); }
 SSW_DEV u32 xl_row_bcast31_keep(u32 keep, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x143, 0xc, 0xf, false); }
 /* value of one lane (wavefront-uniform index) in every lane */

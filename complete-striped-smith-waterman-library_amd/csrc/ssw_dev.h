@@ -384,6 +384,7 @@ int ssw_shim_chainq_resident(int R, int capture, int n);   /* wavefronts of k_ch
 int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream);
 int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream);
 int ssw_shim_launch_trace_wave(const ssw_trace_args* a, void* stream);
+int ssw_shim_launch_trace_diag(int team, const ssw_trace_args* a, void* stream);   /* narrow bands: teams of 16 / 32 lanes, several alignments per wavefront */
 int64_t ssw_shim_trace_lds_need(int band_width, int waves);   /* LDS that keeps a band of this width on chip */   /* one wavefront per alignment (long reads) */
 int ssw_shim_launch_gather(const ssw_gather_args* a, void* stream);
 int ssw_shim_launch_select(const ssw_select_args* a, void* stream);   /* the pass in a->pass */

@@ -56,6 +56,10 @@ typedef struct {
 	int trace_no_lds;       /* SSW_GPU_TRACE_LDS=0: band rows in HBM scratch */
 	int trace_waves;        /* SSW_GPU_TRACE_WAVES=1/4/16: team size; 0: by band width */
 	int trace_unblocked;    /* SSW_GPU_TRACE_BLOCKED=0: teams with one cell per thread */
+	int trace_many;         /* SSW_GPU_TRACE_MANY=<n>: a traceback round with more than n pending alignments sizes its teams for throughput (tests: 0); default 4096 */
+	int trace_diag;         /* SSW_GPU_TRACE_DIAG=1: the anti-diagonal narrow-band kernel (k_trace_diag, four alignments per wavefront) in front of the row
+	                           kernels.  Built, bit-exact, measured in round 5 and NOT faster (52.8 ms against ~48 ms of the row kernel for the same 10^4
+	                           alignments of config 4): kept for tests and as a starting point, off by default */
 	int serial_buckets;     /* SSW_GPU_SERIAL_BUCKETS=1: geometry buckets one after the other on the main stream (the form before round 4) */
 	int no_dbx;             /* SSW_GPU_NO_DBX=1: flagged batches against many targets take the per-target loop (the form before round 4) */
 	int no_tail;            /* SSW_GPU_NO_TAIL=1: equal strips for long queries (no short last strip of the strip kernel: the form before the end of round 4) */
@@ -119,6 +123,7 @@ static void knobs_load(ssw_knobs* k)
 	k->call_trace = env_is("SSW_GPU_CALL_TRACE", '1');
 	k->db_chain_best = 1;
 	k->trace_wave = -1;
+	k->trace_many = 4096;
 #ifdef SSW_GPU_TEST_HOOKS
 	{ const int v = env_int("SSW_GPU_FRAME_K", 0); k->frame_k = v >= 16 ? v : 0; }
 	k->queue_mode = env_is("SSW_GPU_QUEUE", 'j') ? 1 : env_is("SSW_GPU_QUEUE", 's') ? 2 : 0;
@@ -138,6 +143,8 @@ static void knobs_load(ssw_knobs* k)
 	k->trace_no_lds = env_is("SSW_GPU_TRACE_LDS", '0');
 	{ const int v = env_int("SSW_GPU_TRACE_WAVES", 0); k->trace_waves = v == 1 || v == 4 || v == 16 ? v : 0; }
 	k->trace_unblocked = env_is("SSW_GPU_TRACE_BLOCKED", '0');
+	k->trace_diag = env_is("SSW_GPU_TRACE_DIAG", '1');
+	if (getenv("SSW_GPU_TRACE_MANY")) k->trace_many = env_int("SSW_GPU_TRACE_MANY", 4096);
 	k->serial_buckets = env_is("SSW_GPU_SERIAL_BUCKETS", '1');
 	k->no_dbx = env_is("SSW_GPU_NO_DBX", '1');
 	k->no_band = env_is("SSW_GPU_NO_BAND", '1');
@@ -1047,27 +1054,57 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 					for (int32_t k = 0; k < cnt_l; ++k) lst[k] = pend[q0 + k].q;
 					uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)(sstride * cnt_l));
 					if (!d_scr) { trace_ok = 0; break; }
+					int32_t cnt_row = cnt_l;      /* alignments that go on to the row kernel of this round */
+					int list_ready0 = ti->list_on_device && q0 == 0 && cnt_l == npend;
+					if (use_wave0 && c->kn.trace_diag) {
+						/* (experiment, off by default: SSW_GPU_TRACE_DIAG=1) Narrow bands first: teams of 16 lanes, four alignments per wavefront,
+						   bands up to 15 walked by anti-diagonals (k_trace_diag); 72 % of config 4's alignments end there, the others come back
+						   with the band that outgrew the team and their state, exactly like an alignment that ran out of scratch, and the row
+						   kernel below continues them.  Bit-exact, but one pair of a four-team wavefront costs ~180 instructions: no faster than
+						   the row kernel once that one stopped waiting for its stores (profiles/round5_traceback_notes.txt). */
+						ssw_trace_args da;
+						da.tgt = d_tgt; da.qcodes = Q->d_codes; da.qoff = Q->d_off; da.qlist = d_qlist; da.nq = cnt_l; da.mat = d_mat; da.n = n; da.vm = ti->vm;
+						da.gapO = prm->gapO; da.gapE = prm->gapE; da.res = d_res; da.scratch = d_scr; da.scratch_stride = ((int64_t)31 * maxlen + 64 + 15) / 16 * 16; da.soff = 0;
+						da.cigar = d_cig; da.cigar_stride = cig_stride; da.need = d_need; da.resume = d_resume; da.unblocked = 0; da.waves = 1; da.lds_bytes = 1024;
+						if (!list_ready0) to->list_dirty = 1;
+						if (!resume_zeroed) { resume_zeroed = 1; if (ssw_shim_memset(d_resume, 0, sizeof(int32_t) * 8 * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); trace_ok = 0; break; } }
+						if ((!list_ready0 && ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream)) ||
+						    ssw_shim_launch_trace_diag(16, &da, c->stream) ||
+						    ssw_shim_d2h(hnb, d_need, sizeof(int32_t) * 2 * (size_t)cnt_l, c->stream) ||
+						    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
+						cnt_row = 0;
+						for (int32_t k = 0; k < cnt_l; ++k)
+							if (hnb[k] != 0) {
+								if (hnb[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
+								lst[cnt_row++] = lst[k];
+							}
+						if (!trace_ok) break;
+						if (c->kn.debug) fprintf(stderr, "[ssw_gpu] %.1f ms: trace round 0: %d alignments on 16-lane teams (bands <= 15), %d go on to the row kernel\n", dbg_ms(), cnt_l, cnt_row);
+						did_trace = 1;
+						list_ready0 = 0;      /* (the list on the device is the whole chunk's: the row kernel takes the compacted one) */
+						if (cnt_row == 0) continue;
+					}
 					ssw_trace_args ta;
-					ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_l; ta.mat = d_mat; ta.n = n; ta.vm = ti->vm;
+					ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_qlist; ta.nq = cnt_row; ta.mat = d_mat; ta.n = n; ta.vm = ti->vm;
 					ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr; ta.scratch_stride = sstride; ta.soff = 0;
 					ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need;     /* CIGAR slots are indexed by query */
 					ta.resume = d_resume; ta.unblocked = trace_unblocked; ta.waves = 1; ta.lds_bytes = trace_no_lds ? 0 : (int32_t)ssw_shim_trace_lds_need(64, 1);      /* (the round's scratch admits bands up to 48 at the longest read: all of them walk their rows in LDS) */
 					/* (the job list is already on the device when the caller's list IS the ids and one launch takes them all; need and band come
 					   back in one copy: need[0 .. cnt), band[cnt .. 2 cnt)) */
-					const int list_ready = ti->list_on_device && q0 == 0 && cnt_l == npend;
+					const int list_ready = list_ready0;
 					if (!list_ready) to->list_dirty = 1;
 					if (use_wave0 && !resume_zeroed) { resume_zeroed = 1; if (ssw_shim_memset(d_resume, 0, sizeof(int32_t) * 8 * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); trace_ok = 0; break; } }
-					if ((!list_ready && ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_l, c->stream)) ||
+					if ((!list_ready && ssw_shim_h2d(d_qlist, lst, sizeof(int32_t) * (size_t)cnt_row, c->stream)) ||
 					    (use_wave0 ? ssw_shim_launch_trace_wave(&ta, c->stream) : ssw_shim_launch_trace(&ta, c->stream)) ||
-					    ssw_shim_d2h(hnb, d_need, sizeof(int32_t) * 2 * (size_t)cnt_l, c->stream) ||
+					    ssw_shim_d2h(hnb, d_need, sizeof(int32_t) * 2 * (size_t)cnt_row, c->stream) ||
 					    ssw_shim_stream_sync(c->stream)) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
-					for (int32_t k = 0; k < cnt_l; ++k)
+					for (int32_t k = 0; k < cnt_row; ++k)
 						if (hnb[k] != 0) {
 							if (hnb[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
-							nextp[nnext].key = hnb[cnt_l + k]; nextp[nnext].need = hnb[k]; nextp[nnext].q = lst[k]; ++nnext;      /* (both kernels report the band that did not fit) */
+							nextp[nnext].key = hnb[cnt_row + k]; nextp[nnext].need = hnb[k]; nextp[nnext].q = lst[k]; ++nnext;      /* (both kernels report the band that did not fit) */
 						}
-					if (c->kn.debug) fprintf(stderr, "[ssw_gpu] %.1f ms: trace round 0: %d alignments, scratch %lld B each, %d pending so far\n",
-					                                     dbg_ms(), cnt_l, (long long)sstride, nnext);
+					if (c->kn.debug) fprintf(stderr, "[ssw_gpu] %.1f ms: trace round 0 (row kernel): %d alignments, scratch %lld B each, %d pending so far\n",
+					                                     dbg_ms(), cnt_row, (long long)sstride, nnext);
 				}
 			} else {
 				/* every pending alignment gets a multiple of what it last needed (one or two more band doublings).  The
@@ -1102,6 +1139,12 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 								/* a band row of 2b+1 cells is walked in chunks of 64 cells per wavefront: wide bands get 4 or 16 wavefronts */
 								const int32_t b2 = pend[g1].key > (1 << 20) ? (1 << 21) : 2 * pend[g1].key;
 								int wv = b2 <= 96 ? 1 : b2 <= 256 ? 4 : 16;
+								/* ... when the round is about LATENCY (config 4: a few hundred wide bands, a compute unit each).  A round of tens of
+								   thousands of alignments (the survivors of a protein search: ~300 rows, bands of 50 .. 500) is about THROUGHPUT: a
+								   team of 1024 threads on a row of 400 cells leaves 600 of them waiting at two barriers per row, and the device
+								   holds 512 such teams at a time.  Then the smallest team whose threads still have <= 4 (one wavefront) or <= 12
+								   cells of a row each: 62 114 alignments of the 2048 x 10 000 search 109 -> xx ms (profiles/round5_dbx*.json). */
+								if (npend > c->kn.trace_many) wv = b2 <= 254 ? 1 : b2 <= 3070 ? 4 : 16;
 								if (trace_waves_env > 0) wv = trace_waves_env;
 								/* few LDS classes (16, 64, 128, 160 KiB): only a handful of hardware queues run side by side */
 								int64_t l = ssw_shim_trace_lds_need(b2, wv), cls = 16384;

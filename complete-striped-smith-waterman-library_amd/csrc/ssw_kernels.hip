@@ -2192,6 +2192,20 @@ SSW_DEV int cigar_score(const u32* cig, int n_ops, const int8_t* ref, const int8
 	return score;
 }
 
+/* cigar_alignment_score (src/ssw.c:785-811) by one wavefront: the residues of an M run spread over the 64 lanes (matrix in LDS) */
+SSW_DEV int cigar_score_wave(const u32* cig, int n_ops, const int8_t* ref, const int8_t* read, const unsigned char* lds, int n, int gapO, int gapE, int lane)
+{
+	int part = 0, gaps = 0, rp = 0, qp = 0;
+	for (int i = 0; i < n_ops; ++i) {
+		const int len = (int)(cig[i] >> 4), op = (int)(cig[i] & 0xf);
+		if (op == 0) { for (int x = lane; x < len; x += 64) part += lds_ld8s(lds, (u32)((int)ref[rp + x] * n + read[qp + x])); rp += len; qp += len; }
+		else { gaps += gapO + (len > 1 ? (len - 1) * gapE : 0); if (op == 1) qp += len; else if (op == 2) rp += len; }
+	}
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) part += (int)xl_shfl((u32)part, lane ^ d);
+	return part - gaps;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * trace_wave: the same banded_sw, one WAVEFRONT per alignment (long reads: bands of hundreds of cells, 10^4 rows).
  * The cells of a band row are spread over the 64 lanes in chunks; E and the diagonal term only need the previous
@@ -2258,6 +2272,7 @@ struct TraceBest { int best, i, j; };
 #define TX_CARRY 1216u
 #define TX_BCAST 1232u
 #define TX_BEST 1280u
+#define TX_READ 1472u      /* 64 bytes: the read's codes of the 64 rows being walked (after the 16 x 12 bytes of TX_BEST) */
 
 /* one band width: fills the direction bytes, updates the running best cell (row-major, strict >).  NW wavefronts
    (64 * NW cells per chunk) work on one alignment; the horizontal dependency is a two-level max-plus scan. */
@@ -2278,7 +2293,9 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 	trace_sync<L, NW>();
 	int rd = read[0];
 	for (int i = 0; i < readLen; ++i) {
-		const int rdn = i + 1 < readLen ? read[i + 1] : 0;             /* next row's base: in flight during this row */
+		/* (a global load in the row loop waits, on this target, for the row's direction-byte STORES as well -- one vmcnt for both: the rows that
+		   live in LDS take the read's codes from an LDS window of 64 rows, refilled with the target window) */
+		const int rdn = L ? 0 : i + 1 < readLen ? read[i + 1] : 0;             /* HBM rows: next row's base, in flight during this row */
 		const int xi = i - band_width > 0 ? i - band_width : 0;
 		const int xp = i - 1 - band_width > 0 ? i - 1 - band_width : 0;
 		const int sft = xi - xp;                                   /* 0 or 1: how far the band slid against the previous row */
@@ -2291,9 +2308,11 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 			int64_t hi = (int64_t)i + band_width + 65; if (hi > refLen) hi = refLen;
 			for (int j = staged + tid; j < (int)hi; j += NT) lds_st8(lds, oring + ((u32)j & ring_mask), (u32)(unsigned char)ref[j]);
 			if ((int)hi > staged) staged = (int)hi;
+			if (tid < 64) lds_st8(lds, TX_READ + (u32)tid, (u32)(unsigned char)read[i + tid < readLen ? i + tid : readLen - 1]);
 		}
 		if (tid == 0) { R.sthb(0, 0); R.sthb(edge, 0); R.sthc(0, 0); R.steb(0, NEG); R.steb(edge, NEG); }
 		trace_sync<L, NW>();
+		if (L) rd = lds_ld8s(lds, TX_READ + (u32)(i & 63));
 		int carryF = NEG, carryA = 0, carryH = 0;                  /* F, A and h of the cell left of the chunk (h_c[0] = 0) */
 		for (int c0 = 1; c0 <= ncell; c0 += NT) {
 			const int u = c0 + tid;
@@ -2370,7 +2389,7 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 		if (NW == 1) trace_sync<L, NW>();    /* NW > 1: every thread is past the chunk's second barrier, and copies the cells it wrote itself */
 		for (int u = 1 + tid; u <= ncell; u += NT) R.sthb(u, R.ldhc(u));
 		trace_sync<L, NW>();
-		rd = rdn;
+		if (!L) rd = rdn;
 	}
 	/* the scalar walk's best cell: highest h above the carried best; among equals the first in row-major order */
 	if (lb <= tb.best) { lb = NEG; li = 0x7fffffff; lj = 0x7fffffff; }
@@ -2431,10 +2450,9 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 	int staged = 0;
 	int lb = tb.best, li = 0, lj = 0;
 	trace_sync<true, NW>();
-	int rd = read[0];
+	int rd = 0;
 	const int u0 = tid * CPT + 1;
 	for (int i = 0; i < readLen; ++i) {
-		const int rdn = i + 1 < readLen ? read[i + 1] : 0;
 		const int xi = i - band_width > 0 ? i - band_width : 0;
 		const int xp = i - 1 - band_width > 0 ? i - 1 - band_width : 0;
 		const int sft = xi - xp;
@@ -2449,8 +2467,12 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 			int64_t hi = (int64_t)i + band_width + 65; if (hi > refLen) hi = refLen;
 			for (int j = staged + tid; j < (int)hi; j += NT) lds_st8(lds, oring + ((u32)j & ring_mask), (u32)(unsigned char)ref[j]);
 			if ((int)hi > staged) staged = (int)hi;
+			/* the read's codes of these 64 rows too: a global load inside the row loop would wait for the rows' direction-byte stores (one
+			   vmcnt for loads and stores on this target) -- a store round trip per row */
+			if (tid < 64) lds_st8(lds, TX_READ + (u32)tid, (u32)(unsigned char)read[i + tid < readLen ? i + tid : readLen - 1]);
 			trace_sync<true, NW>();
 		}
+		rd = lds_ld8s(lds, TX_READ + (u32)(i & 63));
 		/* ---- this thread's cells: u0 .. u0 + cnt - 1 */
 		const int cnt = u0 > ncell ? 0 : (ncell - u0 + 1 < CPT ? ncell - u0 + 1 : CPT);
 		/* a wavefront whose 64 CPT cells all lie past the row's end (the class rounds the cells per thread up; a band's first and last rows are
@@ -2576,7 +2598,6 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 			const u32 b = (byte_first & 0x80u) ? ((byte_first & 1u) | ((u32)(4 + df5) << 2)) : byte_first;
 			line[u0 - 1] = (int8_t)(b | ((u32)df5 << 1));
 		}
-		rd = rdn;
 	}
 	/* the scalar walk's best cell: highest h above the carried best; among equals the first in row-major order */
 	if (lb <= tb.best) { lb = NEG; li = 0x7fffffff; lj = 0x7fffffff; }
@@ -2653,13 +2674,36 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 	band_width /= 2;
 	const int best_i = tb.i, best_j = tb.j;
 
-	if (NW > 1) { wg_fence(); __syncthreads(); } else wg_fence();
+	if (NW > 1) { dev_fence(); __syncthreads(); } else dev_fence();
 	int nops = 0;
-	if (tid == 0) {
-		int run = 0, state = 2, cur = 0, prev = 0, i = best_i, j = best_j, failed = 0;
+	if (tid < 64) {
+		/* The walk back (src/ssw.c:682-762) by the team's first wavefront.  It used to be thread 0's loop: 10^4 dependent one-byte loads for a
+		   10-kb read, a memory latency each -- tens of milliseconds per alignment, after the passes, with the other 1023 threads waiting.  Now all 64 lanes follow
+		   the same walk and the bytes come in batches: lane t fetches twelve bytes of row (base - t) around the band index the path has if
+		   it keeps to its diagonal, a step takes its byte from the lane that holds its row with one cross-lane move; a path that drifts
+		   out of a row's window (a long run of gap steps) or leaves the 64 rows of the batch starts a new batch where it stands. */
+		int run = 0, state = 2, cur = 0, prev = 0, i = best_i, j = best_j, failed = 0, wbase = -1, jbase = 0;
+		u32 ww0 = 0, ww1 = 0, ww2 = 0;
 		while (i >= 0 && j > 0) {
 			const int x0 = i - band_width > 0 ? i - band_width : 0;
-			const int pk = (unsigned char)dir[(int64_t)width_d * i + (j - x0)];
+			const int64_t pos = (int64_t)width_d * i + (j - x0);
+			int t = wbase - i, o;
+			{
+				int64_t P = ((int64_t)width_d * i + ((jbase - t) - x0) - 4) & ~(int64_t)3; if (P < 0) P = 0;
+				const int64_t oo = pos - P;
+				o = oo < 0 || oo >= 12 ? -1 : (int)oo;
+			}
+			if (t < 0 || t >= 64 || o < 0) {      /* (uniform: every lane holds the same walk state) */
+				wbase = i; jbase = j; t = 0;
+				const int r = wbase - tid, jr = jbase - tid, xr = r - band_width > 0 ? r - band_width : 0;
+				int64_t P = ((int64_t)width_d * r + (jr - xr) - 4) & ~(int64_t)3; if (P < 0) P = 0;
+				if (r >= 0) { const u32* src = (const u32*)(dir + P); ww0 = src[0]; ww1 = src[1]; ww2 = src[2]; }
+				int64_t P0 = (pos - 4) & ~(int64_t)3; if (P0 < 0) P0 = 0;
+				o = (int)(pos - P0);
+			}
+			const int sel = o >> 2;
+			const u32 word = xl_shfl(sel <= 0 ? ww0 : sel == 1 ? ww1 : ww2, t);
+			const int pk = (int)((word >> (8 * (o & 3))) & 0xffu);
 			const int d = state == 0 ? 2 + (pk & 1) : state == 1 ? 4 + ((pk >> 1) & 1) : pk >> 2;
 			if (d == 1) { --i; --j; state = 2; cur = 0; }
 			else if (d == 2) { --i; state = 0; cur = 1; }
@@ -2668,20 +2712,23 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 			else if (d == 5) { --j; state = 2; cur = 2; }
 			else { failed = 1; break; }
 			if (cur == prev) ++run;
-			else { if (nops < cigcap) cig[nops] = ((u32)run << 4) | (u32)prev; ++nops; prev = cur; run = 1; }
+			else { if (tid == 0 && nops < cigcap) cig[nops] = ((u32)run << 4) | (u32)prev; ++nops; prev = cur; run = 1; }
 		}
 		if (failed) nops = -1;
 		else {
-			if (cur == 0) { if (nops < cigcap) cig[nops] = ((u32)(run + 1) << 4); ++nops; }
+			if (cur == 0) { if (tid == 0 && nops < cigcap) cig[nops] = ((u32)(run + 1) << 4); ++nops; }
 			else {
-				if (nops < cigcap) cig[nops] = ((u32)run << 4) | (u32)cur; ++nops;
-				if (nops < cigcap) cig[nops] = (1u << 4); ++nops;
+				if (tid == 0 && nops < cigcap) cig[nops] = ((u32)run << 4) | (u32)cur; ++nops;
+				if (tid == 0 && nops < cigcap) cig[nops] = (1u << 4); ++nops;
 			}
 			if (nops > cigcap) { *need = -(int64_t)nops; nops = -2; }
-			else for (int x = 0, y = nops - 1; x < y; ++x, --y) { const u32 t = cig[x]; cig[x] = cig[y]; cig[y] = t; }
+			else {
+				dev_fence();
+				for (int x = tid; x < nops / 2; x += 64) { const u32 tt = cig[x]; cig[x] = cig[nops - 1 - x]; cig[nops - 1 - x] = tt; }
+			}
 		}
 	}
-	wg_fence();
+	dev_fence();
 	return team_bcast0<NW>(lds, nops, tid);
 }
 
@@ -2732,7 +2779,7 @@ __global__ void __launch_bounds__(64 * NW) SSW_WAVES_PER_EU(NW == 1 ? 5 : 4, 8) 
 		}
 		if (nops < 0) break;
 		int sc = 0;
-		if (tid == 0) sc = cigar_score(cig, nops, ref, read, a.mat, a.n, a.gapO, a.gapE);
+		if (tid < 64) sc = cigar_score_wave(cig, nops, ref, read, lds, a.n, a.gapO, a.gapE, tid);      /* (the matrix is in the first KiB of LDS) */
 		sc = team_bcast0<NW>(lds, sc, tid);
 		if (sc == r.score1) break;
 		if (stage || band0 >= full) { nops = -1; break; }
@@ -2742,6 +2789,305 @@ __global__ void __launch_bounds__(64 * NW) SSW_WAVES_PER_EU(NW == 1 ? 5 : 4, 8) 
 	if (tid == 0) {
 		if (nops < 0) { a.res[q].flag = 1; a.res[q].cigarLen = 0; }
 		else { a.res[q].cigarLen = nops; a.res[q].cigar_off = (int64_t)q * a.cigar_stride; }
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * k_trace_diag<TEAM>: the same banded_sw for NARROW bands, SEVERAL alignments per wavefront (round 5).
+ *
+ * What the row kernels above cost a narrow band: a row of 9 .. 31 cells occupies one wavefront for ~110 vector instructions whatever its
+ * width, and 72 % of config 4's alignments (all of a protein search's survivors) never leave bands <= 15.  Here a TEAM of 16 (32) lanes
+ * owns one alignment -- four (two) alignments per wavefront -- and walks the band by ANTI-DIAGONALS, so that no scan is needed:
+ * lane k of a team owns the two band diagonals d = 2k - w and 2k + 1 - w (d = column - row, |d| <= w), and in "pair" s it evaluates the
+ * cells A = (i, i + 2k - w) and then B = (i, i + 2k + 1 - w) of row i = s - k.  Every neighbour is then already there:
+ *     A: left  = lane k-1's B of the pair before (one DPP move each for h and F), up = this lane's B of the pair before, diagonal = its A;
+ *     B: left  = A of this pair, diagonal = this lane's B of the pair before, up = lane k+1's A of THIS pair (one DPP move each for h and E).
+ * A pass over a band of width w takes readLen + w pairs; cells outside the matrix or the band hand on h = 0, E = F = -inf, which is what
+ * the reference's row arrays hold at those places (h_b[0], h_c[0], the forced index `edge` of src/ssw.c:636-639 one past a row's end).
+ * The one place where `edge` lands on a REAL cell -- target coordinates applied as band coordinates: rows 1 .. w + 1 of a band that
+ * spans the whole target (refLen <= 2w + 2) see the last column of the row above as 0 / -inf -- is reproduced explicitly (quirk below).
+ * Values, direction bytes (same packing and [row][band index] layout as k_trace_wave), the row-major strict-> best cell (per lane in
+ * visiting order = row-major within its two diagonals, then max / smallest (row, column) across the team), the doubling loop with its
+ * persistent best, the walk, the re-score and the single full-band retry are the reference's.  A team whose band outgrows it
+ * (w > TEAM - 1) hands over exactly like an alignment that ran out of scratch: need / band / resume state, and a row kernel continues.
+ *
+ * The teams of a wavefront are in different phases at the same time (passes of different lengths, the serial walk back, the re-score):
+ * one flat loop, every iteration = one pair of the teams that are in a pass + one walk step / a few re-score steps of the others; all
+ * cross-lane moves are executed by all lanes in uniform control flow.
+ * ------------------------------------------------------------------------------------------------ */
+template <int TEAM> SSW_DEV u32 team_from_below(u32 keep, u32 v, int k)     /* value of lane k - 1 of the team; lane 0 keeps */
+{
+	if (TEAM == 16) return xl_row_shr1_keep(keep, v);
+	const u32 r = xl_wave_shr1_keep(keep, v);
+	return k == 0 ? keep : r;
+}
+template <int TEAM> SSW_DEV u32 team_from_above(u32 keep, u32 v, int k)     /* value of lane k + 1 of the team; the last lane keeps */
+{
+	if (TEAM == 16) return xl_row_shl1_keep(keep, v);
+	const u32 r = xl_wave_shl1_keep(keep, v);
+	return k == TEAM - 1 ? keep : r;
+}
+
+#define TD_PASS 1
+#define TD_WALK 2
+#define TD_SCORE 3
+#define TD_RETRY 4
+#define TD_REVERSE 5
+#define TD_DONE 0
+
+template <int TEAM>
+__global__ void __launch_bounds__(64) SSW_WAVES_PER_EU(4, 8) k_trace_diag(ssw_trace_args a)
+{
+	SSW_DYN_LDS(lds);
+	constexpr int TPW = 64 / TEAM;
+	const int NEG = -1073741824;
+	const int lane = (int)threadIdx.x, k = lane % TEAM, lead = lane - k;
+	const int job = (int)blockIdx.x * TPW + lane / TEAM;
+	const int n = a.n, gapO = a.gapO, gapE = a.gapE;
+	for (int x = lane; x < n * n && x < 1024; x += 64) lds_st8(lds, (u32)x, (u32)(unsigned char)a.mat[x]);
+	/* The codes a pair needs come from two 256-byte LDS rings per team (read rows, target columns), refilled 64 entries at a time.  A global
+	   load inside the pair loop would make every pair wait for the direction-byte STORES of the pair before it: loads and stores share one
+	   counter (vmcnt) on this target and return out of order with each other, so a wait for a load is a wait for everything. */
+	const u32 ring_rd = 1024u + 512u * (u32)(lane / TEAM), ring_rf = ring_rd + 256u;
+	for (u32 x = 4u * (u32)lane; x < 512u * TPW; x += 256u) lds_st32(lds, 1024u + x, 0u);
+	wave_lds_fence();
+	constexpr int FILL = 64 / TEAM;      /* ring entries a lane fetches per refill of 64 */
+	auto refill = [&](int base, const int8_t* rdp, int rdl, const int8_t* rfp, int rfl) {      /* entries [base, base + 64) of both rings */
+		u32 wr = 0, wf = 0;
+#pragma unroll
+		for (int b = 0; b < FILL; ++b) {
+			const int x = base + FILL * k + b;
+			wr |= (u32)(unsigned char)rdp[x < 0 ? 0 : x >= rdl ? rdl - 1 : x] << (8 * b);
+			wf |= (u32)(unsigned char)rfp[x < 0 ? 0 : x >= rfl ? rfl - 1 : x] << (8 * b);
+		}
+		const u32 at = (u32)(base + FILL * k) & 255u;
+		if (FILL == 4) { lds_st32(lds, ring_rd + at, wr); lds_st32(lds, ring_rf + at, wf); }
+		else { lds_st16(lds, ring_rd + at, wr); lds_st16(lds, ring_rf + at, wf); }
+	};
+
+	/* ---- the team's alignment */
+	int state = TD_DONE, q = 0, refLen = 1, readLen = 1, score = 0, band0 = 1, full = 1, stage = 0;
+	const int8_t* ref = a.tgt; const int8_t* read = a.qcodes;
+	u32* cig = a.cigar; int8_t* dir = (int8_t*)a.scratch; int64_t scap = 0; int32_t* rs = a.resume;
+	int tb_best = 0, tb_i = 0, tb_j = 0;
+	int w = 1;
+	if (job < a.nq) {
+		q = a.qlist[job];
+		const ssw_dres r = a.res[q];
+		if (k == 0) a.need[job] = 0;
+		if (r.want_cigar && r.status == 0) {
+			ref = vm_target(a.vm, a.tgt, q) + r.ref_begin1;
+			read = a.qcodes + a.qoff[vm_query(a.vm, q)] + r.read_begin1;
+			refLen = r.ref_end1 - r.ref_begin1 + 1; readLen = r.read_end1 - r.read_begin1 + 1;
+			score = r.score1;
+			const int d = refLen - readLen;
+			band0 = (d < 0 ? -d : d) + 1; full = refLen > readLen ? refLen : readLen;
+			cig = a.cigar + (int64_t)q * a.cigar_stride;
+			dir = (int8_t*)(a.soff ? a.scratch + a.soff[job] : a.scratch + (int64_t)job * a.scratch_stride);
+			scap = a.soff ? a.soff[job + 1] - a.soff[job] : a.scratch_stride;
+			rs = a.resume + (int64_t)q * 8;
+			w = band0;
+			if (rs[0] > 0) { w = rs[0]; tb_best = rs[1]; tb_i = rs[2]; tb_j = rs[3]; stage = rs[4]; }
+			state = TD_RETRY;      /* (enters the loop through the common "start a pass at band w" code) */
+		}
+	}
+	const int cigcap = (int)a.cigar_stride;
+	/* pass state */
+	int s = 0, S = 0, width_d = 3;
+	int HAp = 0, HBp = 0, EBp = NEG, FBp = NEG;
+	int lb = 0, li = 0, lj = 0;
+	/* walk / re-score state (the same in every lane of the team), and this lane's twelve direction bytes of the current batch */
+	int wi = 0, wj = 0, wst = 2, cur = 0, prev = 0, run = 0, nops = 0, wbase = -1, jbase = 0;
+	u32 ww0 = 0, ww1 = 0, ww2 = 0;
+	int oi = 0, rp = 0, qp = 0, sc = 0;
+	bool fresh = state == TD_RETRY;      /* first entry: the band is the resumed / first one, not the full-band retry */
+
+	while (wave_any(state != TD_DONE)) {
+		/* ---- start a pass at band w (first entry, next doubling, full-band retry): team-uniform */
+		if (wave_any(state == TD_RETRY)) {
+			if (state == TD_RETRY) {
+				if (!fresh) { stage = 1; w = full; tb_best = 0; tb_i = 0; tb_j = 0; }
+				fresh = false;
+				const int64_t want = (int64_t)(2 * w + 1) * readLen + 16;
+				if (w > TEAM - 1 || want > scap) {      /* hand over to a row kernel: the band that did not fit and what it needs there (three padded rows + directions) */
+					if (k == 0) {
+						const int64_t need = 3 * ((int64_t)(2 * w + 16) * 6 + 64) + (int64_t)(2 * w + 1) * readLen + 64;
+						a.need[job] = (int)((need + 4095) >> 12); a.need[a.nq + job] = w;
+						rs[0] = w; rs[1] = tb_best; rs[2] = tb_i; rs[3] = tb_j; rs[4] = stage;
+					}
+					state = TD_DONE;
+				} else {
+					width_d = 2 * w + 1; s = 0; S = readLen + w;
+					HAp = 0; HBp = 0; EBp = NEG; FBp = NEG;
+					lb = tb_best; li = 0; lj = 0;
+					refill(0, read, readLen, ref, refLen); refill(64, read, readLen, ref, refLen); refill(128, read, readLen, ref, refLen);
+					state = TD_PASS;
+				}
+			}
+			wave_lds_fence();
+		}
+		/* ---- one pair of every team that is in a pass */
+		if (wave_any(state == TD_PASS)) {
+			const bool P = state == TD_PASS;
+			if (wave_any(P && s > 0 && (s & 63) == 0)) {      /* entries [s + 128, s + 192): needed from pair s + 113 on */
+				if (P && s > 0 && (s & 63) == 0) refill(s + 128, read, readLen, ref, refLen);
+				wave_lds_fence();
+			}
+			const int i = s - k, jA = s + k - w, jB = jA + 1;
+			const int cr = lds_ld8s(lds, ring_rd + ((u32)i & 255u)), cA = lds_ld8s(lds, ring_rf + ((u32)jA & 255u)), cB = lds_ld8s(lds, ring_rf + ((u32)jB & 255u));
+			const bool rowok = P && i >= 0 && i < readLen;
+			const bool vA = rowok && k <= w && jA >= 0 && jA < refLen;
+			const bool vB = rowok && k < w && jB >= 0 && jB < refLen;
+			/* the reference's forced index on a real cell (see above): rows 1 .. w + 1, last target column, band spanning the target */
+			const bool qrow = i >= 1 && i <= w + 1 && refLen <= 2 * w + 2;
+			const int x0 = i - w > 0 ? i - w : 0;
+			int8_t* line = dir + (int64_t)width_d * i - x0;
+			/* cell A */
+			const int hl = (int)team_from_below<TEAM>(0u, (u32)HBp, k), fl = (int)team_from_below<TEAM>((u32)NEG, (u32)FBp, k);
+			int hA, eA, fA;
+			{
+				const bool qk = qrow && jA == refLen - 1;
+				const int hu = qk ? 0 : HBp, eu = qk ? NEG : EBp;
+				const int open = hu - gapO, ext = eu - gapE;
+				const int e = open > ext ? open : ext, de3 = open > ext ? 1 : 0;
+				const int fo = hl - gapO, fe = fl - gapE;
+				const int f = fo > fe ? fo : fe, df5 = fo > fe ? 1 : 0;
+				const int e1 = e > 0 ? e : 0, f1 = f > 0 ? f : 0, gap = e1 > f1 ? e1 : f1;
+				const int dia = HAp + lds_ld8s(lds, (u32)(cA * n + cr));
+				const int h = gap > dia ? gap : dia;
+				const int dh = gap <= dia ? 1 : (e1 > f1 ? 2 + de3 : 4 + df5);
+				if (vA) {
+					line[jA] = (int8_t)(de3 | (df5 << 1) | (dh << 2));
+					if (h > lb) { lb = h; li = i; lj = jA; }
+				}
+				hA = vA ? h : 0; eA = vA ? e : NEG; fA = vA ? f : NEG;
+			}
+			/* cell B */
+			const int hu2 = (int)team_from_above<TEAM>(0u, (u32)hA, k), eu2 = (int)team_from_above<TEAM>((u32)NEG, (u32)eA, k);
+			int hB, eB, fB;
+			{
+				const bool qk = qrow && jB == refLen - 1;
+				const int hu = qk ? 0 : hu2, eu = qk ? NEG : eu2;
+				const int open = hu - gapO, ext = eu - gapE;
+				const int e = open > ext ? open : ext, de3 = open > ext ? 1 : 0;
+				const int fo = hA - gapO, fe = fA - gapE;
+				const int f = fo > fe ? fo : fe, df5 = fo > fe ? 1 : 0;
+				const int e1 = e > 0 ? e : 0, f1 = f > 0 ? f : 0, gap = e1 > f1 ? e1 : f1;
+				const int dia = HBp + lds_ld8s(lds, (u32)(cB * n + cr));
+				const int h = gap > dia ? gap : dia;
+				const int dh = gap <= dia ? 1 : (e1 > f1 ? 2 + de3 : 4 + df5);
+				if (vB) {
+					line[jB] = (int8_t)(de3 | (df5 << 1) | (dh << 2));
+					if (h > lb) { lb = h; li = i; lj = jB; }
+				}
+				hB = vB ? h : 0; eB = vB ? e : NEG; fB = vB ? f : NEG;
+			}
+			if (P) { HAp = hA; HBp = hB; EBp = eB; FBp = fB; ++s; }
+			/* ---- end of a pass: the team's best cell, then the reference's loop condition (src/ssw.c:679) */
+			if (wave_any(P && s == S)) {
+				const bool E = P && s == S;
+				int rb = lb, ri = li, rj = lj;
+				if (rb <= tb_best) { rb = NEG; ri = 0x7fffffff; rj = 0x7fffffff; }
+#pragma unroll
+				for (int d = 1; d < TEAM; d <<= 1) {
+					const int oh = (int)xl_shfl((u32)rb, lane ^ d), oi2 = (int)xl_shfl((u32)ri, lane ^ d), oj2 = (int)xl_shfl((u32)rj, lane ^ d);
+					if (oh > rb || (oh == rb && (oi2 < ri || (oi2 == ri && oj2 < rj)))) { rb = oh; ri = oi2; rj = oj2; }
+				}
+				dev_fence();      /* the direction bytes the team's lanes stored are visible to its lane 0 (a full-band retry rewrites lines an earlier walk has read) */
+				if (E) {
+					if (rb > tb_best) { tb_best = rb; tb_i = ri; tb_j = rj; }
+					if (tb_best < score && 2 * w <= full) { w *= 2; fresh = true; state = TD_RETRY; }      /* next doubling (may hand over) */
+					else {
+						wi = tb_i; wj = tb_j; wst = 2; cur = 0; prev = 0; run = 0; nops = 0; wbase = -1; jbase = 0;
+						state = TD_WALK;
+					}
+				}
+			}
+		}
+		/* ---- walk back (src/ssw.c:682-762).  The walk is a chain of 10^4 dependent one-byte loads for a 10-kb read -- at one memory latency
+		   each it took longer than the passes.  Here every lane of the team follows the same walk (team-uniform state), and the bytes come in
+		   BATCHES: lane t fetches twelve bytes of row (base - t) around the band index the path has if it keeps to its diagonal; a step then
+		   takes its byte from the lane that holds its row with one cross-lane move.  A path that drifts out of a row's window (a long
+		   run of gap steps) or leaves the TEAM rows of the batch starts a new batch where it stands. */
+		if (wave_any(state == TD_WALK)) {
+			const bool Wk = state == TD_WALK;
+			const bool stepping = Wk && wi >= 0 && wj > 0;
+			int64_t pos; int o, t;
+			{
+				const int x0 = wi - w > 0 ? wi - w : 0;
+				pos = (int64_t)width_d * wi + (wj - x0);
+				t = wbase - wi;
+				const int jr = jbase - t, xr = wi - w > 0 ? wi - w : 0;
+				int64_t P = ((int64_t)width_d * wi + (jr - xr) - 4) & ~(int64_t)3; if (P < 0) P = 0;
+				const int64_t oo = pos - P;
+				o = oo < 0 || oo >= 12 ? -1 : (int)oo;
+			}
+			const bool reload = stepping && (t < 0 || t >= TEAM || o < 0);
+			if (wave_any(reload)) {
+				if (reload) {
+					wbase = wi; jbase = wj; t = 0;
+					const int r = wbase - k, jr = jbase - k, xr = r - w > 0 ? r - w : 0;
+					int64_t P = ((int64_t)width_d * r + (jr - xr) - 4) & ~(int64_t)3; if (P < 0) P = 0;
+					if (r >= 0) { const u32* src = (const u32*)(dir + P); ww0 = src[0]; ww1 = src[1]; ww2 = src[2]; }
+					int64_t P0 = ((int64_t)width_d * wi + (wj - (wi - w > 0 ? wi - w : 0)) - 4) & ~(int64_t)3; if (P0 < 0) P0 = 0;
+					o = (int)(pos - P0);
+				}
+			}
+			const int sel = o >> 2;
+			const u32 mine = sel <= 0 ? ww0 : sel == 1 ? ww1 : ww2;
+			const u32 word = xl_shfl(mine, lead + (stepping ? t : 0));
+			if (stepping) {
+				const int pk = (int)((word >> (8 * (o & 3))) & 0xffu);
+				const int d = wst == 0 ? 2 + (pk & 1) : wst == 1 ? 4 + ((pk >> 1) & 1) : pk >> 2;
+				bool bad = false;
+				if (d == 1) { --wi; --wj; wst = 2; cur = 0; }
+				else if (d == 2) { --wi; wst = 0; cur = 1; }
+				else if (d == 3) { --wi; wst = 2; cur = 1; }
+				else if (d == 4) { --wj; wst = 1; cur = 2; }
+				else if (d == 5) { --wj; wst = 2; cur = 2; }
+				else bad = true;
+				if (bad) { if (k == 0) { a.res[q].flag = 1; a.res[q].cigarLen = 0; } state = TD_DONE; }      /* banded_sw returns NULL: no retry (src/ssw.c:947) */
+				else if (cur == prev) ++run;
+				else { if (k == 0 && nops < cigcap) cig[nops] = ((u32)run << 4) | (u32)prev; ++nops; prev = cur; run = 1; }
+			} else if (Wk) {
+				if (cur == 0) { if (k == 0 && nops < cigcap) cig[nops] = ((u32)(run + 1) << 4); ++nops; }
+				else {
+					if (k == 0 && nops < cigcap) cig[nops] = ((u32)run << 4) | (u32)cur; ++nops;
+					if (k == 0 && nops < cigcap) cig[nops] = (1u << 4); ++nops;
+				}
+				if (nops > cigcap) { if (k == 0) { a.need[job] = -1; a.need[a.nq + job] = w; } state = TD_DONE; }      /* "CIGAR slot too small": the host reports it */
+				else { oi = 0; rp = 0; qp = 0; sc = 0; state = TD_REVERSE; }
+			}
+			if (wave_any(state == TD_REVERSE)) {      /* the operations were emitted last to first: reversed in place by the whole team, then re-scored */
+				dev_fence();
+				if (state == TD_REVERSE) {
+					for (int x = k; x < nops / 2; x += TEAM) { const u32 tt = cig[x]; cig[x] = cig[nops - 1 - x]; cig[nops - 1 - x] = tt; }
+				}
+				dev_fence();
+				if (state == TD_REVERSE) state = TD_SCORE;
+			}
+		}
+		/* ---- cigar_alignment_score (src/ssw.c:785-811): one operation per iteration, the residues of an M run spread over the team's lanes */
+		if (wave_any(state == TD_SCORE)) {
+			const bool Sc = state == TD_SCORE, fin = Sc && oi == nops;
+			int part = 0, olen = 0, oop = 0;
+			if (Sc && !fin) {
+				const u32 c = cig[oi];
+				olen = (int)(c >> 4); oop = (int)(c & 0xf);
+				if (oop == 0) for (int x = k; x < olen; x += TEAM) part += lds_ld8s(lds, (u32)((int)ref[rp + x] * n + read[qp + x]));
+			}
+#pragma unroll
+			for (int d = 1; d < TEAM; d <<= 1) part += (int)xl_shfl((u32)part, lane ^ d);
+			if (Sc && !fin) {
+				if (oop == 0) { sc += part; rp += olen; qp += olen; }
+				else { sc -= gapO + (olen > 1 ? (olen - 1) * gapE : 0); if (oop == 1) qp += olen; else if (oop == 2) rp += olen; }
+				++oi;
+			} else if (fin) {
+				if (sc == score) { if (k == 0) { a.res[q].cigarLen = nops; a.res[q].cigar_off = (int64_t)q * a.cigar_stride; } state = TD_DONE; }
+				else if (stage || band0 >= full) { if (k == 0) { a.res[q].flag = 1; a.res[q].cigarLen = 0; } state = TD_DONE; }
+				else state = TD_RETRY;
+			}
+		}
 	}
 }
 
@@ -3175,6 +3521,16 @@ extern "C" int ssw_shim_launch_trace(const ssw_trace_args* a, void* stream)
 	ssw_trace_args args = *a;
 	if (args.nq <= 0) return 0;
 	SSW_LAUNCH(k_trace, ssw_trace_args, args, (args.nq + 63) / 64, 64, 0, stream);
+	return SSW_LAUNCH_OK();
+}
+
+extern "C" int ssw_shim_launch_trace_diag(int team, const ssw_trace_args* a, void* stream)
+{
+	ssw_trace_args args = *a;
+	if (args.nq <= 0) return 0;
+	if (args.n * args.n > 1024) return -1;      /* (the matrix lives in 1 KiB of LDS; SSW_MAX_N = 32) */
+	if (team == 32) SSW_LAUNCH((k_trace_diag<32>), ssw_trace_args, args, (args.nq + 1) / 2, 64, 1024 + 512 * 2, stream);
+	else SSW_LAUNCH((k_trace_diag<16>), ssw_trace_args, args, (args.nq + 3) / 4, 64, 1024 + 512 * 4, stream);
 	return SSW_LAUNCH_OK();
 }
 

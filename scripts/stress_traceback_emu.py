@@ -2,6 +2,7 @@
 """Build container (no GPU): randomized stress of the traceback kernels on the SIMT emulator -- reads with random deletions / insertions /
 unrelated reads, random scoring, teams of 1 / 4 / 16 wavefronts -- every record and CIGAR against the unmodified reference (tests/parity.py).
 usage: stress_traceback_emu.py <seconds> <seed>     (end of round 4: 1 386 cases in 4 x 7 minutes, 0 mismatches)
+       stress_traceback_emu.py <seconds> <seed> --narrow            the 16-lane anti-diagonal teams: short reads / targets, bands spanning the target, hand-overs
        stress_traceback_emu.py <seconds> <seed> --free-gap-open     the gapO = 0 regime with every CIGAR flag (tests/parity.py free_gap_open_case):
                                                                     no call may fail, every record / CIGAR (mostly `flag 1`) as the reference's"""
 import os, sys, time
@@ -9,11 +10,26 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'complete-striped-smith-waterman-library_amd'))
 import ssw_amd
-from parity import compare_batch, free_gap_open_case, make_reads
+from parity import compare_batch, free_gap_open_case, make_reads, narrow_band_batches
 from sswutil import dna_matrix, random_ref, blosum50
 lib = ssw_amd.load(os.path.join(ROOT, 'tests', 'emu', 'libssw_emu.so'))
 t_end = time.time() + float(sys.argv[1])
 seed = int(sys.argv[2]); it = 0; nbad = 0
+if "--narrow" in sys.argv:      # the 16-lane traceback teams (k_trace_diag, opt-in): tests/parity.py narrow_band_batches
+    os.environ["SSW_GPU_TRACE_DIAG"] = "1"
+    ctx = ssw_amd.Context(0, lib)
+    rng = np.random.default_rng(seed); nal = 0
+    while time.time() < t_end:
+        for reads, ref, mat, gapO, gapE, flag in narrow_band_batches(rng, 1):
+            it += 1; nal += len(reads)
+            Q = ctx.upload(reads); T = ctx.upload([ref])
+            res, cig = ctx.align_batch(Q, T, mat, 5, gapO, gapE, flag, 0, 0, -1, 2)
+            Q.free(); T.free()
+            bad = compare_batch(res, cig, reads, [ref], mat, 5, gapO, gapE, flag, 0, 0, -1, 2)
+            if bad:
+                nbad += 1; print("MISMATCH batch", it, "seed", seed, bad[:2])
+    print("narrow bands: batches", it, "alignments", nal, "mismatching batches", nbad)
+    sys.exit(1 if nbad else 0)
 if "--free-gap-open" in sys.argv:
     ctx = ssw_amd.Context(0, lib)
     rng = np.random.default_rng(seed); nal = nflag1 = nfail = 0

@@ -117,6 +117,16 @@ SSW_DEV u32 xl_wave_shr1_keep(u32 keep, u32 v)
 	int l = emu::cur->lane;
 	return emu::exchange(v, l - 1, l != 0, keep);
 }
+SSW_DEV u32 xl_row_shl1_keep(u32 keep, u32 v)
+{
+	int l = emu::cur->lane;
+	return emu::exchange(v, l + 1, (l & 15) != 15, keep);
+}
+SSW_DEV u32 xl_wave_shl1_keep(u32 keep, u32 v)
+{
+	int l = emu::cur->lane;
+	return emu::exchange(v, l + 1, l != 63, keep);
+}
 template <int N> SSW_DEV u32 xl_row_ror(u32 v)
 {
 	int l = emu::cur->lane;

@@ -2,6 +2,7 @@
 import numpy as np
 
 from sswutil import RES_FIELDS, cigar_str, oracle_align, ref_align, ref_lib
+from sswutil import dna_matrix as _dna_matrix, random_ref as _random_ref
 
 
 def expected(read, mat, n, ref, gapO, gapE, flag, filters, filterd, maskLen, score_size, use_ref=True):
@@ -82,3 +83,24 @@ def free_gap_open_case(rng):
         reads = [rng.integers(0, nc, size=len(r), dtype=np.int8) for r in reads]
     return (reads, ref, mat, n, 0, int(rng.choice([0, 1, 1, 2, 3])), int(rng.choice([1, 2, 9, 12, 15])),
             int(rng.choice([0, 1000])), int(rng.choice([-1, 15, 40])))
+
+
+def narrow_band_batches(rng, count):
+    """batches for the 16-lane traceback teams (k_trace_diag): several alignments per wavefront, teams partly filled, reads and targets short
+    enough that a band spans the whole target (the reference's forced index then lands on a real cell: rows 1 .. w + 1, last column), indels
+    that make a band double once or twice inside the team's range, some that outgrow it (hand-over to the row kernel), unrelated reads"""
+    for _ in range(count):
+        kind = rng.random()
+        if kind < 0.5:      # tiny: the band covers the target
+            ref = rng.integers(0, 4, size=int(rng.integers(6, 70)), dtype=np.int8)
+            nq = int(rng.integers(1, 14))
+            reads = make_reads(rng, ref, nq, rng.integers(3, 60, size=nq), 4, sub=0.08, ins=0.05, dele=0.05, frac_random=0.3)
+        else:
+            ref = _random_ref(int(rng.integers(200, 1500)), int(rng.integers(1 << 30)), 4)
+            nq = int(rng.integers(3, 11))
+            reads = make_reads(rng, ref, nq, rng.integers(30, 420, size=nq), 4, sub=0.04, ins=0.02, dele=0.02, frac_random=0.15)
+            if rng.random() < 0.4:      # one read with a long deletion: its band starts beyond the team or outgrows it
+                o = int(rng.integers(0, len(ref) - 150))
+                reads[0] = np.ascontiguousarray(np.concatenate([ref[o:o + 50], ref[o + 50 + int(rng.integers(10, 40)):o + 140]]))
+        gapE = int(rng.integers(1, 3)); gapO = gapE + int(rng.integers(1, 5))
+        yield reads, ref, _dna_matrix(int(rng.integers(1, 4)), int(rng.integers(1, 5))), gapO, gapE, int(rng.choice([1, 2, 2, 9, 15]))

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import ssw_amd
-from parity import compare_batch, free_gap_open_case, make_reads
+from parity import compare_batch, free_gap_open_case, make_reads, narrow_band_batches
 from sswutil import blosum50, dna_matrix, random_ref
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -165,11 +165,15 @@ def test_traceback_band_growth_and_both_kernels(ectx, wave, monkeypatch):
         _run(ectx, [np.ascontiguousarray(r, dtype=np.int8) for r in reads], [ref], dna_matrix(2, 2), 5, flag=flag)
 
 
-@pytest.mark.parametrize("teams", [None, "4", "16"])
+@pytest.mark.parametrize("teams", [None, "4", "16", "throughput"])
 def test_long_read_wave_traceback_resumes_across_rounds(ectx, teams, monkeypatch):
     """reads above 1024 bases take the wavefront traceback by default; a 90-base deletion and a 70-base insertion push the
-    band through several doublings, i.e. through scratch-negotiation rounds that resume at the band that did not fit"""
-    if teams:
+    band through several doublings, i.e. through scratch-negotiation rounds that resume at the band that did not fit.
+    "throughput": the team sizes of a round with very many pending alignments (one wavefront up to 255 cells per row, four up to 3071;
+    SSW_GPU_TRACE_MANY=0 makes this toy round one of those)"""
+    if teams == "throughput":
+        monkeypatch.setenv("SSW_GPU_TRACE_MANY", "0")
+    elif teams:
         monkeypatch.setenv("SSW_GPU_TRACE_WAVES", teams)
     rng = np.random.default_rng(44)
     ref = random_ref(2600, 23, 4)
@@ -314,6 +318,20 @@ def test_column_reduction_with_mixed_lengths(ectx, monkeypatch):
     _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
     monkeypatch.delenv("SSW_GPU_SEG_REDUCE")
     _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
+
+
+def test_narrow_band_traceback_teams(ectx, monkeypatch):
+    """k_trace_diag (round 5, opt-in: SSW_GPU_TRACE_DIAG=1 -- bit-exact but measured no faster than the row kernels, so off by default):
+    four alignments per wavefront on anti-diagonals, cooperative walk back and re-score, hand-over of bands that outgrow the team --
+    against the reference; the same batches on the default path (row kernels, cooperative walk) as well"""
+    rng = np.random.default_rng(31)
+    batches = list(narrow_band_batches(rng, 40))
+    monkeypatch.setenv("SSW_GPU_TRACE_DIAG", "1")
+    for reads, ref, mat, gapO, gapE, flag in batches:
+        _run(ectx, reads, [ref], mat, 5, gapO, gapE, flag=flag)
+    monkeypatch.delenv("SSW_GPU_TRACE_DIAG")
+    for reads, ref, mat, gapO, gapE, flag in batches[:12]:
+        _run(ectx, reads, [ref], mat, 5, gapO, gapE, flag=flag)
 
 
 def test_bad_arguments_fail_loudly(ectx):

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from parity import compare_batch, free_gap_open_case, make_reads
+from parity import compare_batch, free_gap_open_case, make_reads, narrow_band_batches
 from sswutil import RES_FIELDS, blosum50, dna_matrix, encode_dna, random_ref, sample_reads
 
 pytestmark = pytest.mark.gpu
@@ -341,6 +341,37 @@ def test_layout_dependent_gap_regime(gpu_ctx):
         _run(gpu_ctx, reads, [ref], mat, n, gapO, gapE, flag=int(rng.choice([0, 1, 2, 8, 9, 15, 4, 6, 3])),
              filters=int(rng.choice([0, 0, 30, 80])), filterd=int(rng.choice([0, 20, 1000])),
              maskLen=int(rng.choice([-1, -1, 15, 10, 40])), ss=int(rng.choice([2, 2, 2, 0, 1])))
+
+
+def test_narrow_band_traceback_teams(gpu_ctx, gpu_hctx, monkeypatch):
+    """narrow bands (emulator twin in tests/test_emu_pipeline.py): 400 batches of short reads / targets against the reference on the default
+    path (row kernels with the cooperative walk back) and with k_trace_diag in front (SSW_GPU_TRACE_DIAG=1, opt-in: four alignments per
+    wavefront on anti-diagonals); then config 4's first 400 reads (10 kb) against the fixture, both ways"""
+    import workloads as W
+    rng = np.random.default_rng(31)
+    batches = list(narrow_band_batches(rng, 400))
+    for reads, ref, mat, gapO, gapE, flag in batches:
+        _run(gpu_ctx, reads, [ref], mat, 5, gapO, gapE, flag=flag)
+    monkeypatch.setenv("SSW_GPU_TRACE_DIAG", "1")
+    for reads, ref, mat, gapO, gapE, flag in batches:
+        _run(gpu_hctx, reads, [ref], mat, 5, gapO, gapE, flag=flag)
+    monkeypatch.delenv("SSW_GPU_TRACE_DIAG")
+    z4 = np.load(os.path.join(HERE, "golden", "full", "config4_block0.npz"))
+    ref4, reads4, p4 = W.dna_config(4, 0)
+    k4 = 400
+    for ctx, env in ((gpu_ctx, None), (gpu_hctx, "1")):
+        if env is not None:
+            monkeypatch.setenv("SSW_GPU_TRACE_DIAG", env)
+        Q = ctx.upload(list(reads4[:k4])); T = ctx.upload([ref4])
+        try:
+            res, cig = ctx.align_batch(Q, T, dna_matrix(2, 2), 5, 3, 1, 2, 0, 0, p4["mask_len"], 2)
+        finally:
+            Q.free(); T.free()
+        g = res[:, 0]
+        got = np.stack([g["score1"], g["score2"], g["ref_begin1"], g["ref_end1"], g["read_begin1"], g["read_end1"], g["ref_end2"], g["cigarLen"], g["flag"]], axis=1).astype(np.int32)
+        assert (got == z4["fields"][:k4]).all()
+        hsh = np.array([W.fnv1a_words(cig[int(x["cigar_off"]):int(x["cigar_off"]) + int(x["cigarLen"])]) if x["cigarLen"] > 0 else 0 for x in g], dtype=np.uint32)
+        assert (hsh == z4["cigar_fnv"][:k4]).all()
 
 
 def test_free_gap_open_with_traceback(gpu_ctx):
