@@ -88,6 +88,10 @@ SSW_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
    out NOT to stop it from hoisting a lane's loads of other lanes' slots above the stores (seen on gfx950, ROCm 7.2) -- and
    (b) nothing more than lgkmcnt(0).  Global loads in flight are not waited for. */
 SSW_DEV void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+/* workgroup barrier that orders LDS traffic ONLY: __syncthreads() is also a memory fence, i.e. s_waitcnt vmcnt(0) in front of the s_barrier --
+   a kernel that streams direction bytes to HBM and exchanges band rows through LDS then waits for a store round trip at every barrier
+   (two per band row in the traceback teams).  The stores stay in flight here; whoever reads them back later fences first. */
+SSW_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 /* LDS accessors with byte offsets into the dynamic segment */
 SSW_DEV u32x4 lds_ld128(const unsigned char* lds, u32 off) { return *(const u32x4*)(lds + off); }

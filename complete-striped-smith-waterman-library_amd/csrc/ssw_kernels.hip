@@ -2257,7 +2257,7 @@ template <bool L> struct TraceRows {
 /* all threads of the alignment's team (NW wavefronts) see each other's LDS / scratch writes afterwards */
 template <bool L, int NW> SSW_DEV void trace_sync()
 {
-	if (NW > 1) { if (!L) wg_fence(); __syncthreads(); }
+	if (NW > 1) { if (!L) { wg_fence(); __syncthreads(); } else lds_barrier(); }
 	else if (L) wave_lds_fence();
 	else wg_fence();
 }
@@ -2343,7 +2343,7 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 			int P = NEG;                                            /* ... then across the wavefronts to the left: s of the cell before lane 0 */
 			if (NW > 1) {
 				if (lane == 63) lds_st32(lds, TX_T + 4u * (u32)wv, (u32)s);
-				__syncthreads();
+				lds_barrier();
 				{   /* every wavefront scans the (at most 16) wave totals itself: lane v holds T_v, decay 64 m per wavefront */
 					int t = lane < NW ? (int)lds_ld32(lds, TX_T + 4u * (u32)lane) : NEG, o;
 					o = (int)xl_row_shr_keep<1>((u32)NEG, (u32)t) - 64 * m; t = o > t ? o : t;
@@ -2369,7 +2369,7 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 			if (NW > 1) {
 				if (lane == 63) { lds_st32(lds, TX_H + 4u * (u32)wv, (u32)h); lds_st32(lds, TX_F + 4u * (u32)wv, (u32)F); }
 				if (tid == last) { lds_st32(lds, TX_CARRY, (u32)F); lds_st32(lds, TX_CARRY + 4, (u32)A); lds_st32(lds, TX_CARRY + 8, (u32)h); }
-				__syncthreads();
+				lds_barrier();
 				int kh = carryH, kf = carryF;
 				if (wv > 0) { kh = (int)lds_ld32(lds, TX_H + 4u * (u32)(wv - 1)); kf = (int)lds_ld32(lds, TX_F + 4u * (u32)(wv - 1)); }
 				hleft = (int)xl_wave_shr1_keep((u32)kh, (u32)h); Fleft = (int)xl_wave_shr1_keep((u32)kf, (u32)F);
@@ -2400,12 +2400,12 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 	}
 	if (NW > 1) {
 		if (lane == 0) { lds_st32(lds, TX_BEST + 12u * (u32)wv, (u32)lb); lds_st32(lds, TX_BEST + 12u * (u32)wv + 4, (u32)li); lds_st32(lds, TX_BEST + 12u * (u32)wv + 8, (u32)lj); }
-		__syncthreads();
+		lds_barrier();
 		for (int v = 0; v < NW; ++v) {
 			const int oh = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v), oi = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v + 4), oj = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v + 8);
 			if (oh > lb || (oh == lb && (oi < li || (oi == li && oj < lj)))) { lb = oh; li = oi; lj = oj; }
 		}
-		__syncthreads();
+		lds_barrier();
 	}
 	if (lb > tb.best) { tb.best = lb; tb.i = li; tb.j = lj; }
 }
@@ -2533,7 +2533,7 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 		int Pw = wv == 0 ? 0 : NEG;                   /* S at the cell before this wavefront's first one; cell 0 of the row holds h_c[0] = 0 */
 		if (NW > 1) {
 			if (lane == 63) lds_st32(lds, TX_T + 4u * (u32)wv, (u32)V);
-			__syncthreads();                                /* barrier 1: wave totals; every phase-1 read of the previous row is done */
+			lds_barrier();                                /* barrier 1: wave totals; every phase-1 read of the previous row is done */
 			if (has) {
 			int t = lane < NW ? (int)lds_ld32(lds, TX_T + 4u * (u32)lane) : NEG, o;
 			if (lane == 0) { const int z = 0 - 64 * D; t = z > t ? z : t; }      /* the row's cell 0 decayed to the end of wavefront 0 */
@@ -2607,14 +2607,14 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 		if (oh > lb || (oh == lb && (oi < li || (oi == li && oj < lj)))) { lb = oh; li = oi; lj = oj; }
 	}
 	if (NW > 1) {
-		__syncthreads();
+		lds_barrier();
 		if (lane == 0) { lds_st32(lds, TX_BEST + 12u * (u32)wv, (u32)lb); lds_st32(lds, TX_BEST + 12u * (u32)wv + 4, (u32)li); lds_st32(lds, TX_BEST + 12u * (u32)wv + 8, (u32)lj); }
-		__syncthreads();
+		lds_barrier();
 		for (int v = 0; v < NW; ++v) {
 			const int oh = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v), oi = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v + 4), oj = (int)lds_ld32(lds, TX_BEST + 12u * (u32)v + 8);
 			if (oh > lb || (oh == lb && (oi < li || (oi == li && oj < lj)))) { lb = oh; li = oi; lj = oj; }
 		}
-		__syncthreads();
+		lds_barrier();
 	} else wave_lds_fence();
 	if (lb > tb.best) { tb.best = lb; tb.i = li; tb.j = lj; }
 }
@@ -2624,9 +2624,9 @@ template <int NW> SSW_DEV int team_bcast0(unsigned char* lds, int v, int tid)
 {
 	if (NW == 1) return wave_bcast(v, 0);
 	if (tid == 0) lds_st32(lds, TX_BCAST, (u32)v);
-	__syncthreads();
+	lds_barrier();
 	const int r = (int)lds_ld32(lds, TX_BCAST);
-	__syncthreads();
+	lds_barrier();
 	return r;
 }
 

@@ -175,6 +175,7 @@ SSW_DEV unsigned long long wave_ballot(bool p)
 	return m;
 }
 SSW_DEV void wave_lds_fence() { emu::wave_sync(); }
+SSW_DEV void lds_barrier() { emu::block_sync(); }
 
 static inline void emu_lds_check(u32 off, u32 bytes, u32 align, const char* what)
 {
