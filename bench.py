@@ -486,6 +486,25 @@ def bench_dna(args, world, rank, local_rank, dist):
                                    "note": "HBM is not the binding resource of this path (see roofline)"}
             out["roofline"]["traffic"] = traffic      # (HBM GB/s of the same kernel from the PMC passes: the contract's key; details in roofline_hbm)
             out["roofline"]["traffic_unit"] = "GB/s of HBM traffic (FETCH_SIZE + WRITE_SIZE), see roofline_hbm"
+            # the same batch under the library's DEFAULT scratch budget (min(64 GiB, half of the free HBM): what a caller gets who does not say
+            # "this device is mine"), on a second context, two steps after one warm-up -- next to the exclusive budget the timed region used
+            if world == 1 and not args.quiet and own_device(args, world, lib) and args.lib is None:
+                try:
+                    ctx2 = ssw_amd.Context(local_rank % ndev, lib)
+                    b2 = int(lib.ssw_gpu_get_budget(ctx2.h))
+                    qh2 = lib.ssw_gpu_seqs_upload(ctx2.h, qcodes.ctypes.data_as(C.POINTER(C.c_int8)), off.ctypes.data_as(C.POINTER(C.c_int64)), nreads)
+                    Qd = ssw_amd.Seqs.__new__(ssw_amd.Seqs); Qd.ctx = ctx2; Qd.count = nreads; Qd.h = qh2
+                    Td = ctx2.upload([ref])
+                    run2 = lambda: ctx2.align_batch(Qd, Td, mat, 5, args.gap_open, args.gap_extend, flag, 0, 0, p["mask_len"], 2, want_cigar=want_cigar)
+                    run2()
+                    t2 = time.perf_counter(); run2(); run2(); d2 = (time.perf_counter() - t2) / 2
+                    out["value_default_budget"] = {"value": round(cells_per_step / d2 / 1e9, 2), "unit": "GCUPS", "scratch_budget_gib": round(b2 / 2.0 ** 30, 1),
+                                                   "fill_launches_per_step": int(ctx2.timing()["fill_launches"]),
+                                                   "note": "same batch, a second context with the library's default budget; `value` ran under ssw_gpu_set_budget_exclusive "
+                                                           "(%.1f GiB); the budget sweep is profiles/round5_budget_sweep_config2.txt" % (budget / 2.0 ** 30)}
+                    Qd.free(); Td.free(); ctx2.close()
+                except Exception as e:      # the metric's line must survive a failure here
+                    out["value_default_budget"] = {"error": "%s: %s" % (type(e).__name__, e)}
             # PCIe-inclusive rate: one more step with the reads uploaded (and freed) inside it
             if world == 1 and not args.quiet:
                 t1 = time.perf_counter()
