@@ -143,6 +143,9 @@ def parse_args(argv=None):
     ap.add_argument("--also", default=None,
                     help="comma-separated other BASELINE configs run for 2 steps each AFTER the timed region and attached to the line as "
                          "`also` (default: 3,4,5 when the metric's config runs as stated on one GPU; 'none' to skip)")
+    ap.add_argument("--plain", action="store_true",
+                    help="profiling runs: no second context under the default scratch budget after the timed region (its launches have another size and "
+                         "would mix into the per-kernel statistics of rocprofv3)")
     ap.add_argument("--full", action="store_true",
                     help="config 3 at its STATED size: the 1M reads = 50 read blocks of 20 000, all of them, divided over the ranks (block b on rank b mod N: "
                          "strong scaling -- the 1/2/4/8-GPU lines are the same job); a step is one pass over all blocks")
@@ -488,7 +491,7 @@ def bench_dna(args, world, rank, local_rank, dist):
             out["roofline"]["traffic_unit"] = "GB/s of HBM traffic (FETCH_SIZE + WRITE_SIZE), see roofline_hbm"
             # the same batch under the library's DEFAULT scratch budget (min(64 GiB, half of the free HBM): what a caller gets who does not say
             # "this device is mine"), on a second context, two steps after one warm-up -- next to the exclusive budget the timed region used
-            if world == 1 and not args.quiet and own_device(args, world, lib) and args.lib is None:
+            if world == 1 and not args.quiet and not args.plain and own_device(args, world, lib) and args.lib is None:
                 try:
                     ctx2 = ssw_amd.Context(local_rank % ndev, lib)
                     b2 = int(lib.ssw_gpu_get_budget(ctx2.h))

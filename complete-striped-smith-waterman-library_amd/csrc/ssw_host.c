@@ -2212,7 +2212,8 @@ s_align* ssw_gpu_result_to_align(const ssw_gpu_result* r, const uint32_t* cigar_
  * (src/main.c:462-526) and hand in the same reference over and over; it is re-uploaded only when its bytes changed
  * (compared against a host copy -- the caller may reuse one buffer for different targets, as main.c does).
  * ------------------------------------------------------------------------------------------------ */
-typedef struct {
+typedef struct implicit_ctx_s {
+	struct implicit_ctx_s* next;    /* parked contexts (below) */
 	ssw_gpu_ctx* ctx;
 	ssw_gpu_seqs q, t;              /* one-sequence sets over pooled device buffers */
 	int64_t q_hoff[2], t_hoff[2];
@@ -2226,17 +2227,21 @@ static pthread_key_t g_ictx_key;
 static pthread_once_t g_ictx_once = PTHREAD_ONCE_INIT;
 static int g_next_device = 0;
 
+/* A caller thread that ends PARKS its context; the next new caller thread takes it over (streams, events and pooled buffers are process-wide
+   objects: nothing in them belongs to the thread that created them).  The thread-exit hook must not call into the HIP runtime: it runs as a
+   pthread-key destructor, i.e. AFTER the C++ thread_local objects of the exiting thread -- the runtime's own per-thread state among them --
+   have been destroyed, and a hipFree / hipStreamDestroy from there works on freed memory.  Round 4's hook closed the context right there;
+   with 16 caller threads ending together that corrupted the heap now and then (a crash at process exit, found with the round-5 latency
+   harness).  Parked contexts are reused, never closed: what is left at process exit goes with the process. */
+static pthread_mutex_t g_park_mu = PTHREAD_MUTEX_INITIALIZER;
+static implicit_ctx* g_parked;
 static void implicit_destroy(void* p)
 {
 	implicit_ctx* ic = (implicit_ctx*)p;
 	if (!ic) return;
-	if (ic->ctx) {
-		ssw_shim_set_device(ic->ctx->device);
-		ssw_shim_stream_sync(ic->ctx->stream);
-		ssw_shim_free(ic->q.d_off); ssw_shim_free(ic->t.d_off);      /* (one allocation each: offsets, then codes) */
-		ssw_gpu_close(ic->ctx);
-	}
-	free(ic->tcopy); free(ic->stage); free(ic);
+	pthread_mutex_lock(&g_park_mu);
+	ic->next = g_parked; g_parked = ic;
+	pthread_mutex_unlock(&g_park_mu);
 }
 /* Runs once per process, before the first implicit context exists (pthread_once), not from every first-calling thread.
    Caller threads' calls overlap on the device only as far as the runtime has hardware queues for their streams: ROCm's default is four
@@ -2255,6 +2260,11 @@ static implicit_ctx* implicit_get(void)
 	pthread_once(&g_ictx_once, implicit_key_init);
 	implicit_ctx* ic = (implicit_ctx*)pthread_getspecific(g_ictx_key);
 	if (ic) return ic;
+	pthread_mutex_lock(&g_park_mu);      /* a context parked by a caller thread that ended: taken over as it is (its device, its buffers, its resident target) */
+	ic = g_parked;
+	if (ic) g_parked = ic->next;
+	pthread_mutex_unlock(&g_park_mu);
+	if (ic) { ic->next = 0; pthread_setspecific(g_ictx_key, ic); return ic; }
 	const int ndev = ssw_shim_device_count();
 	const char* e = getenv("SSW_GPU_DEVICE");
 	const int dev = e ? atoi(e) : (ndev > 0 ? __atomic_fetch_add(&g_next_device, 1, __ATOMIC_RELAXED) % ndev : 0);

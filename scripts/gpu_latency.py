@@ -20,7 +20,7 @@ lib.ssw_align.argtypes = [C.c_void_p, i8p, C.c_int32, C.c_uint8, C.c_uint8, C.c_
 lib.align_destroy.argtypes = [C.POINTER(SAlign)]; lib.init_destroy.argtypes = [C.c_void_p]
 mat = dna_matrix(2, 2)
 out = {}
-for ref_len in (10_000, 1_000_000):
+for ref_len in (() if os.environ.get('LAT_QUICK') else (10_000, 1_000_000)):
     ref = random_ref(ref_len, 1, 4)
     for rl in (150, 1000):
         reads = sample_reads(ref, 200, rl, seed=5)
@@ -45,7 +45,7 @@ import threading
 ref = random_ref(1_000_000, 1, 4)
 reads = [np.ascontiguousarray(r) for r in sample_reads(ref, 512, 150, seed=6)]
 PER_THREAD = 256
-for nth in (1, 4, 8, 16):
+for nth in [int(x) for x in os.environ.get('LAT_THREADS', '1,4,8,16').split(',')]:
     for flag in (0, 2):
         bar = threading.Barrier(nth + 1)
         def work(k):

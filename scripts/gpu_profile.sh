@@ -13,12 +13,12 @@ R=$PWD
 cd /tmp
 trace() { timeout $1 rocprofv3 --kernel-trace --stats -d $P/$2 -o bench -- python $B $3 > $P/$2.log 2>&1; echo "$2 rc=$?"; }
 pmc() { timeout $1 rocprofv3 --pmc $4 -d $P/$2 -o bench -- python $B $3 > $P/$2.log 2>&1; echo "$2 rc=$?"; }
-trace 200 trace_config2 "--config 2 --steps 1 --warmup 1 --cpu-sample 0 --also none"
-trace 200 trace_config4 "--config 4 --steps 1 --warmup 1 --cpu-sample 0"
+trace 200 trace_config2 "--config 2 --steps 1 --warmup 1 --cpu-sample 0 --also none --plain"
+trace 200 trace_config4 "--config 4 --steps 1 --warmup 1 --cpu-sample 0 --plain"
 trace 300 trace_config5 "--config 5 --steps 1 --warmup 0 --cpu-sample 0"
-trace 200 trace_config6 "--config 6 --steps 1 --warmup 1 --cpu-sample 0"
-S2="--config 2 --reads 16000 --steps 1 --warmup 0 --cpu-sample 0 --also none"
-S4="--config 4 --steps 1 --warmup 0 --cpu-sample 0"      # full size: below ~2048 jobs the queue hands out whole jobs and runs one wavefront per SIMD
+trace 200 trace_config6 "--config 6 --steps 1 --warmup 1 --cpu-sample 0 --plain"
+S2="--config 2 --reads 16000 --steps 1 --warmup 0 --cpu-sample 0 --also none --plain"
+S4="--config 4 --steps 1 --warmup 0 --cpu-sample 0 --plain"      # full size: below ~2048 jobs the queue hands out whole jobs and runs one wavefront per SIMD
 S5="--config 5 --reads 8192 --db-targets 2048 --steps 1 --warmup 0 --cpu-sample 0"
 SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY"
 GR="GRBM_GUI_ACTIVE GRBM_COUNT"

@@ -30,7 +30,7 @@ for cfg in (2, 4, 5, 6):
                           "max(lds_size), max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
         tot = sum(r[2] for r in rows) or 1
         with open(os.path.join(out_dir, ROUND + "_config%d_kernel_stats.csv" % cfg), "w") as f:
-            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --config %d --steps 1 --warmup %d --cpu-sample 0 [--also none]   (durations in ns; vgpr = the trace record's arch_vgpr field, NOT the allocation: the code objects say 72 for k_fill<10,frame>)\n" % (cfg, 0 if cfg == 5 else 1))
+            f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --config %d --steps 1 --warmup %d --cpu-sample 0 [--also none] --plain   (durations in ns; vgpr = the trace record's arch_vgpr field, NOT the allocation: the code objects say 72 for k_fill<10,frame>)\n" % (cfg, 0 if cfg == 5 else 1))
             f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent,vgpr,sgpr,lds_bytes,max_grid_x,workgroup_x\n")
             for r in rows:
                 f.write("\"%s\",%d,%d,%.0f,%d,%d,%.3f,%d,%d,%d,%d,%d\n" % (r[0], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot, r[6], r[7], r[8], r[9], r[10]))
