@@ -276,11 +276,11 @@ def test_free_gap_open_with_traceback(ectx):
     nflag1 = 0
     for it in range(140):
         reads, ref, mat, n, gapO, gapE, flag, filterd, maskLen = free_gap_open_case(rng)
-        if it % 4 and it not in (79, 126, 139):
-            continue      # (every draw advances the stream; a quarter of them and the three known aborts are run)
+        if it % 6 and it not in (79, 126, 139):
+            continue      # (every draw advances the stream; a sixth of them and the three known aborts are run)
         res = _run(ectx, reads, [ref], mat, n, gapO, gapE, flag=flag, filterd=filterd, maskLen=maskLen)
         nflag1 += int((res["flag"] == 1).sum())
-    assert nflag1 > 20      # the regime was drawn: most tracebacks end as the reference's failure record
+    assert nflag1 > 12      # the regime was drawn: most tracebacks end as the reference's failure record
 
 
 def test_empty_target_after_a_flagged_call(ectx, emu_lib_path):
@@ -325,12 +325,12 @@ def test_narrow_band_traceback_teams(ectx, monkeypatch):
     four alignments per wavefront on anti-diagonals, cooperative walk back and re-score, hand-over of bands that outgrow the team --
     against the reference; the same batches on the default path (row kernels, cooperative walk) as well"""
     rng = np.random.default_rng(31)
-    batches = list(narrow_band_batches(rng, 40))
+    batches = list(narrow_band_batches(rng, 16))
     monkeypatch.setenv("SSW_GPU_TRACE_DIAG", "1")
     for reads, ref, mat, gapO, gapE, flag in batches:
         _run(ectx, reads, [ref], mat, 5, gapO, gapE, flag=flag)
     monkeypatch.delenv("SSW_GPU_TRACE_DIAG")
-    for reads, ref, mat, gapO, gapE, flag in batches[:12]:
+    for reads, ref, mat, gapO, gapE, flag in batches[:5]:
         _run(ectx, reads, [ref], mat, 5, gapO, gapE, flag=flag)
 
 
