@@ -1012,7 +1012,9 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 		int32_t* d_need = (int32_t*)ensure(c, &c->need, sizeof(int32_t) * 2 * (size_t)nq);
 		int32_t* d_resume = (int32_t*)ensure(c, &c->tresume, sizeof(int32_t) * 8 * (size_t)nq);
 		if (!d_cig || !d_need || !d_resume) return -1;      /* (the teams' resume state is zeroed before the first team launch) */
-		int64_t sstride = ((int64_t)3 * 720 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;      /* three rows of a band of 48 (padded: ssw_kernels.hip trace_rowbytes) + 99 direction bytes per row */
+		int64_t sstride = ((int64_t)3 * 720 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;      /* three rows of a band of 48 (padded: ssw_kernels.hip trace_rowbytes) + 99 direction bytes per row (k_trace: band 16, three bytes per cell) */
+		if (c->kn.trace_wave != 0)      /* the team kernels keep one NIBBLE per cell (round 5): a band of 48 is 49 bytes per row */
+			sstride = ((int64_t)3 * 720 + (int64_t)49 * maxlen + 64 + 15) / 16 * 16;
 		/* long reads: one wavefront per alignment (wide bands, 10^4 rows); short reads: one thread per alignment */
 		/* Which kernel walks a band.  Rounds 1-3 gave short reads ONE THREAD per alignment (k_trace) and only reads above 1 kb a TEAM of wavefronts
 		   (k_trace_wave: band rows in LDS, a row's cells in parallel, direction bytes packed).  Measured in round 4, the team kernel wins

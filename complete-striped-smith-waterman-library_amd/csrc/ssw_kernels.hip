@@ -2303,7 +2303,7 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 		const int end = i + band_width < refLen - 1 ? i + band_width : refLen - 1;
 		const int edge = end + 1 < width - 1 ? end + 1 : width - 1;
 		const int ncell = end - beg + 1;
-		int8_t* line = dir + (int64_t)width_d * i;     /* one packed byte per cell: bit 0 = E opened, bit 1 = F opened, bits 2.. = H's source */
+		int8_t* line = dir + (int64_t)(band_width + 1) * i;     /* one nibble per cell, a row of 2 b + 1 cells in b + 1 bytes */
 		if (L && (i & 63) == 0) {   /* target window: everything the next 64 rows can touch */
 			int64_t hi = (int64_t)i + band_width + 65; if (hi > refLen) hi = refLen;
 			for (int j = staged + tid; j < (int)hi; j += NT) lds_st8(lds, oring + ((u32)j & ring_mask), (u32)(unsigned char)ref[j]);
@@ -2379,10 +2379,13 @@ SSW_DEV void trace_band(const TraceRows<L>& R, const int8_t* ref, const int8_t* 
 				carryF = (int)xl_readlane((u32)F, last); carryA = (int)xl_readlane((u32)A, last); carryH = (int)xl_readlane((u32)h, last);
 			}
 			const int8_t df = (hleft - gapO) > (Fleft - gapE) ? 5 : 4;
+			/* direction NIBBLE of the cell: bit 0 = E opened, bit 1 = F opened, bits 2-3 = H's source (0 diagonal, 1 E, 2 F); cells 2m and 2m + 1 of
+			   a row share a byte (the even lane stores it: 32 contiguous bytes per wavefront) */
+			const u32 nb = ok ? (u32)((de == 3 ? 1 : 0) | (df == 5 ? 2 : 0) | ((gap <= dia ? 0 : (e1 > f1 ? 1 : 2)) << 2)) : 0u;
+			const u32 nb_hi = xl_wave_shl1_keep(0u, nb);
 			if (ok) {
 				R.steb(u, e); R.sthc(u, h);
-				const int dh = gap <= dia ? 1 : (e1 > f1 ? de : df);
-				line[u - 1] = (int8_t)((de == 3 ? 1 : 0) | (df == 5 ? 2 : 0) | (dh << 2));     /* 64 contiguous bytes per wavefront store */
+				if (!(tid & 1)) line[(u - 1) >> 1] = (int8_t)(nb | (nb_hi << 4));
 				if (h > lb) { lb = h; li = i; lj = j; }      /* rows and chunks come in row-major order: strict > keeps the first */
 			}
 		}
@@ -2462,7 +2465,7 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 		const int endn = i + 1 + band_width < refLen - 1 ? i + 1 + band_width : refLen - 1;      /* the next row's forced index */
 		const int edgen = endn + 1 < width - 1 ? endn + 1 : width - 1;
 		const u32 hp = (i & 1) ? oh0 : oh1, hcur = (i & 1) ? oh1 : oh0;      /* previous row's H, this row's H */
-		int8_t* line = dir + (int64_t)width_d * i;
+		int8_t* line = dir + (int64_t)(band_width + 1) * i;      /* direction nibbles (trace_band): a row of 2 b + 1 cells in b + 1 bytes */
 		if ((i & 63) == 0) {   /* target window: everything the next 64 rows can touch */
 			int64_t hi = (int64_t)i + band_width + 65; if (hi > refLen) hi = refLen;
 			for (int j = staged + tid; j < (int)hi; j += NT) lds_st8(lds, oring + ((u32)j & ring_mask), (u32)(unsigned char)ref[j]);
@@ -2549,6 +2552,7 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 		/* ---- finish the cells */
 		int hl = 0, Fl = NEG;                          /* h and F of the cell to the left (cell 0: h_c[0] = 0, no F); a thread's first cell learns them after barrier 2 */
 		u32 byte_first = 0;
+		unsigned long long nibbles = 0;                /* direction nibbles of this thread's cells of the row (cell k at bits 4k..4k+3) */
 		if (has) {
 		{ const int sp = Pw - (lane + 1) * D; V = sp > V ? sp : V; }
 		const int P = (int)xl_wave_shr1_keep((u32)Pw, (u32)V);      /* S at the cell before this thread's first one */
@@ -2563,16 +2567,13 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 			const int gap = e1 > f1 ? e1 : f1;
 			const int h = gap > dia[k] ? gap : dia[k];
 			const int de3 = (int)((deb >> k) & 1u);
-			u32 byte = 0;
-			if (k == 0) byte_first = (u32)de3 | (gap <= dia[k] ? 4u : (e1 > f1 ? (u32)((2 + de3) << 2) : 0x80u));     /* 0x80: H's source is F, direction known after barrier 2 */
+			const u32 hs = gap <= dia[k] ? 0u : (e1 > f1 ? 1u : 2u);      /* H's source: diagonal / E / F */
+			if (k == 0) byte_first = (u32)de3 | (hs << 2);                 /* (whether F was opened into the first cell is known after barrier 2) */
 			else {
 				const int df5 = (hl - gapO) > (Fl - gapE) ? 1 : 0;
-				const int dh = gap <= dia[k] ? 1 : (e1 > f1 ? 2 + de3 : 4 + df5);
-				byte = (u32)(de3 | (df5 << 1) | (dh << 2));
+				if (k < cnt) nibbles |= (unsigned long long)((u32)de3 | ((u32)df5 << 1) | (hs << 2)) << (4 * k);
 			}
 			if (k < cnt) {      /* (stores and moves only: nothing in here waits) */
-				const int u = u0 + k;
-				if (k > 0) line[u - 1] = (int8_t)byte;
 				lds_st32(lds, oeb + 4u * (BS * (u32)tid + (u32)k + (PAD ? 2u : 1u)), (u32)e[k]);      /* = entry(u) */
 				lds_st32(lds, hcur + 4u * (BS * (u32)tid + (u32)k + (PAD ? 2u : 1u)), (u32)h);
 				hm = h > hm ? h : hm;
@@ -2595,8 +2596,17 @@ SSW_DEV void trace_band_blocked(unsigned char* lds, u32 oh0, u32 oh1, u32 oeb, c
 		if (cnt > 0) {
 			if (NW > 1 && tid > 0) { hleft = (int)lds_ld32(lds, TX_SLOT + 4u * (u32)(tid - 1)); Fleft = (int)lds_ld32(lds, TX_SLOT + 4u * (u32)(NT + tid - 1)); }
 			const int df5 = (hleft - gapO) > (Fleft - gapE) ? 1 : 0;
-			const u32 b = (byte_first & 0x80u) ? ((byte_first & 1u) | ((u32)(4 + df5) << 2)) : byte_first;
-			line[u0 - 1] = (int8_t)(b | ((u32)df5 << 1));
+			nibbles |= (unsigned long long)(byte_first | ((u32)df5 << 1));
+		}
+		/* the thread's direction nibbles of this row, two cells per byte: its first cell has an even index in the row (tid x CPT, CPT even);
+		   one cell per lane (CPT = 1): the even lane takes its neighbour's nibble */
+		if (CPT == 1) {
+			const u32 nb = cnt > 0 ? (u32)nibbles : 0u, nb_hi = xl_wave_shl1_keep(0u, nb);
+			if (cnt > 0 && !(tid & 1)) line[(u0 - 1) >> 1] = (int8_t)(nb | (nb_hi << 4));
+		} else {
+#pragma unroll
+			for (int kb = 0; kb < CPT / 2; ++kb)
+				if (2 * kb < cnt) line[((u0 - 1) >> 1) + kb] = (int8_t)((nibbles >> (8 * kb)) & 0xffu);
 		}
 	}
 	/* the scalar walk's best cell: highest h above the carried best; among equals the first in row-major order */
@@ -2643,7 +2653,7 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 	do {
 		const int width = band_width * 2 + 3; width_d = band_width * 2 + 1;
 		const int64_t rowbytes = trace_rowbytes(band_width, 64 * NW);
-		const int64_t want = 3 * rowbytes + (int64_t)width_d * readLen + 16;
+		const int64_t want = 3 * rowbytes + (int64_t)(band_width + 1) * readLen + 16;      /* direction nibbles: b + 1 bytes per row of 2 b + 1 cells */
 		if (want > cap) { *need = want; *band_io = band_width; return -2; }
 		dir = (int8_t*)(scratch + 3 * rowbytes);
 		/* (8 and 12 cells per thread for the teams, not for single wavefronts: their kernel keeps five wavefronts per SIMD) */
@@ -2684,27 +2694,30 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 		   out of a row's window (a long run of gap steps) or leaves the 64 rows of the batch starts a new batch where it stands. */
 		int run = 0, state = 2, cur = 0, prev = 0, i = best_i, j = best_j, failed = 0, wbase = -1, jbase = 0;
 		u32 ww0 = 0, ww1 = 0, ww2 = 0;
+		const int64_t RB = band_width + 1;      /* bytes per row of direction nibbles */
+		(void)width_d;
 		while (i >= 0 && j > 0) {
 			const int x0 = i - band_width > 0 ? i - band_width : 0;
-			const int64_t pos = (int64_t)width_d * i + (j - x0);
+			const int64_t pos = RB * i + ((j - x0) >> 1);      /* the byte that holds the cell's nibble */
 			int t = wbase - i, o;
 			{
-				int64_t P = ((int64_t)width_d * i + ((jbase - t) - x0) - 4) & ~(int64_t)3; if (P < 0) P = 0;
+				int64_t P = (RB * i + ((((jbase - t) - x0) >> 1)) - 4) & ~(int64_t)3; if (P < 0) P = 0;
 				const int64_t oo = pos - P;
 				o = oo < 0 || oo >= 12 ? -1 : (int)oo;
 			}
 			if (t < 0 || t >= 64 || o < 0) {      /* (uniform: every lane holds the same walk state) */
 				wbase = i; jbase = j; t = 0;
 				const int r = wbase - tid, jr = jbase - tid, xr = r - band_width > 0 ? r - band_width : 0;
-				int64_t P = ((int64_t)width_d * r + (jr - xr) - 4) & ~(int64_t)3; if (P < 0) P = 0;
+				int64_t P = (RB * r + ((jr - xr) >> 1) - 4) & ~(int64_t)3; if (P < 0) P = 0;
 				if (r >= 0) { const u32* src = (const u32*)(dir + P); ww0 = src[0]; ww1 = src[1]; ww2 = src[2]; }
 				int64_t P0 = (pos - 4) & ~(int64_t)3; if (P0 < 0) P0 = 0;
 				o = (int)(pos - P0);
 			}
 			const int sel = o >> 2;
 			const u32 word = xl_shfl(sel <= 0 ? ww0 : sel == 1 ? ww1 : ww2, t);
-			const int pk = (int)((word >> (8 * (o & 3))) & 0xffu);
-			const int d = state == 0 ? 2 + (pk & 1) : state == 1 ? 4 + ((pk >> 1) & 1) : pk >> 2;
+			const int pk = (int)((word >> (8 * (o & 3) + 4 * ((j - x0) & 1))) & 0xfu);
+			const int hs = pk >> 2;
+			const int d = state == 0 ? 2 + (pk & 1) : state == 1 ? 4 + ((pk >> 1) & 1) : hs == 0 ? 1 : hs == 1 ? 2 + (pk & 1) : hs == 2 ? 4 + ((pk >> 1) & 1) : 0;
 			if (d == 1) { --i; --j; state = 2; cur = 0; }
 			else if (d == 2) { --i; state = 0; cur = 1; }
 			else if (d == 3) { --i; state = 2; cur = 1; }
