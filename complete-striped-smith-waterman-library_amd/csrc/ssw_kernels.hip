@@ -703,12 +703,12 @@ __global__ void __launch_bounds__(16 * NCH) SSW_WAVES_PER_EU(DB_WAVES_PER_EU, 8)
 SSW_DEV int half16(u32 w, int hi) { return (int)((hi ? (w >> 16) : w) & 0xffffu); }
 
 /* block-wide (max value, then min index) reduction; result valid in every thread */
-SSW_DEV void block_argmax(unsigned char* lds, int tid, int& val, int& idx)
+SSW_DEV void block_argmax(unsigned char* lds, int tid, int& val, int& idx, int nthreads = 256)
 {
 	lds_st32(lds, 8u * tid, (u32)val);
 	lds_st32(lds, 8u * tid + 4, (u32)idx);
 	__syncthreads();
-	for (int st = 128; st > 0; st >>= 1) {
+	for (int st = nthreads >> 1; st > 0; st >>= 1) {
 		if (tid < st) {
 			int v0 = (int)lds_ld32(lds, 8u * tid), i0 = (int)lds_ld32(lds, 8u * tid + 4);
 			int v1 = (int)lds_ld32(lds, 8u * (tid + st)), i1 = (int)lds_ld32(lds, 8u * (tid + st) + 4);
@@ -834,7 +834,7 @@ SSW_DEV void seg_first_column(const uint32_t* cols, int seg, int refLen, int hi,
 
 SSW_DEV void reduce_seg_body(const ssw_reduce_args& a, const int pair, unsigned char* lds)
 {
-	const int tid = (int)threadIdx.x;
+	const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;      /* 256, or 1024 when a handful of pairs meets a long target (a single ssw_align call: the scan is a chain of memory latencies) */
 	const ssw_pair pr = a.pairs[pair];
 	const uint32_t* c16 = a.cm16 + (int64_t)pair * a.cm_stride;
 	const uint32_t* c8 = a.cm8 + (int64_t)pair * a.cm_stride;
@@ -847,7 +847,7 @@ SSW_DEV void reduce_seg_body(const ssw_reduce_args& a, const int pair, unsigned 
 	   against a 1 Mb target is 62 500 groups -- the scan is a chain of memory latencies, 0.3 ms with one word per iteration; the rows of the
 	   group arrays are 16-byte aligned and padded: seg_stride is a multiple of 4 and >= nseg + 4) */
 	int best[2] = { 0, 0 }, bseg[2] = { 0x7fffffff, 0x7fffffff };
-	for (int g0 = tid * 4; g0 < nseg; g0 += 1024) {
+	for (int g0 = tid * 4; g0 < nseg; g0 += 4 * nthr) {
 		const u32x4 w4 = *(const u32x4*)(g16 + g0);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
@@ -859,8 +859,8 @@ SSW_DEV void reduce_seg_body(const ssw_reduce_args& a, const int pair, unsigned 
 			}
 		}
 	}
-	block_argmax(lds, tid, best[0], bseg[0]);
-	block_argmax(lds, tid, best[1], bseg[1]);
+	block_argmax(lds, tid, best[0], bseg[0], nthr);
+	block_argmax(lds, tid, best[1], bseg[1], nthr);
 	int bidx[2] = { 0x7fffffff, 0x7fffffff };
 	for (int h = 0; h < 2; ++h) if (best[h] > 0) seg_first_column(c16, bseg[h], a.refLen, h, best[h], 0, 0, false, bidx[h]);
 
@@ -898,7 +898,7 @@ SSW_DEV void reduce_seg_body(const ssw_reduce_args& a, const int pair, unsigned 
 		if (!live[h]) continue;
 		const uint32_t* gs = use8[h] ? g8 : g16;
 		const uint32_t* cs = use8[h] ? c8 : c16;
-		for (int g0 = tid * 4; g0 < nseg; g0 += 1024) {
+		for (int g0 = tid * 4; g0 < nseg; g0 += 4 * nthr) {
 			const u32x4 w4 = *(const u32x4*)(gs + g0);
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
@@ -913,8 +913,8 @@ SSW_DEV void reduce_seg_body(const ssw_reduce_args& a, const int pair, unsigned 
 			}
 		}
 	}
-	block_argmax(lds, tid, s2[0], g2[0]);
-	block_argmax(lds, tid, s2[1], g2[1]);
+	block_argmax(lds, tid, s2[0], g2[0], nthr);
+	block_argmax(lds, tid, s2[1], g2[1], nthr);
 	if (tid == 0) {
 		for (int h = 0; h < 2; ++h) {
 			const int q = h ? pr.qb : pr.qa;
@@ -941,7 +941,7 @@ SSW_DEV void reduce_seg_body(const ssw_reduce_args& a, const int pair, unsigned 
 	}
 }
 
-__global__ void __launch_bounds__(256) k_reduce_seg(ssw_reduce_args a)
+__global__ void __launch_bounds__(1024) k_reduce_seg(ssw_reduce_args a)
 {
 	SSW_DYN_LDS(lds);
 	reduce_seg_body(a, (int)blockIdx.x, lds);
@@ -3399,7 +3399,11 @@ extern "C" int ssw_shim_launch_reduce(const ssw_reduce_args* a, void* stream)
 {
 	ssw_reduce_args args = *a;
 	if (args.npairs <= 0) return 0;
-	if (args.sg16) SSW_LAUNCH(k_reduce_seg, ssw_reduce_args, args, args.npairs, 256, 256 * 8, stream);
+	if (args.sg16) {
+		/* a handful of pairs against a long target (one ssw_align call: 62 500 groups of a 1 Mb target): 1024 threads share the scan -- 64 -> ~20 us */
+		const int nthr = args.npairs <= 8 && args.refLen >= (1 << 17) ? 1024 : 256;
+		SSW_LAUNCH(k_reduce_seg, ssw_reduce_args, args, args.npairs, nthr, nthr * 8, stream);
+	}
 	else SSW_LAUNCH(k_reduce, ssw_reduce_args, args, args.npairs, 256, 256 * 8, stream);
 	return SSW_LAUNCH_OK();
 }

@@ -334,6 +334,15 @@ def test_narrow_band_traceback_teams(ectx, monkeypatch):
         _run(ectx, reads, [ref], mat, 5, gapO, gapE, flag=flag)
 
 
+def test_few_pairs_long_target_reduction_on_1024_threads(ectx):
+    """a handful of pairs against a target of >= 2^17 columns (a single ssw_align call against a megabase): k_reduce_seg runs with 1024
+    threads instead of 256 (the scan over the group maxima is a chain of memory latencies); same records"""
+    rng = np.random.default_rng(71)
+    ref = random_ref(133000, 72, 4)
+    reads = make_reads(rng, ref, 3, [150, 70, 101], 4, frac_random=0.0)
+    _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=2)
+
+
 def test_bad_arguments_fail_loudly(ectx):
     ref = random_ref(100, 1, 4)
     Q = ectx.upload([ref[:30]]); T = ectx.upload([ref])
