@@ -1672,13 +1672,19 @@ plan_again:
 					   halo columns in sequence: then the tiles go down to half the halo (at least 64 columns) as long as all chains of the
 					   call still fit the device at once (since round 5: down to an eighth of the halo); the recomputed halos run on compute units that would idle.  One 150-bp read against a
 					   10-kb target: 736 steps instead of 10 000 (2.3 -> 0.x ms per ssw_align call, profiles/round4_latency.txt). */
-					int64_t slots = use_x ? (int64_t)c->dev_wave_slots : (int64_t)c->dev_cus * 96;      /* chains the device holds at once */
+					/* chains a latency-bound call spreads over: for the 16-lane chains TWO workgroups (32 chains, two wavefronts per SIMD) per compute
+					   unit -- a step of a lone wavefront is bound by the latency of its dependent instructions (~800 cycles for ~75), a second one hides
+					   in it, a third and fourth only share the issue port (measured: 977 workgroups on 256 CUs 0.61 ms per call, 260: 0.57) */
+					int64_t slots = use_x ? (int64_t)c->dev_wave_slots : (int64_t)c->dev_cus * (c->device_share > 1 ? 96 : 32);      /* (several caller threads: what the device holds, shared below) */
 					if (c->device_share > 1) { slots /= c->device_share; if (slots < 256) slots = 256; }      /* other caller threads' pairs are on the device too */
 					const int64_t all_pairs = npairs_total > 0 ? npairs_total : 1;
 					if (all_pairs * want < slots && halo_full < refLen) {
 						/* (round 5: an eighth of the halo, not half -- a chain's latency is tile + halo steps and the halo is fixed; one 150-bp read against
 						   1 Mb: k_fill 240 -> ~185 us of the call's 0.53 ms, profiles/round5_latency_single_pair.json) */
-						const int64_t mint = halo_full / 8 > 64 ? halo_full / 8 : 64;
+						/* ... for the 16-lane chains of a call that is alone on the device; the strip kernel (two wavefronts per SIMD by its LDS) and
+						   calls that share the device with other caller threads keep half a halo: their extra chains would only queue up */
+						const int div = !use_x && c->device_share <= 1 ? 8 : 2;
+						const int64_t mint = halo_full / div > 64 ? halo_full / div : 64;
 						int64_t small = slots / all_pairs;
 						if (small > refLen / mint) small = refLen / mint;
 						if (small > want) { want = small; small_call = 1; }
