@@ -988,8 +988,13 @@ __global__ void __launch_bounds__(64) k_capture(ssw_capture_args a)
 		qlen = (int)(a.qoff[qs + 1] - a.qoff[qs]);
 		plen = a.reverse ? r.read_end1 + 1 : qlen;
 		P = (plen + 15) & ~15;
-		/* exact halo: a positive-scoring path spans < P + P*max(mat)/gapE columns */
-		long long w = (long long)P + ((long long)P * (a.maxmat > 0 ? a.maxmat : 0) + a.gapE - 1) / (a.gapE > 0 ? a.gapE : 1) + 1;
+		/* exact window for a KNOWN score (round 5).  A path that ends with score S has D <= P diagonal steps (<= max(mat) each) and G target-only
+		   gap steps (>= gapE each, gapO > gapE): S <= D max(mat) - G gapE, so it spans D + G <= P + (P max(mat) - S) / gapE columns.  Both passes only
+		   ask where score1 is reached: a cell whose true value is score1 has its whole path inside a window of that width, every other cell
+		   only gets a lower bound of a value < score1 -- the same cells are found as with the score-free bound P + P max(mat) / gapE, which a
+		   clean 150-bp read (score 280 of 300) undercuts 2.4 times (k_capture is 182 of a single ssw_align call's 510 us). */
+		const long long lost = (long long)P * (a.maxmat > 0 ? a.maxmat : 0) - r.score1;
+		long long w = (long long)P + (lost > 0 ? lost : 0) / (a.gapE > 0 ? a.gapE : 1) + 1;
 		if (a.gapE <= 0 || w > r.ref_end1) w = r.ref_end1;
 		ncols = (int)w + 1;
 		c_edge = a.reverse ? r.ref_end1 : r.ref_end1 - (int)w;   /* traversal column 0 */
@@ -1479,7 +1484,9 @@ SSW_DEV void cap_half_setup(CapHalf& h, const ssw_chainx_args& a, int q)
 	h.qlen = (int)(a.qoff[qs + 1] - a.qoff[qs]);
 	h.lena = a.reverse ? h.r.read_end1 + 1 : h.qlen;
 	h.rows = (h.lena + 15) & ~15;
-	long long w = (long long)h.rows + ((long long)h.rows * (a.maxmat > 0 ? a.maxmat : 0) + a.gapE - 1) / (a.gapE > 0 ? a.gapE : 1) + 1;
+	/* exact window for the known score1 (see k_capture): rows + (rows max(mat) - score1) / gapE + 1 columns */
+	const long long lost0 = (long long)h.rows * (a.maxmat > 0 ? a.maxmat : 0) - h.r.score1;
+	long long w = (long long)h.rows + (lost0 > 0 ? lost0 : 0) / (a.gapE > 0 ? a.gapE : 1) + 1;
 	if (a.gapE <= 0 || w > h.r.ref_end1) w = h.r.ref_end1;
 	if (a.reverse && a.window_extra >= 0) {   /* first try: the alignment rarely spans more than its rows + 25 % */
 		const long long cap = (long long)h.rows + h.rows / 4 + a.window_extra;
