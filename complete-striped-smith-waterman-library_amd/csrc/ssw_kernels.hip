@@ -1490,8 +1490,11 @@ SSW_DEV void cap_half_setup(CapHalf& h, const ssw_chainx_args& a, int q)
 	if (a.gapE <= 0 || w > h.r.ref_end1) w = h.r.ref_end1;
 	if (a.reverse && a.window_extra >= 0) {   /* first try: the alignment rarely spans more than its rows + 25 % */
 		const long long cap = (long long)h.rows + h.rows / 4 + a.window_extra;
-		if (cap < w) {
-			w = cap; h.capped = true;
+		long long wfree = (long long)h.rows + ((long long)h.rows * (a.maxmat > 0 ? a.maxmat : 0) + a.gapE - 1) / (a.gapE > 0 ? a.gapE : 1) + 1;      /* the score-free bound */
+		if (a.gapE <= 0 || wfree > h.r.ref_end1) wfree = h.r.ref_end1;
+		if (cap < wfree) {      /* (as before round 5: the capped first try and its diagonal band are worth it; the window is the smaller of cap and the exact one) */
+			if (cap < w) w = cap;
+			h.capped = true;
 			/* the diagonal band is only worth trying where its acceptance proof (cap_half_finish) can succeed: an alignment that scores
 			   close to max(mat) per row.  A weak one -- an unrelated read's best local alignment, hundreds of rows of the linear regime --
 			   would be found and then rerun with the exact window; it keeps the whole capped window instead. */
