@@ -374,6 +374,18 @@ def test_narrow_band_traceback_teams(gpu_ctx, gpu_hctx, monkeypatch):
         assert (hsh == z4["cigar_fnv"][:k4]).all()
 
 
+def test_few_pairs_against_a_megabase(gpu_ctx):
+    """what a single ssw_align call is inside: one to eight pairs against a 1 Mb target -- tiles of an eighth of the halo on two workgroups per
+    compute unit, the group-maxima scan on 1024 threads, the locate / reverse passes on the exact window for the known score; flags 0, 2, 9"""
+    import workloads as W
+    ref, reads, p = W.dna_config(2, 0, reads=64)
+    rng = np.random.default_rng(3)
+    for nq, flag in ((1, 0), (1, 2), (3, 2), (8, 9), (16, 0)):
+        sub = [np.ascontiguousarray(reads[i]) for i in rng.choice(64, size=nq, replace=False)]
+        sub[0] = np.ascontiguousarray(sub[0][:int(rng.integers(20, 150))])      # a shorter read: another geometry bucket beside the others
+        _run(gpu_ctx, sub, [ref], dna_matrix(2, 2), 5, flag=flag)
+
+
 def test_free_gap_open_with_traceback(gpu_ctx):
     """gapO = 0 with every flag that asks for a CIGAR (round-4 verdict; the emulator twin is tests/test_emu_pipeline.py): no call may fail,
     every record and CIGAR -- mostly the reference's `cigarLen 0, flag 1` after the full-band retry -- equals the reference's."""
