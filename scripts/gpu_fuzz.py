@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the batch ABI against the unmodified reference (oracle/_ref), on the GPU box (or, with --emu, on the SIMT emulator):
+exotic parameters on purpose -- alphabets of 4..24 letters, full-range / all-non-positive / sparse matrices, gapO <= gapE, gapO = 0, gapE = 0,
+gaps up to 255, maskLen 0..40, every flag, score_size 0 / 1 / 2, filters, lengths 1..700, one or several targets (the database path from four
+targets on).  Every record and CIGAR is compared (tests/parity.py); a call that fails is counted separately from a wrong value.
+usage: gpu_fuzz.py <seconds> <seed> [--emu]        -> one JSON line"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "complete-striped-smith-waterman-library_amd"))
+import ssw_amd          # noqa: E402
+from parity import compare_batch, make_reads   # noqa: E402
+from sswutil import blosum50, dna_matrix   # noqa: E402
+
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+emu = "--emu" in sys.argv
+lib = ssw_amd.load(os.path.join(ROOT, "tests", "emu", "libssw_emu.so") if emu else None)
+ctx = ssw_amd.Context(0, lib)
+rng = np.random.default_rng(seed)
+t_end = time.time() + secs
+calls = aln = failed = wrong = nullrec = flag1 = 0
+regimes = {"gapO>gapE": 0, "gapO<=gapE": 0, "gapO=0": 0, "db_path": 0}
+first = []
+while time.time() < t_end:
+    kind = rng.random()
+    if kind < 0.3:
+        n, nc, mat = 5, 4, dna_matrix(int(rng.integers(1, 6)), int(rng.integers(0, 7)))
+    elif kind < 0.45:
+        n, nc, mat = 24, 20, blosum50()
+    else:
+        n = int(rng.integers(4, 25)); nc = n - 1 if n > 4 else n
+        style = rng.random()
+        if style < 0.3:
+            m = rng.integers(-128, 128, size=(n, n))
+        elif style < 0.5:
+            m = -rng.integers(0, 30, size=(n, n))           # all non-positive
+        elif style < 0.75:
+            m = np.full((n, n), -int(rng.integers(1, 9))); m[np.arange(n), np.arange(n)] = rng.integers(1, 12, size=n)
+        else:
+            m = rng.integers(-12, 13, size=(n, n))
+        mat = np.ascontiguousarray(m.astype(np.int8).reshape(-1))
+    g = rng.random()
+    if g < 0.55:
+        gapE = int(rng.integers(1, 6)); gapO = gapE + int(rng.integers(1, 12))
+    elif g < 0.75:
+        gapO = int(rng.integers(0, 8)); gapE = gapO + int(rng.integers(0, 6))
+    elif g < 0.85:
+        gapO = 0; gapE = int(rng.integers(0, 4))
+    else:
+        gapO = int(rng.integers(0, 256)); gapE = int(rng.integers(0, 256))
+    nt = 1 if rng.random() < 0.7 else int(rng.integers(2, 9))
+    refs = [rng.integers(0, nc, size=int(rng.integers(1, 701)), dtype=np.int8) for _ in range(nt)]
+    nq = int(rng.integers(1, 10))
+    lens = rng.integers(1, 701, size=nq) if rng.random() < 0.3 else rng.integers(1, 160, size=nq)
+    reads = make_reads(rng, refs[0], nq, lens, nc, frac_random=0.3)
+    flag = int(rng.integers(0, 16)); ss = int(rng.choice([2, 2, 2, 0, 1]))
+    filters = int(rng.choice([0, 0, 20, 100])); filterd = int(rng.choice([0, 30, 1000])); maskLen = int(rng.choice([-1, -1, 0, 14, 15, 40]))
+    regimes["gapO=0" if gapO == 0 else "gapO<=gapE" if gapO <= gapE else "gapO>gapE"] += 1
+    if nt >= 4: regimes["db_path"] += 1
+    calls += 1; aln += nq * nt
+    Q = ctx.upload(reads); T = ctx.upload(refs)
+    try:
+        res, cig = ctx.align_batch(Q, T, mat, n, gapO, gapE, flag, filters, filterd, maskLen, ss)
+    except Exception as e:      # noqa: BLE001
+        failed += 1
+        if len(first) < 5: first.append({"failed": str(e)[:200], "n": n, "gapO": gapO, "gapE": gapE, "flag": flag, "ss": ss, "nq": nq, "nt": nt})
+        continue
+    finally:
+        Q.free(); T.free()
+    bad = compare_batch(res, cig, reads, refs, mat, n, gapO, gapE, flag, filters, filterd, maskLen, ss, max_report=2)
+    nullrec += int((res["status"] == 1).sum()); flag1 += int((res["flag"] == 1).sum())
+    if bad:
+        wrong += 1
+        if len(first) < 5: first.append({"mismatch": bad[0][:300], "n": n, "gapO": gapO, "gapE": gapE, "flag": flag, "ss": ss, "maskLen": maskLen})
+print(json.dumps({"seconds": secs, "seed": seed, "library": "emulator" if emu else "libssw.so on the GPU", "calls": calls, "alignments": aln, "failed_calls": failed,
+                  "calls_with_wrong_values": wrong, "records_where_the_reference_returns_NULL": nullrec, "records_with_flag_1": flag1, "regimes": regimes, "first": first}))
