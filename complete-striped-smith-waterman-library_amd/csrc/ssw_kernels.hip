@@ -2694,7 +2694,7 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 	band_width /= 2;
 	const int best_i = tb.i, best_j = tb.j;
 
-	if (NW > 1) { dev_fence(); __syncthreads(); } else dev_fence();
+	if (NW > 1) { wg_fence(); __syncthreads(); } else wg_fence();      /* (workgroup scope: writers and readers are one workgroup on one compute unit; an agent-scope fence writes L2 back, 10^5 times per batch) */
 	int nops = 0;
 	if (tid < 64) {
 		/* The walk back (src/ssw.c:682-762) by the team's first wavefront.  It used to be thread 0's loop: 10^4 dependent one-byte loads for a
@@ -2746,12 +2746,12 @@ SSW_DEV int trace_team(const int8_t* ref, const int8_t* read, int refLen, int re
 			}
 			if (nops > cigcap) { *need = -(int64_t)nops; nops = -2; }
 			else {
-				dev_fence();
+				wg_fence();
 				for (int x = tid; x < nops / 2; x += 64) { const u32 tt = cig[x]; cig[x] = cig[nops - 1 - x]; cig[nops - 1 - x] = tt; }
 			}
 		}
 	}
-	dev_fence();
+	wg_fence();
 	return team_bcast0<NW>(lds, nops, tid);
 }
 
@@ -3016,7 +3016,7 @@ __global__ void __launch_bounds__(64) SSW_WAVES_PER_EU(4, 8) k_trace_diag(ssw_tr
 					const int oh = (int)xl_shfl((u32)rb, lane ^ d), oi2 = (int)xl_shfl((u32)ri, lane ^ d), oj2 = (int)xl_shfl((u32)rj, lane ^ d);
 					if (oh > rb || (oh == rb && (oi2 < ri || (oi2 == ri && oj2 < rj)))) { rb = oh; ri = oi2; rj = oj2; }
 				}
-				dev_fence();      /* the direction bytes the team's lanes stored are visible to its lane 0 (a full-band retry rewrites lines an earlier walk has read) */
+				wg_fence();      /* the direction bytes the team's lanes stored are visible to its lane 0 (a full-band retry rewrites lines an earlier walk has read) */
 				if (E) {
 					if (rb > tb_best) { tb_best = rb; tb_i = ri; tb_j = rj; }
 					if (tb_best < score && 2 * w <= full) { w *= 2; fresh = true; state = TD_RETRY; }      /* next doubling (may hand over) */
@@ -3082,11 +3082,11 @@ __global__ void __launch_bounds__(64) SSW_WAVES_PER_EU(4, 8) k_trace_diag(ssw_tr
 				else { oi = 0; rp = 0; qp = 0; sc = 0; state = TD_REVERSE; }
 			}
 			if (wave_any(state == TD_REVERSE)) {      /* the operations were emitted last to first: reversed in place by the whole team, then re-scored */
-				dev_fence();
+				wg_fence();
 				if (state == TD_REVERSE) {
 					for (int x = k; x < nops / 2; x += TEAM) { const u32 tt = cig[x]; cig[x] = cig[nops - 1 - x]; cig[nops - 1 - x] = tt; }
 				}
-				dev_fence();
+				wg_fence();
 				if (state == TD_REVERSE) state = TD_SCORE;
 			}
 		}
