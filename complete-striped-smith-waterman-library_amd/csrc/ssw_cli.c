@@ -299,7 +299,13 @@ static void* stage_parse(void* arg)
 	pipeline* pl = (pipeline*)arg;
 	reader* qr = (reader*)xmalloc(sizeof(reader)); memset(qr, 0, sizeof *qr);
 	qr->f = gzopen(pl->qfile, "r");
-	if (!qr->f) { fprintf(stderr, "gzopen of '%s' failed.\n", pl->qfile); exit(EXIT_FAILURE); }
+	if (!qr->f) {      /* (no exit() from a worker thread: the main thread may be inside its stdout buffer -- the failure travels as a work item) */
+		fprintf(stderr, "gzopen of '%s' failed.\n", pl->qfile);
+		work* w = (work*)xmalloc(sizeof(work)); memset(w, 0, sizeof *w);
+		w->fatal = EXIT_FAILURE; queue_push(&pl->parsed, w);
+		free(qr);
+		return 0;
+	}
 	gzbuffer(qr->f, 1 << 20);
 	int32_t ramp = pl->batch < 4096 ? pl->batch : 4096;
 	for (int first = 1; ; first = 0) {
@@ -360,7 +366,9 @@ static void* stage_device(void* arg)
 				free(tmp);
 			}
 			if (ssw_gpu_pool_align(pl->gp, codes, off2, nr * sets, 0, 0, nt, &pl->prm, w->res, &w->pool, &w->words)) {
-				fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_pool_last_error(pl->gp)); exit(EXIT_FAILURE);
+				fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_pool_last_error(pl->gp));
+				free(codes); free(off2);
+				w->fatal = EXIT_FAILURE; queue_push(&pl->aligned, w); return 0;
 			}
 			free(codes); free(off2);
 		} else {
@@ -387,7 +395,10 @@ static void* stage_device(void* arg)
 				}
 			}
 			if (!Qs || !Qa || ssw_gpu_align_batch(pl->g, Qa, pl->T, 0, nt, &pl->prm, w->res, &w->pool, &w->words)) {
-				fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(pl->g)); exit(EXIT_FAILURE);
+				fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(pl->g));
+				if (Qa && Qa != Qs) ssw_gpu_seqs_free(Qa);
+				if (Qs) ssw_gpu_seqs_free(Qs);
+				w->fatal = EXIT_FAILURE; queue_push(&pl->aligned, w); return 0;
 			}
 			if (Qa != Qs) ssw_gpu_seqs_free(Qa);
 			ssw_gpu_seqs_free(Qs);
@@ -420,6 +431,9 @@ static void usage(void)
 
 int main(int argc, char* const argv[])
 {
+	/* stdout buffer first, before ANY output (the SAM header below): setvbuf after I/O on the stream is undefined (round-5 advisor) */
+	static char obuf[1 << 22];
+	setvbuf(stdout, obuf, _IOFBF, sizeof obuf);
 	int32_t match = 2, mismatch = 2, gap_open = 3, gap_ext = 1, path = 0, reverse = 0, n = 5, sam = 0, protein = 0, header = 0, filter = 0;
 	int32_t batch = 65536, gpus = 0;
 	const char* mat_name = 0;
@@ -488,7 +502,8 @@ int main(int argc, char* const argv[])
 	   (10 397 / 10 236 / 9 947 GCUPS on config 2), but its first allocation costs 3.7 s, and right after another process released tens of
 	   gigabytes even 2 x 30 GB can take seconds (the driver hands out scrubbed memory): profiles/round5_budget_sweep_config2.txt,
 	   round5_cli_end_to_end.json. */
-	if (!getenv("SSW_GPU_CM_BUDGET_MB")) ssw_gpu_set_budget(g, (size_t)16 << 30);
+	/* ... and never more than the library's own default for this device (half of the free HBM: a shared or partitioned device, round-5 advisor) */
+	if (!getenv("SSW_GPU_CM_BUDGET_MB") && ssw_gpu_get_budget(g) > ((size_t)16 << 30)) ssw_gpu_set_budget(g, (size_t)16 << 30);
 	ssw_gpu_seqs* T = ssw_gpu_seqs_upload(g, tcodes, toff, nt);
 	if (!T) { fprintf(stderr, "ssw_test_gpu: %s\n", ssw_gpu_last_error(g)); return EXIT_FAILURE; }
 	CLI_TRACE("targets resident");
@@ -515,8 +530,6 @@ int main(int argc, char* const argv[])
 	const clock_t t_start = clock();
 	pthread_t th_parse, th_dev;
 	if (pthread_create(&th_parse, 0, stage_parse, &pl) || pthread_create(&th_dev, 0, stage_device, &pl)) { fprintf(stderr, "ssw_test_gpu: cannot start the pipeline threads\n"); return EXIT_FAILURE; }
-	static char obuf[1 << 22];
-	setvbuf(stdout, obuf, _IOFBF, sizeof obuf);
 	int rc_main = 0;
 	for (;;) {
 		work* w = (work*)queue_pop(&pl.aligned);

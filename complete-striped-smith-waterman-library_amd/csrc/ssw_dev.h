@@ -14,7 +14,8 @@ extern "C" {
 #endif
 
 #define SSW_RMAX 24            /* rows per lane supported by the 16-lane chains: queries up to 16*24 = 384 residues */
-#define SSW_MAX_N 32           /* alphabet size limit (profile residues held in LDS) */
+#define SSW_MAX_N 32           /* alphabet size limit of the profile kernels (profile residues held in LDS) */
+#define SSW_MAX_N_WIDE 128     /* wider alphabets (33 .. 128 letters: every int8 code) take the lane-model kernel with the matrix in LDS and the thread traceback */
 #define SSW_LDS_LIMIT (160 * 1024)   /* LDS per workgroup on gfx950 */
 
 /* two queries that share one systolic chain (low / high 16-bit half of every VGPR) */

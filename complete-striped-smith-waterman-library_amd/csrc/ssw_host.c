@@ -21,6 +21,9 @@
 #include <pthread.h>
 #include "ssw.h"
 #include "ssw_gpu.h"
+#ifdef SSW_GPU_TEST_HOOKS
+#include "ssw_gpu_diag.h"      /* the diagnostics exist in the test-hooks build only */
+#endif
 #include "ssw_dev.h"
 
 _Static_assert(sizeof(struct ssw_out_rec) == sizeof(ssw_gpu_result), "device record layout must equal ssw_gpu_result");
@@ -80,6 +83,7 @@ struct ssw_gpu_ctx {
 	void* tstream[SSW_TSTREAMS]; void* tev[SSW_TSTREAMS];   /* traceback classes of one negotiation round run side by side */
 	void *ev_fill[2], *ev_red[2];
 	char err[512];
+	pthread_mutex_t mu;                 /* guards the lazily created streams and the error text: ONE other thread may upload sequences while a batch call runs */
 	ssw_gpu_timing tm;
 	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, cigar2, need, goff, gpool, bnd, tlist, cand, tresume, queue, cands, sg16, sg8, qerr, fmtab;
 	dbuf sres, svq, svt, scnt;          /* flagged database search: survivor records, their (query, target) maps, counters */
@@ -87,6 +91,7 @@ struct ssw_gpu_ctx {
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d, *ev_db;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
 	int busy;                           /* a batch call is running on this context (one call at a time per context) */
+	int side_ready;                     /* the side streams exist (ctx_side_streams) */
 	int budget_shrunk;                  /* an allocation failed once: the device is shared, the budget was cut (SSW_ALLOC_RETRY) */
 	ssw_knobs kn;                       /* environment hooks of the running call (knobs_load) */
 	int dev_cus, dev_wave_slots;        /* compute units and resident wavefront slots of the device (hipGetDeviceProperties) */
@@ -153,15 +158,11 @@ static void knobs_load(ssw_knobs* k)
 	{ const int v = env_int("SSW_GPU_DBX_SLAB", 0); k->dbx_slab = v > 0 ? v : 0; }
 #endif
 }
-/* 1 when this build reads the form-switching SSW_GPU_* hooks (tests refuse to run their variants on a library that would ignore them) */
-int ssw_gpu_has_test_hooks(void)
-{
 #ifdef SSW_GPU_TEST_HOOKS
-	return 1;
-#else
-	return 0;
+/* this build reads the form-switching SSW_GPU_* hooks (tests refuse to run their variants on a library that would ignore them; libssw.so has
+   no such symbol: include/ssw_gpu_diag.h) */
+int ssw_gpu_has_test_hooks(void) { return 1; }
 #endif
-}
 
 #include <time.h>
 static double dbg_ms(void)      /* wall clock for the SSW_GPU_DEBUG progress lines */
@@ -172,8 +173,12 @@ static double dbg_ms(void)      /* wall clock for the SSW_GPU_DEBUG progress lin
 
 static int fail(ssw_gpu_ctx* c, const char* fmt, const char* detail)
 {
-	char* dst = c ? c->err : g_open_err;
-	snprintf(dst, 512, fmt, detail ? detail : "");
+	if (!c) { snprintf(g_open_err, 512, fmt, detail ? detail : ""); return -1; }
+	char tmp[512];
+	snprintf(tmp, sizeof tmp, fmt, detail ? detail : "");
+	pthread_mutex_lock(&c->mu);      /* (a feeder thread's upload and the batch call may both fail: whole messages, one after the other) */
+	memcpy(c->err, tmp, sizeof tmp);
+	pthread_mutex_unlock(&c->mu);
 	return -1;
 }
 
@@ -203,6 +208,7 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
 	ssw_gpu_ctx* c = (ssw_gpu_ctx*)calloc(1, sizeof(*c));
 	if (!c) { fail(0, "out of host memory%s", ""); return 0; }
 	c->device = device;
+	pthread_mutex_init(&c->mu, 0);
 	c->stream = ssw_shim_stream_create();
 	int ok = c->stream != 0;      /* (the side streams come with the first call that is more than one pair: ctx_side_streams) */
 	for (int i = 0; i < 2; ++i) { c->ev_fill[i] = ssw_shim_event_create(); c->ev_red[i] = ssw_shim_event_create(); ok = ok && c->ev_fill[i] && c->ev_red[i]; }
@@ -235,10 +241,17 @@ ssw_gpu_ctx* ssw_gpu_open(int device)
    calls ran one after the other however many threads called (scripts/probes/dropin_threads.c, profiles/round4_dropin_threads.txt). */
 static int ctx_side_streams(ssw_gpu_ctx* c)
 {
-	if (c->stream2) return 0;
-	c->stream2 = ssw_shim_stream_create();
-	int ok = c->stream2 != 0;
-	for (int i = 0; i < SSW_TSTREAMS; ++i) { c->tstream[i] = ssw_shim_stream_create(); c->tev[i] = ssw_shim_event_create(); ok = ok && c->tstream[i] && c->tev[i]; }
+	/* under the context's lock (round-5 advisor): a feeder thread's FIRST upload creates these too (upload_stream), possibly while the first
+	   batch call is on its way here -- created twice, the first set would leak and the hardware-queue order the launch plans assume change */
+	pthread_mutex_lock(&c->mu);
+	int ok = 1;
+	if (!__atomic_load_n(&c->side_ready, __ATOMIC_ACQUIRE)) {
+		c->stream2 = ssw_shim_stream_create();
+		ok = c->stream2 != 0;
+		for (int i = 0; i < SSW_TSTREAMS; ++i) { c->tstream[i] = ssw_shim_stream_create(); c->tev[i] = ssw_shim_event_create(); ok = ok && c->tstream[i] && c->tev[i]; }
+		if (ok) __atomic_store_n(&c->side_ready, 1, __ATOMIC_RELEASE);
+	}
+	pthread_mutex_unlock(&c->mu);
 	return ok ? 0 : fail(c, "stream/event creation failed: %s", ssw_shim_last_error());
 }
 
@@ -299,6 +312,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_stream_destroy(c->stream2); ssw_shim_stream_destroy(c->ustream);
 	for (int i = 0; i < SSW_TSTREAMS; ++i) { ssw_shim_stream_destroy(c->tstream[i]); ssw_shim_event_destroy(c->tev[i]); }
 	ssw_shim_stream_destroy(c->stream);
+	pthread_mutex_destroy(&c->mu);
 	free(c);
 }
 
@@ -309,12 +323,16 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
    stream) */
 static void* upload_stream(ssw_gpu_ctx* c)
 {
-	if (!c->ustream) {
+	void* us = __atomic_load_n(&c->ustream, __ATOMIC_ACQUIRE);
+	if (!us) {
 		/* (after the side streams: the launch plans of a batch call know which hardware queue each of THOSE lands on by creation order) */
 		(void)ctx_side_streams(c);
-		c->ustream = ssw_shim_stream_create();
+		pthread_mutex_lock(&c->mu);
+		if (!c->ustream) __atomic_store_n(&c->ustream, ssw_shim_stream_create(), __ATOMIC_RELEASE);
+		us = c->ustream;
+		pthread_mutex_unlock(&c->mu);
 	}
-	return c->ustream ? c->ustream : c->stream;
+	return us ? us : c->stream;
 }
 
 /* host-side shell of a sequence set + its two device arrays (codes, offsets); NULL with the error set on failure */
@@ -1013,7 +1031,8 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 		int32_t* d_resume = (int32_t*)ensure(c, &c->tresume, sizeof(int32_t) * 8 * (size_t)nq);
 		if (!d_cig || !d_need || !d_resume) return -1;      /* (the teams' resume state is zeroed before the first team launch) */
 		int64_t sstride = ((int64_t)3 * 720 + (int64_t)(2 * 16 + 1) * maxlen * 3 + 64 + 15) / 16 * 16;      /* three rows of a band of 48 (padded: ssw_kernels.hip trace_rowbytes) + 99 direction bytes per row (k_trace: band 16, three bytes per cell) */
-		if (c->kn.trace_wave != 0)      /* the team kernels keep one NIBBLE per cell (round 5): a band of 48 is 49 bytes per row */
+		const int wide = n > SSW_MAX_N;      /* the team kernels hold the matrix in 1 KiB of LDS: wider alphabets walk on threads (k_trace reads it through the cache) */
+		if (c->kn.trace_wave != 0 && !wide)      /* the team kernels keep one NIBBLE per cell (round 5): a band of 48 is 49 bytes per row */
 			sstride = ((int64_t)3 * 720 + (int64_t)49 * maxlen + 64 + 15) / 16 * 16;
 		/* long reads: one wavefront per alignment (wide bands, 10^4 rows); short reads: one thread per alignment */
 		/* Which kernel walks a band.  Rounds 1-3 gave short reads ONE THREAD per alignment (k_trace) and only reads above 1 kb a TEAM of wavefronts
@@ -1022,8 +1041,8 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 		   tracebacks 17 ms on threads, 6 ms on teams (one wavefront each); 88 000 protein tracebacks 1654 vs 189 ms, 524 000: 11.6 vs 0.64 s;
 		   one ssw_align call with flag 2: 1.24 vs 0.96 ms (profiles/round4_dbx.txt, round4_latency.txt).  The thread kernel stays for
 		   SSW_GPU_TRACE_WAVE=0 (tests compare the two). */
-		const int use_wave0 = c->kn.trace_wave >= 0 ? c->kn.trace_wave : 1;
-		const int use_wave = c->kn.trace_wave >= 0 ? c->kn.trace_wave : 1;      /* rounds after the first */
+		const int use_wave0 = wide ? 0 : c->kn.trace_wave >= 0 ? c->kn.trace_wave : 1;
+		const int use_wave = wide ? 0 : c->kn.trace_wave >= 0 ? c->kn.trace_wave : 1;      /* rounds after the first */
 		const int trace_no_lds = c->kn.trace_no_lds;     /* experiment / test: band rows in HBM scratch instead of LDS */
 		const int trace_waves_env = c->kn.trace_waves;   /* experiment / test */
 		const int trace_unblocked = c->kn.trace_unblocked;      /* experiment / test: teams with one cell per thread */
@@ -1389,19 +1408,26 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 	if (!Q || !T || !prm || (!results && !ds) || !prm->mat) return fail(c, "align_batch: NULL argument%s", "");
 	if (Q->ctx != c || T->ctx != c) return fail(c, "align_batch: sequences belong to another context%s", "");
 	if (tfirst < 0 || tcount < 0 || tfirst + tcount > T->count) return fail(c, "align_batch: target range out of bounds%s", "");
-	if (prm->n < 1 || prm->n > SSW_MAX_N) return fail(c, "align_batch: alphabet size must be 1..32%s", "");
+	if (prm->n < 1) return fail(c, "align_batch: alphabet size must be >= 1%s", "");
 	if (prm->score_size < 0 || prm->score_size > 2) return fail(c, "align_batch: score_size must be 0, 1 or 2%s", "");
-	const int literal = prm->gapO <= prm->gapE;   /* layout-dependent regime of the reference: lane-model kernel (k_literal) */
+	/* Alphabets.  The reference takes any int32 n (src/ssw.h:86, ssw.c:826-847).  Up to 32 letters the per-residue score profile of a query
+	   lives in LDS (the profile kernels); 33 .. 128 letters -- every value an int8 code can take -- run on the lane-model kernel, which looks
+	   its scores up in the MATRIX (n x n bytes of LDS) and is exact in every gap regime, and on the thread traceback, which reads the matrix
+	   through the cache: slow (a CPU-class path, like gapO <= gapE), but the reference's answer instead of a refusal.  n > 128: codes are int8,
+	   so only the leading 128 x 128 block of the matrix can ever be addressed -- the kernels get that block; the 8-bit bias is still the minimum
+	   over the WHOLE matrix, as ssw_init computes it (ssw.c:834-836). */
+	const int wide = prm->n > SSW_MAX_N;
+	const int literal = prm->gapO <= prm->gapE || wide;   /* layout-dependent regime of the reference / wide alphabet: lane-model kernel (k_literal) */
 	ssw_shim_set_device(c->device);
 	knobs_load(&c->kn);
 	if ((Q->count > 1 || tcount > 1 || ds) && ctx_side_streams(c)) return -1;      /* (one pair never leaves the main stream) */
 	if (cigar_pool) *cigar_pool = 0;
 	if (cigar_words) *cigar_words = 0;
-	const int32_t nq = Q->count, n = prm->n;
+	const int32_t nq = Q->count, n = prm->n > SSW_MAX_N_WIDE ? SSW_MAX_N_WIDE : prm->n;
 	if (nq == 0 || tcount == 0) return 0;
 
 	int32_t bias = 0, maxmat = 0;
-	for (int32_t i = 0; i < n * n; ++i) { if (prm->mat[i] < bias) bias = prm->mat[i]; if (prm->mat[i] > maxmat) maxmat = prm->mat[i]; }
+	for (int64_t i = 0; i < (int64_t)prm->n * prm->n; ++i) { if (prm->mat[i] < bias) bias = prm->mat[i]; if (prm->mat[i] > maxmat) maxmat = prm->mat[i]; }
 	const int32_t minmat = bias;      /* <= 0 */
 	bias = (prm->score_size == 0 || prm->score_size == 2) ? -bias : 0;
 
@@ -1527,7 +1553,8 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 	int8_t* d_mat = (int8_t*)d_hdr;
 	ssw_pair* d_pairs = (ssw_pair*)(d_hdr + hdr_mat);
 	int32_t* d_qlist = (int32_t*)(d_hdr + hdr_mat + hdr_pairs);
-	memcpy(hhdr, prm->mat, (size_t)n * n);
+	if (n == prm->n) memcpy(hhdr, prm->mat, (size_t)n * n);
+	else for (int32_t r = 0; r < n; ++r) memcpy(hhdr + (size_t)r * n, prm->mat + (size_t)r * prm->n, (size_t)n);      /* the addressable block of a matrix wider than int8 codes */
 	memcpy(hhdr + hdr_mat, pairs, sizeof(ssw_pair) * (size_t)npairs_total);
 	memcpy(hhdr + hdr_mat + hdr_pairs, order, sizeof(int32_t) * (size_t)nqa);
 	ssw_shim_event_record(c->ev_t0, c->stream);
@@ -1608,8 +1635,8 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 			void* e0 = next_event(c); void* e1 = next_event(c);
 			ssw_shim_event_record(e0, c->stream);
 			for (int pass = 0; pass < (prm->flag != 0 ? 2 : 1); ++pass)
-				for (int32_t q0 = 0; q0 < nq; q0 += (int32_t)per) {
-					const int32_t cnt_q = nq - q0 < per ? nq - q0 : (int32_t)per;
+				for (int32_t q0 = 0; q0 < nqa; q0 += (int32_t)per) {      /* (d_qlist holds the nqa NON-EMPTY queries; empty ones keep the zeroed record) */
+					const int32_t cnt_q = nqa - q0 < per ? nqa - q0 : (int32_t)per;
 					uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)(sstr * cnt_q));
 					if (!d_scr) goto done;
 					ssw_literal_args la;
@@ -2163,6 +2190,7 @@ void ssw_gpu_host_free(ssw_gpu_ctx* c, void* p)
 	ssw_shim_host_free(p);
 }
 
+#ifdef SSW_GPU_TEST_HOOKS      /* diagnostics: libssw_hooks.so and the emulator only (include/ssw_gpu_diag.h) */
 int ssw_gpu_selftest_lanes(ssw_gpu_ctx* c, uint32_t* out1024)
 {
 	if (!c || !out1024) return -1;
@@ -2196,6 +2224,7 @@ double ssw_gpu_valu_probe(ssw_gpu_ctx* c, int32_t blocks, int32_t iters)
 	ssw_shim_free(sink);
 	return best;
 }
+#endif
 
 s_align* ssw_gpu_result_to_align(const ssw_gpu_result* r, const uint32_t* cigar_pool)
 {
@@ -2242,27 +2271,54 @@ static int g_next_device = 0;
    pthread-key destructor, i.e. AFTER the C++ thread_local objects of the exiting thread -- the runtime's own per-thread state among them --
    have been destroyed, and a hipFree / hipStreamDestroy from there works on freed memory.  Round 4's hook closed the context right there;
    with 16 caller threads ending together that corrupted the heap now and then (a crash at process exit, found with the round-5 latency
-   harness).  Parked contexts are reused, never closed: what is left at process exit goes with the process. */
+   harness).  Parked contexts are reused by the next new caller thread; more than SSW_PARK_MAX of them are closed by the next LIVE thread that
+   comes through implicit_get, and ssw_gpu_release_parked() closes all of them (round-5 advisor: after a burst of N caller threads the process
+   kept N contexts' HBM until exit).  What is still parked at process exit goes with the process. */
+#define SSW_PARK_MAX 4
 static pthread_mutex_t g_park_mu = PTHREAD_MUTEX_INITIALIZER;
 static implicit_ctx* g_parked;
+static int g_nparked;
 static void implicit_destroy(void* p)
 {
 	implicit_ctx* ic = (implicit_ctx*)p;
 	if (!ic) return;
 	pthread_mutex_lock(&g_park_mu);
-	ic->next = g_parked; g_parked = ic;
+	ic->next = g_parked; g_parked = ic; ++g_nparked;
 	pthread_mutex_unlock(&g_park_mu);
 }
+static void implicit_free(implicit_ctx* ic)      /* from a live thread only (HIP calls inside) */
+{
+	ssw_gpu_ctx* c = ic->ctx;
+	ssw_shim_set_device(c->device);
+	ssw_shim_stream_sync(c->stream);
+	if (ic->q.d_off) ssw_shim_free(ic->q.d_off);
+	if (ic->t.d_off) ssw_shim_free(ic->t.d_off);
+	free(ic->tcopy); free(ic->stage);
+	ssw_gpu_close(c);
+	free(ic);
+}
+/* closes the parked contexts beyond `keep`; returns how many were closed */
+static int parked_trim(int keep)
+{
+	implicit_ctx* drop = 0; int n = 0;
+	pthread_mutex_lock(&g_park_mu);
+	while (g_nparked > keep && g_parked) { implicit_ctx* ic = g_parked; g_parked = ic->next; --g_nparked; ic->next = drop; drop = ic; }
+	pthread_mutex_unlock(&g_park_mu);
+	while (drop) { implicit_ctx* ic = drop; drop = ic->next; implicit_free(ic); ++n; }
+	return n;
+}
+int ssw_gpu_release_parked(void) { return parked_trim(0); }
 /* Runs once per process, before the first implicit context exists (pthread_once), not from every first-calling thread.
    Caller threads' calls overlap on the device only as far as the runtime has hardware queues for their streams: ROCm's default is four
-   per process.  If nobody chose otherwise and the runtime is not up yet (this is typically the process's first HIP call), ask for eight:
-   8 caller threads 6 085 -> 8 146 calls per second (profiles/round4_dropin_threads.txt).  Without effect in a process that initialised
-   HIP before; a user's own GPU_MAX_HW_QUEUES is left alone, and SSW_GPU_KEEP_ENV=1 makes the library leave the environment alone
-   altogether (an embedder whose other threads may be inside getenv at that moment: INTEGRATION.md). */
+   per process; eight made 8 caller threads 6 085 -> 8 146 calls per second (profiles/round4_dropin_threads.txt).  Rounds 4-5 asked for
+   eight by themselves (setenv GPU_MAX_HW_QUEUES); a drop-in library does not change process-wide runtime configuration unasked (round-5
+   verdict): it is OPT-IN now -- SSW_GPU_HW_QUEUES=<n> in the environment makes the library ask for n queues if nobody set
+   GPU_MAX_HW_QUEUES and the runtime is not up yet; without it the environment is left alone. */
 static void implicit_key_init(void)
 {
 	pthread_key_create(&g_ictx_key, implicit_destroy);
-	if (!getenv("SSW_GPU_KEEP_ENV")) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+	const char* q = getenv("SSW_GPU_HW_QUEUES");
+	if (q && q[0] >= '1' && q[0] <= '9') setenv("GPU_MAX_HW_QUEUES", q, 0);
 }
 
 static implicit_ctx* implicit_get(void)
@@ -2272,8 +2328,9 @@ static implicit_ctx* implicit_get(void)
 	if (ic) return ic;
 	pthread_mutex_lock(&g_park_mu);      /* a context parked by a caller thread that ended: taken over as it is (its device, its buffers, its resident target) */
 	ic = g_parked;
-	if (ic) g_parked = ic->next;
+	if (ic) { g_parked = ic->next; --g_nparked; }
 	pthread_mutex_unlock(&g_park_mu);
+	parked_trim(SSW_PARK_MAX);            /* (this thread is alive: it may call into the runtime) */
 	if (ic) { ic->next = 0; pthread_setspecific(g_ictx_key, ic); return ic; }
 	const int ndev = ssw_shim_device_count();
 	const char* e = getenv("SSW_GPU_DEVICE");

@@ -3534,12 +3534,14 @@ extern "C" int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream)
 	const int64_t st = args.state_bytes;
 	int threads = 64;
 	args.lds_stride = 0;
+	if (args.n < 1 || args.n > SSW_MAX_N_WIDE) return -1;
+	const int64_t matb = ((int64_t)args.n * args.n + 15) / 16 * 16 < 1024 ? 1024 : ((int64_t)args.n * args.n + 15) / 16 * 16;      /* the matrix in LDS: 1 KiB up to 32 letters, 16 KiB at 128 */
 	/* (an alignment is one DPP row -- 16 lanes -- whatever the workgroup: small batches take wavefront-sized workgroups so that
 	   they spread over more CUs) */
-	if (st > 0 && st * 16 <= 65536 && args.nq >= 16 * 2048) { threads = 256; args.lds_stride = (int32_t)st; }
-	else if (st > 0 && st * 4 + 1024 <= (int64_t)SSW_LDS_LIMIT) { threads = 64; args.lds_stride = (int32_t)st; }
+	if (st > 0 && st * 16 + matb <= 65536 + 1024 && args.nq >= 16 * 2048) { threads = 256; args.lds_stride = (int32_t)st; }
+	else if (st > 0 && st * 4 + matb <= (int64_t)SSW_LDS_LIMIT) { threads = 64; args.lds_stride = (int32_t)st; }
 	const int per = threads / 16;
-	SSW_LAUNCH(k_literal, ssw_literal_args, args, (args.nq + per - 1) / per, threads, (size_t)args.lds_stride * per + 1024, stream);
+	SSW_LAUNCH(k_literal, ssw_literal_args, args, (args.nq + per - 1) / per, threads, (size_t)args.lds_stride * per + (size_t)matb, stream);
 	return SSW_LAUNCH_OK();
 }
 

@@ -123,10 +123,12 @@ def load(path=None):
     L.ssw_gpu_host_alloc.restype = C.c_void_p
     L.ssw_gpu_host_free.argtypes = [C.c_void_p, C.c_void_p]
     L.ssw_gpu_host_free.restype = None
-    L.ssw_gpu_selftest_lanes.argtypes = [C.c_void_p, _u32p]
-    L.ssw_gpu_selftest_lanes.restype = C.c_int
-    L.ssw_gpu_valu_probe.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
-    L.ssw_gpu_valu_probe.restype = C.c_double
+    if hasattr(L, "ssw_gpu_valu_probe"):      # diagnostics (include/ssw_gpu_diag.h): libssw_hooks.so and the test emulator only
+        L.ssw_gpu_selftest_lanes.argtypes = [C.c_void_p, _u32p]
+        L.ssw_gpu_selftest_lanes.restype = C.c_int
+        L.ssw_gpu_valu_probe.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.ssw_gpu_valu_probe.restype = C.c_double
+    L.ssw_gpu_release_parked.restype = C.c_int
     L.ssw_gpu_search_db.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Params), C.c_int32, HITS_FN, C.c_void_p]
     L.ssw_gpu_search_db.restype = C.c_int
     L.ssw_gpu_pool_open.argtypes = [C.POINTER(C.c_int), C.c_int]
@@ -218,6 +220,7 @@ class Context(object):
     def __init__(self, device=0, lib=None):
         self.lib = lib if lib is not None and not isinstance(lib, str) else load(lib)
         self._pinned = []
+        self.device = device
         self.h = self.lib.ssw_gpu_open(device)
         if not self.h:
             raise RuntimeError("ssw_gpu_open: " + self.lib.ssw_gpu_last_error(None).decode())
@@ -318,6 +321,7 @@ class Context(object):
         return d
 
     def selftest_lanes(self):
+        """diagnostic of libssw_hooks.so (include/ssw_gpu_diag.h); the product library does not export it"""
         out = np.zeros((16, 64), dtype=np.uint32)
         if self.lib.ssw_gpu_selftest_lanes(self.h, out.ctypes.data_as(_u32p)) != 0:
             raise RuntimeError("ssw_gpu_selftest_lanes: " + self.error())

@@ -199,14 +199,13 @@ int ssw_gpu_pool_stats(const ssw_gpu_pool* pool, int worker, ssw_gpu_pool_stat* 
 void* ssw_gpu_host_alloc(ssw_gpu_ctx* ctx, size_t bytes);
 void ssw_gpu_host_free(ssw_gpu_ctx* ctx, void* p);
 
-/* Diagnostics.  ssw_gpu_selftest_lanes: 16 x 64 words produced by the cross-lane / packed-arithmetic primitives the
-   kernels are written in (checked by tests against the ISA semantics).  ssw_gpu_valu_probe: measured issue rate of
-   packed 16-bit VALU instructions in lane-operations per second (the compute roofline of this integer path). */
-int ssw_gpu_selftest_lanes(ssw_gpu_ctx* ctx, uint32_t* out1024);
-double ssw_gpu_valu_probe(ssw_gpu_ctx* ctx, int32_t blocks, int32_t iters);
-/* 1 when the library was built with -DSSW_GPU_TEST_HOOKS (libssw_hooks.so, the test emulator): only that build reads the form-switching
-   SSW_GPU_* environment hooks of INTEGRATION.md; libssw.so returns 0 and ignores them. */
-int ssw_gpu_has_test_hooks(void);
+/* (Diagnostics -- lane self-test, VALU issue probe, test-hook query -- are declared in include/ssw_gpu_diag.h and exist only in
+   libssw_hooks.so: the product library exports the reference's symbols and the batch ABI above, one by one, in libssw.map.) */
+
+/* Single-pair callers (ssw_align) get an implicit context per calling thread; a thread that ends parks its context for the next new caller
+   thread (at most 4 stay parked).  This closes every parked context now -- their streams, scratch pools and resident target copies -- and
+   returns how many were closed.  Call it from a live thread after a burst of short-lived caller threads. */
+int ssw_gpu_release_parked(void);
 
 /* Convert one batch record into a heap s_align (align_destroy()-compatible), copying its CIGAR. */
 s_align* ssw_gpu_result_to_align(const ssw_gpu_result* r, const uint32_t* cigar_pool);

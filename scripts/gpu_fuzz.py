@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Differential fuzz of the batch ABI against the unmodified reference (oracle/_ref), on the GPU box (or, with --emu, on the SIMT emulator):
-exotic parameters on purpose -- alphabets of 4..24 letters, full-range / all-non-positive / sparse matrices, gapO <= gapE, gapO = 0, gapE = 0,
-gaps up to 255, maskLen 0..40, every flag, score_size 0 / 1 / 2, filters, lengths 1..700, one or several targets (the database path from four
-targets on).  Every record and CIGAR is compared (tests/parity.py); a call that fails is counted separately from a wrong value.
-usage: gpu_fuzz.py <seconds> <seed> [--emu]        -> one JSON line"""
+exotic parameters on purpose -- alphabets of 4..128 letters, full-range / all-non-positive / sparse matrices, gapO <= gapE, gapO = 0, gapE = 0,
+gaps up to 255, maskLen 0..40, every flag, score_size 0 / 1 / 2, filters, lengths 0..700 (EMPTY queries and EMPTY targets in 7 % of the slots
+each -- round-5 verdict: no fuzzer drew them, which is how an out-of-bounds of the gapO <= gapE path survived), one or several targets (the
+database path from four targets on), ALL CALLS ON ONE LONG-LIVED CONTEXT (what a call leaves in the pooled buffers is the next call's
+environment).  Every record and CIGAR is compared (tests/parity.py); a call that fails is counted separately from a wrong value.
+usage: gpu_fuzz.py <seconds> <seed> [--emu | --lib <path>]        -> one JSON line
+(--lib: another build of the emulated library, e.g. the AddressSanitizer one of scripts/asan_emu_fuzz.sh)"""
 import json
 import os
 import sys
@@ -20,12 +23,14 @@ from sswutil import blosum50, dna_matrix   # noqa: E402
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 emu = "--emu" in sys.argv
-lib = ssw_amd.load(os.path.join(ROOT, "tests", "emu", "libssw_emu.so") if emu else None)
+libpath = sys.argv[sys.argv.index("--lib") + 1] if "--lib" in sys.argv else os.path.join(ROOT, "tests", "emu", "libssw_emu.so") if emu else None
+emu = emu or "--lib" in sys.argv
+lib = ssw_amd.load(libpath)
 ctx = ssw_amd.Context(0, lib)
 rng = np.random.default_rng(seed)
 t_end = time.time() + secs
 calls = aln = failed = wrong = nullrec = flag1 = 0
-regimes = {"gapO>gapE": 0, "gapO<=gapE": 0, "gapO=0": 0, "db_path": 0}
+regimes = {"alphabet>32": 0, "gapO>gapE": 0, "gapO<=gapE": 0, "gapO=0": 0, "db_path": 0, "calls_with_empty_query": 0, "calls_with_empty_target": 0}
 first = []
 while time.time() < t_end:
     kind = rng.random()
@@ -34,7 +39,7 @@ while time.time() < t_end:
     elif kind < 0.45:
         n, nc, mat = 24, 20, blosum50()
     else:
-        n = int(rng.integers(4, 25)); nc = n - 1 if n > 4 else n
+        n = int(rng.integers(4, 25)) if rng.random() < 0.85 else int(rng.integers(25, 129)); nc = n - 1 if n > 4 else n      # (above 32 letters: the lane-model kernel + thread traceback)
         style = rng.random()
         if style < 0.3:
             m = rng.integers(-128, 128, size=(n, n))
@@ -55,14 +60,17 @@ while time.time() < t_end:
     else:
         gapO = int(rng.integers(0, 256)); gapE = int(rng.integers(0, 256))
     nt = 1 if rng.random() < 0.7 else int(rng.integers(2, 9))
-    refs = [rng.integers(0, nc, size=int(rng.integers(1, 701)), dtype=np.int8) for _ in range(nt)]
+    refs = [rng.integers(0, nc, size=0 if rng.random() < 0.07 else int(rng.integers(1, 701)), dtype=np.int8) for _ in range(nt)]
     nq = int(rng.integers(1, 10))
     lens = rng.integers(1, 701, size=nq) if rng.random() < 0.3 else rng.integers(1, 160, size=nq)
-    reads = make_reads(rng, refs[0], nq, lens, nc, frac_random=0.3)
+    lens = np.where(rng.random(nq) < 0.07, 0, lens)
+    reads = make_reads(rng, max(refs, key=len), nq, lens, nc, frac_random=0.3)
+    regimes["calls_with_empty_query"] += int((lens == 0).any()); regimes["calls_with_empty_target"] += int(any(len(r) == 0 for r in refs))
     flag = int(rng.integers(0, 16)); ss = int(rng.choice([2, 2, 2, 0, 1]))
     filters = int(rng.choice([0, 0, 20, 100])); filterd = int(rng.choice([0, 30, 1000])); maskLen = int(rng.choice([-1, -1, 0, 14, 15, 40]))
     regimes["gapO=0" if gapO == 0 else "gapO<=gapE" if gapO <= gapE else "gapO>gapE"] += 1
     if nt >= 4: regimes["db_path"] += 1
+    if n > 32: regimes["alphabet>32"] += 1
     calls += 1; aln += nq * nt
     Q = ctx.upload(reads); T = ctx.upload(refs)
     try:

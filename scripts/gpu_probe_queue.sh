@@ -9,7 +9,10 @@ import numpy as np, ssw_amd
 from parity import compare_batch, make_reads
 from sswutil import dna_matrix, random_ref
 print("start", flush=True)
-ctx = ssw_amd.Context(0)
+import os
+lib = ssw_amd.load(os.path.join("complete-striped-smith-waterman-library_amd", "libssw_hooks.so"))      # libssw.so ignores the SSW_GPU_* hooks (round-5 advisor)
+assert lib.ssw_gpu_has_test_hooks() == 1
+ctx = ssw_amd.Context(0, lib)
 rng = np.random.default_rng(3)
 ref = random_ref(20000, 5, 4)
 reads = make_reads(rng, ref, 3, [3000, 2990, 2500], 4, sub=0.02, ins=0.005, dele=0.005, frac_random=0.0)

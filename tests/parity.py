@@ -2,11 +2,16 @@
 import numpy as np
 
 from sswutil import RES_FIELDS, cigar_str, oracle_align, ref_align, ref_lib
-from sswutil import dna_matrix as _dna_matrix, random_ref as _random_ref
+from sswutil import blosum50 as _blosum50, dna_matrix as _dna_matrix, random_ref as _random_ref
 
 
 def expected(read, mat, n, ref, gapO, gapE, flag, filters, filterd, maskLen, score_size, use_ref=True):
-    """The reference's answer: the compiled reference when oracle/_ref is present, else the pinned oracle."""
+    """The reference's answer: the compiled reference when oracle/_ref is present, else the pinned oracle.
+    An EMPTY read is outside the reference's domain (src/ssw.c:264 / :469 index pvHStore[segLen - 1] with segLen == 0: undefined behaviour),
+    but include/ssw.h and ssw_gpu.h declare it legal here: its answer is the record ssw_align starts from (src/ssw.c:870-875) -- score 0,
+    begins -1 -- which is also what the reference returns for `bests[0].score <= 0` (ssw.c:900-903).  The checkers are not called with it."""
+    if len(read) == 0:
+        return dict(zip(RES_FIELDS, (0, 0, -1, 0, -1, 0, 0, 0, 0))), []
     if use_ref and ref_lib() is not None:
         return ref_align(read, mat, n, ref, gapO, gapE, flag, filters, filterd, maskLen, score_size)
     d, cig = oracle_align(read, mat, n, ref, gapO, gapE, flag, filters, filterd, maskLen, score_size, 0)
@@ -104,3 +109,49 @@ def narrow_band_batches(rng, count):
                 reads[0] = np.ascontiguousarray(np.concatenate([ref[o:o + 50], ref[o + 50 + int(rng.integers(10, 40)):o + 140]]))
         gapE = int(rng.integers(1, 3)); gapO = gapE + int(rng.integers(1, 5))
         yield reads, ref, _dna_matrix(int(rng.integers(1, 4)), int(rng.integers(1, 5))), gapO, gapE, int(rng.choice([1, 2, 2, 9, 15]))
+
+
+def empties_two_call_repro(run):
+    """round-5 verdict, weak #1: k_literal's launches were counted over ALL queries while the device query list holds only the non-empty ones;
+    the jobs past the list read whatever the previous call left in the header buffer as a query index and wrote a record through it.  Call A
+    leaves large indices and a 28-letter matrix behind, call B (gapO <= gapE, empty queries in the batch) then walked off the list."""
+    rng = np.random.default_rng(5)
+    n = 28
+    matA = np.ascontiguousarray(rng.integers(-128, 128, size=(n, n)).astype(np.int8).reshape(-1))
+    matA[40:96] = 127      # (where call B's header buffer keeps its query list: stale words there read as huge positive indices)
+    refA = rng.integers(0, n - 1, size=300, dtype=np.int8)
+    run([rng.integers(0, n - 1, size=60, dtype=np.int8) for _ in range(6)], [refA], matA, n, 9, 3, 0)
+    ref = _random_ref(200, 31, 4)
+    empty = np.zeros(0, dtype=np.int8)
+    for flag in (0, 1, 9):
+        reads = [ref[20:70].copy(), empty, ref[100:140].copy(), empty]
+        res = run(reads, [ref], _dna_matrix(2, 2), 5, 1, 1, flag)
+        assert (res["score1"][[1, 3], 0] == 0).all() and (res["ref_begin1"][[1, 3], 0] == -1).all() and (res["score1"][[0, 2], 0] > 0).all()
+
+
+def empties_case(rng):
+    """one batch with empty queries and / or empty targets among the slots, any gap regime, any flag, alphabet and batch size changing from
+    call to call (meant for ONE long-lived context: what a call leaves in the pooled buffers is part of the next call's environment)"""
+    kind = rng.random()
+    if kind < 0.4:
+        n, nc, mat = 5, 4, _dna_matrix(int(rng.integers(1, 4)), int(rng.integers(1, 6)))
+    elif kind < 0.6:
+        n, nc, mat = 24, 20, _blosum50()
+    else:
+        n = int(rng.integers(4, 33)); nc = n - 1
+        mat = np.ascontiguousarray(rng.integers(-20, 21, size=(n, n)).astype(np.int8).reshape(-1))
+    g = rng.random()
+    if g < 0.45:
+        gapE = int(rng.integers(1, 4)); gapO = gapE + int(rng.integers(1, 9))
+    elif g < 0.85:
+        gapO = int(rng.integers(0, 6)); gapE = gapO + int(rng.integers(0, 4))
+    else:
+        gapO = 0; gapE = int(rng.integers(0, 3))
+    nt = 1 if rng.random() < 0.6 else int(rng.integers(2, 8))
+    refs = [rng.integers(0, nc, size=0 if rng.random() < 0.12 else int(rng.integers(1, 400)), dtype=np.int8) for _ in range(nt)]
+    base = max(refs, key=len)
+    nq = int(rng.integers(1, 12))
+    lens = [0 if rng.random() < 0.2 else int(rng.integers(1, 500 if rng.random() < 0.15 else 120)) for _ in range(nq)]
+    reads = [np.zeros(0, dtype=np.int8) if L == 0 else make_reads(rng, base, 1, [L], nc, frac_random=0.3)[0] for L in lens]
+    return (reads, refs, mat, n, gapO, gapE, int(rng.choice([0, 0, 1, 2, 8, 9, 15, 6])), int(rng.choice([0, 0, 30])), int(rng.choice([0, 40, 1000])),
+            int(rng.choice([-1, -1, 0, 15, 40])), int(rng.choice([2, 2, 2, 0, 1])))

@@ -43,13 +43,16 @@ def test_library_exports_nothing_else(product_lib_path):
     import subprocess
     reference = {"ssw_init", "init_destroy", "ssw_align", "align_destroy", "mark_mismatch", "encoded_ops", "add_cigar", "store_previous_m"}
     declared = set(declared_functions("ssw_gpu.h"))
-    for path in (product_lib_path, os.path.join(os.path.dirname(product_lib_path), "libssw_hooks.so")):
+    diag = set(declared_functions("ssw_gpu_diag.h"))      # lane self-test, issue probe, hook query: libssw_hooks.so ONLY (round-5 verdict, weak #7)
+    assert diag == {"ssw_gpu_selftest_lanes", "ssw_gpu_valu_probe", "ssw_gpu_has_test_hooks"}
+    for path, want in ((product_lib_path, reference | declared), (os.path.join(os.path.dirname(product_lib_path), "libssw_hooks.so"), reference | declared | diag)):
         out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
         syms = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
-        extra = syms - reference - declared
-        assert not extra, "%s exports undeclared symbols: %s" % (os.path.basename(path), sorted(extra))
-        assert reference <= syms and declared <= syms
-    assert C.CDLL(product_lib_path).ssw_gpu_has_test_hooks() == 0      # the product ignores the form-switching SSW_GPU_* hooks
+        assert syms == want, "%s: exported but not declared %s, declared but not exported %s" % (os.path.basename(path), sorted(syms - want), sorted(want - syms))
+    # the export maps name every symbol (no wildcard that a new diagnostic could ride into the product)
+    for m in ("libssw.map", "libssw_hooks.map"):
+        body = re.sub(r"/\*.*?\*/", "", open(os.path.join(os.path.dirname(product_lib_path), m)).read(), flags=re.S)
+        assert "*" not in body.split("local:")[0], m
 
 
 def test_s_align_layout_matches_reference_ctypes_mirror():
