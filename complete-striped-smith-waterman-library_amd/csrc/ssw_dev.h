@@ -279,6 +279,10 @@ typedef struct {
 	int64_t mc_off;          /* offset of maxColumn in a region (= state_bytes rounded up to 16) */
 	int64_t state_bytes;     /* H x2, E, Hmax as [segments][16] int16 + codes, sized for the 16-bit kernel of the longest read */
 	int32_t lds_stride;      /* set by the launcher: > 0 = per-alignment state in LDS */
+	int32_t* spec_cnt;       /* optional (forward pass, score_size 2): per QUERY a counter, zeroed by the host -- both rule sets run as separate jobs, the later
+	                            one writes the record; NULL: the 16-bit kernel follows the 8-bit one where that saturated.  Scratch then holds
+	                            ((nq + 3) & ~3) + nq regions */
+	int32_t* spec_out;       /* ... and 2 x 8 ints per QUERY: what each of the two jobs found */
 } ssw_literal_args;
 
 /* banded traceback */

@@ -60,6 +60,8 @@ typedef struct {
 	int trace_waves;        /* SSW_GPU_TRACE_WAVES=1/4/16: team size; 0: by band width */
 	int trace_unblocked;    /* SSW_GPU_TRACE_BLOCKED=0: teams with one cell per thread */
 	int trace_many;         /* SSW_GPU_TRACE_MANY=<n>: a traceback round with more than n pending alignments sizes its teams for throughput (tests: 0); default 4096 */
+	int no_lit_spec;        /* SSW_GPU_LIT_SPEC=0: the lane-model kernel runs its 16-bit rules after the 8-bit ones (never both side by side: the form before round 6) */
+	int trace_no_cls80;     /* SSW_GPU_TRACE_CLS80=0: no 80-KiB LDS class for the traceback teams (the classes before round 6) */
 	int trace_diag;         /* SSW_GPU_TRACE_DIAG=1: the anti-diagonal narrow-band kernel (k_trace_diag, four alignments per wavefront) in front of the row
 	                           kernels.  Built, bit-exact, measured in round 5 and NOT faster (52.8 ms against ~48 ms of the row kernel for the same 10^4
 	                           alignments of config 4): kept for tests and as a starting point, off by default */
@@ -153,6 +155,8 @@ static void knobs_load(ssw_knobs* k)
 	k->serial_buckets = env_is("SSW_GPU_SERIAL_BUCKETS", '1');
 	k->no_dbx = env_is("SSW_GPU_NO_DBX", '1');
 	k->no_band = env_is("SSW_GPU_NO_BAND", '1');
+	k->trace_no_cls80 = env_is("SSW_GPU_TRACE_CLS80", '0');
+	k->no_lit_spec = env_is("SSW_GPU_LIT_SPEC", '0');
 	k->no_tail = env_is("SSW_GPU_NO_TAIL", '1');
 	{ const int v = env_int("SSW_GPU_DB_TSUB", 0); k->db_tsub = v > 0 ? v : 0; }
 	{ const int v = env_int("SSW_GPU_DBX_SLAB", 0); k->dbx_slab = v > 0 ? v : 0; }
@@ -1167,10 +1171,13 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 								   cells of a row each: 62 114 alignments of the 2048 x 10 000 search 109 -> xx ms (profiles/round5_dbx*.json). */
 								if (npend > c->kn.trace_many) wv = b2 <= 254 ? 1 : b2 <= 3070 ? 4 : 16;
 								if (trace_waves_env > 0) wv = trace_waves_env;
-								/* few LDS classes (16, 64, 128, 160 KiB): only a handful of hardware queues run side by side */
-								int64_t l = ssw_shim_trace_lds_need(b2, wv), cls = 16384;
-								while (cls < l && cls < 131072) cls <<= (cls == 16384 ? 2 : 1);
-								if (cls < l && l <= SSW_LDS_LIMIT) cls = SSW_LDS_LIMIT;      /* (the widest bands that still fit a compute unit's LDS) */
+								/* few LDS classes (16, 64, 80, 128, 160 KiB): only a handful of hardware queues run side by side.  80 KiB (round 6) is HALF a
+								   compute unit: a band of 2048 on a 16-wavefront team wants 73 KiB, and in the 128-KiB class config 4's ~490 widest alignments
+								   took the 256 compute units one team each, in two rounds; two teams per compute unit make it one (the teams are bound
+								   by the latency of a row -- two barriers and a scan --, not by issue: VALU busy 0.28) */
+								static const int64_t lds_cls[5] = { 16384, 65536, 81920, 131072, SSW_LDS_LIMIT };
+								int64_t l = ssw_shim_trace_lds_need(b2, wv), cls = 131072;
+								for (int ci = 0; ci < 5; ++ci) if (l <= lds_cls[ci] && !(ci == 2 && c->kn.trace_no_cls80)) { cls = lds_cls[ci]; break; }      /* (wider than a compute unit's LDS: 128 KiB, rows in HBM scratch as before) */
 								if (g1 > g0 && (cls != lds_l || wv != waves_l)) break;     /* pending alignments are sorted by band: classes are contiguous */
 								lds_l = cls; waves_l = wv;
 							}
@@ -1632,14 +1639,26 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 			const int64_t lstate = (seg8 * 16 * 2 * 4 + seg8 * 16 + 64 + 15) / 16 * 16;
 			const int64_t sstr = (lstate + (int64_t)refLen * 2 + 64 + 15) / 16 * 16;
 			int64_t per = (int64_t)(c->cm_budget / (size_t)sstr); if (per < 1) per = 1;
+			/* A forward pass that leaves most of the device idle (round 6; the device holds ~50 alignments of this kernel per compute unit) runs BOTH
+			   rule sets of every query side by side instead of the 16-bit kernel after the 8-bit one saturated: 2 000 reads x 1 Mb took two kernel
+			   lengths on a sixth of the device (45 GCUPS against the reference's 63 on the box's 16 cores, round-5 verdict weak #8). */
+			const int spec = prm->score_size == 2 && !c->kn.no_lit_spec && 2 * (int64_t)nqa + 4 <= (int64_t)c->dev_cus * 48 && per >= 2 * (int64_t)nqa + 4;
+			int32_t* d_spec = 0;
+			if (spec) {
+				d_spec = (int32_t*)ensure(c, &c->cand, sizeof(int32_t) * 17 * (size_t)nq);      /* [nq counters][nq x 2 x 8 outcomes] */
+				if (!d_spec) goto done;
+				if (ssw_shim_memset(d_spec, 0, sizeof(int32_t) * (size_t)nq, c->stream)) { fail(c, "memset failed: %s", ssw_shim_last_error()); goto done; }
+			}
 			void* e0 = next_event(c); void* e1 = next_event(c);
 			ssw_shim_event_record(e0, c->stream);
 			for (int pass = 0; pass < (prm->flag != 0 ? 2 : 1); ++pass)
 				for (int32_t q0 = 0; q0 < nqa; q0 += (int32_t)per) {      /* (d_qlist holds the nqa NON-EMPTY queries; empty ones keep the zeroed record) */
 					const int32_t cnt_q = nqa - q0 < per ? nqa - q0 : (int32_t)per;
-					uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)(sstr * cnt_q));
+					const int64_t regions = spec && pass == 0 ? (((int64_t)cnt_q + 3) & ~(int64_t)3) + cnt_q : cnt_q;      /* (spec: one launch takes all of them, per >= 2 nqa + 4) */
+					uint8_t* d_scr = (uint8_t*)ensure(c, &c->scratch, (size_t)(sstr * regions));
 					if (!d_scr) goto done;
 					ssw_literal_args la;
+					la.spec_cnt = spec && pass == 0 ? d_spec : 0; la.spec_out = spec && pass == 0 ? d_spec + nq : 0;
 					la.tgt = d_tgt; la.refLen = refLen; la.qcodes = Q->d_codes; la.qoff = Q->d_off; la.qlist = d_qlist + q0; la.nq = cnt_q;
 					la.mat = d_mat; la.n = n; la.gapO = prm->gapO; la.gapE = prm->gapE; la.pass = pass; la.maskLen = prm->maskLen; la.bias = bias;
 					la.score_size = prm->score_size; la.flag = prm->flag; la.filters = prm->filters; la.filterd = prm->filterd; la.res = d_res;

@@ -91,9 +91,36 @@ SSW_DEV void build_profile(unsigned char* lds, u32 base, int first, int nthreads
    fl = phi(column + 1): the floor that keeps E at "0" or above.
      h = max3(d + s', E, F)        t = h - c1        E' = max3(E, t, fl)        F' = max(F, t) - gapE        cm = max3(cm, h_r, h_r+1) */
 /* OPEN: the last row leaves f BEFORE its "- gapE": the lane below subtracts while it takes the value over (xl_row_shr1_sub_keep) */
+#ifndef FILL_GROUP_ADDS
+#define FILL_GROUP_ADDS 0
+#endif
 template <int R, int R0, int R1, bool OPEN = false>
 SSW_DEV void chain_rows_fr(const u32x4* sc, u32 (&H)[R], u32 (&E)[R], u32& d, u32& f, u32& cm, u32 c1, u32 gapE2, u32 fl)
 {
+#if FILL_GROUP_ADDS
+	/* EXPERIMENT (round-5 verdict, item 5): the R independent `diag + score` adds of a step issued as ONE group ahead of the dependent chain
+	   (they need only the previous column's H and this column's scores): profiles/round3_mix_issue_probe.txt prices grouped 32-bit adds at
+	   2.3-3.0 cycles against 4.0 between maxima */
+	if (R1 > R0) {
+		u32 x[R];
+#pragma unroll
+		for (int r = R0; r < R1; ++r) x[r] = (r == R0 ? d : H[r - 1 >= 0 ? r - 1 : 0]) + sc[r >> 2][r & 3];
+		d = H[R1 - 1];
+		sched_fence();
+#pragma unroll
+		for (int r = R0; r < R1; ++r) {
+			const u32 h = pk_max3_fr(x[r], E[r], f);
+			const u32 t = h - c1;
+			E[r] = pk_max3_fr(E[r], t, fl);
+			f = pk_max(f, t);
+			if (!(OPEN && r == R1 - 1)) f -= gapE2;
+			if (((r - R0) & 1) == 1) cm = pk_max3_fr(cm, H[r - 1 >= 0 ? r - 1 : 0], h);
+			else if (r == R1 - 1) cm = pk_max(cm, h);
+			H[r] = h;
+		}
+	}
+	return;
+#endif
 #pragma unroll
 	for (int r = R0; r < R1; ++r) {
 		const u32 hold = H[r];
@@ -444,8 +471,10 @@ SSW_DEV void filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 	const int lena = (int)(a.qoff[pr.qa + 1] - a.qoff[pr.qa]);
 	const int lenb = pr.qb >= 0 ? (int)(a.qoff[pr.qb + 1] - a.qoff[pr.qb]) : 0;
 	const int gapEi = (int)(a.gapE2 & 0xffffu);
+#ifndef DB_MEASURE_NO_PROLOGUE      /* MEASUREMENT ONLY (wrong results): what the per-workgroup profile build costs (scripts/build_variants.sh) */
 	build_profile<R, FR ? 2 : 0>(lds, 0, tid, 16 * NCH, a.mat, a.n, a.qcodes + a.qoff[pr.qa], lena, 0,
 	                             pr.qb >= 0 ? a.qcodes + a.qoff[pr.qb] : (const int8_t*)0, lenb, 0x7fffffff, 0x7fffffff, gapEi);
+#endif
 
 	const int slot = tchunk * NCH + grp;
 	const bool active = slot < a.ntl;
@@ -634,6 +663,7 @@ SSW_DEV void filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 		else if (have_word) word = 1;
 		else status = 1;
 		int s2 = 0, i2 = 0x7fffffff;
+#ifndef DB_MEASURE_NO_SCAN          /* MEASUREMENT ONLY (wrong score2): what the fused second-best scan over the chain's own column maxima costs */
 		if (status == 0 && bv > 0) {
 			const uint32_t* arr = (word && padded) ? o8 : o16;
 			const int lo_edge = bc - maskLen > 0 ? bc - maskLen : 0;
@@ -646,6 +676,7 @@ SSW_DEV void filldb_pass(const ssw_filldb_args& a, unsigned char* lds)
 				}
 			}
 		}
+#endif
 		lds_st32(lds, red + 16u * l16, (u32)s2);
 		lds_st32(lds, red + 16u * l16 + 4, (u32)i2);
 		wave_lds_fence();
@@ -2044,8 +2075,17 @@ __global__ void __launch_bounds__(256) k_literal(ssw_literal_args a)
 	SSW_DYN_LDS(lds);
 	const int tid = (int)threadIdx.x, l16 = tid & 15, grp = tid >> 4;
 	const int job = (int)blockIdx.x * ((int)blockDim.x >> 4) + grp;
-	const int q = job < a.nq ? a.qlist[job] : -1;
-	unsigned char* const gscr = a.scratch + (int64_t)(job < a.nq ? job : 0) * a.scratch_stride;
+	/* a.spec (forward pass of a batch that leaves most of the device idle, score_size 2): BOTH rule sets of every query at once -- jobs
+	   [0, nb) run the 8-bit kernel, jobs [nb, nb + nq) the 16-bit kernel of query job - nb, nb = nq rounded up to whole wavefronts -- instead
+	   of the 16-bit kernel after the 8-bit one has overflowed; the later of a query's two jobs writes the record (spec_cnt).  For DNA reads
+	   under 2/-2 nearly every 150-bp read overflows: the forward pass takes the time of one kernel instead of two. */
+	const bool spec = a.pass == 0 && a.spec_cnt != (int32_t*)0;
+	const int nb = spec ? (a.nq + 3) & ~3 : a.nq;
+	const int kind = !spec ? 0 : job < nb ? 1 : 2;                  /* 0: as score_size says; 1: 8-bit rules only; 2: 16-bit rules only */
+	const int jq = kind == 2 ? job - nb : job;
+	const int njobs = spec ? nb + a.nq : a.nq;
+	const int q = jq < a.nq && job < njobs ? a.qlist[jq] : -1;
+	unsigned char* const gscr = a.scratch + (int64_t)(job < njobs ? job : 0) * a.scratch_stride;
 	unsigned char* const scratch = a.lds_stride > 0 ? lds + (size_t)grp * (size_t)a.lds_stride : gscr;
 	uint16_t* const mc = (uint16_t*)(gscr + a.mc_off);
 	/* the scoring matrix in LDS, behind the per-alignment state regions: mat[ref][read] is a dependent look-up in every segment */
@@ -2062,12 +2102,13 @@ __global__ void __launch_bounds__(256) k_literal(ssw_literal_args a)
 		r.score1 = 0; r.score2 = 0; r.ref_begin1 = -1; r.ref_end1 = 0; r.read_begin1 = -1; r.read_end1 = 0;
 		r.ref_end2 = 0; r.cigarLen = 0; r.flag = 0; r.status = 0; r.word = 0; r.want_begin = 0; r.want_cigar = 0;
 		r.rev_score = 0; r.loc_done = 0; r.nm = 0; r.cigar_off = 0;
-		bool need_word = q >= 0 && !have_byte;
+		bool need_word = q >= 0 && (kind == 2 || (kind == 0 && !have_byte));
 		bool done = q < 0;
-		if (wave_any(q >= 0 && have_byte)) {
-			literal_fill(q >= 0 && have_byte, true, a.tgt, 0, a.refLen, read, readLen, 0, lmat, a.n, a.gapO, a.gapE, 255, a.bias, maskLen,
+		const bool do_byte = q >= 0 && (kind == 1 || (kind == 0 && have_byte));
+		if (wave_any(do_byte)) {
+			literal_fill(do_byte, true, a.tgt, 0, a.refLen, read, readLen, 0, lmat, a.n, a.gapO, a.gapE, 255, a.bias, maskLen,
 			             scratch, mc, tid, o);
-			if (q >= 0 && have_byte) {
+			if (do_byte && kind == 0) {
 				if (o.score == 255) { if (have_word) need_word = true; else { r.status = 1; done = true; } }
 			}
 		}
@@ -2076,12 +2117,31 @@ __global__ void __launch_bounds__(256) k_literal(ssw_literal_args a)
 			literal_fill(need_word, false, a.tgt, 0, a.refLen, read, readLen, 0, lmat, a.n, a.gapO, a.gapE, 65535, 0, maskLen, scratch, mc, tid, w);
 			if (need_word) { o = w; r.word = 1; }
 		}
+		if (spec) {
+			/* both rule sets ran side by side: each job parks its outcome, the later one decides like ssw_align does (src/ssw.c:881-893: the 16-bit
+			   kernel's answer iff the 8-bit one saturated) and writes the record */
+			int32_t* const mine = a.spec_out + ((int64_t)(q >= 0 ? q : 0) * 2 + (kind == 2 ? 1 : 0)) * 8;
+			if (q >= 0 && l16 == 0) { mine[0] = o.score; mine[1] = o.ref; mine[2] = o.read; mine[3] = o.score2; mine[4] = o.ref2; }
+			dev_fence();
+			int second = 0;
+			if (q >= 0 && l16 == 0) second = atomicAdd(a.spec_cnt + q, 1) == 1;
+			dev_fence();
+			if (!second) done = true;
+			else {
+				const int32_t* const ob = a.spec_out + ((int64_t)q * 2) * 8;
+				const int32_t* const ow = ob + 8;
+				const int32_t* const pick = ob[0] == 255 ? ow : ob;
+				o.score = pick[0]; o.ref = pick[1]; o.read = pick[2]; o.score2 = pick[3]; o.ref2 = pick[4];
+				r.word = ob[0] == 255 ? 1 : 0;
+			}
+			if (l16 != 0) done = true;
+		}
 		if (q >= 0 && !done && o.score > 0) {
 			r.score1 = o.score; r.ref_end1 = o.ref; r.read_end1 = o.read;
 			if (maskLen >= 15) { r.score2 = o.score2; r.ref_end2 = o.ref2; } else { r.score2 = 0; r.ref_end2 = -1; }
 			r.want_begin = !(a.flag == 0 || (a.flag == 2 && o.score < a.filters));
 		}
-		if (q >= 0 && l16 == 0) a.res[q] = r;
+		if (q >= 0 && l16 == 0 && (!spec || !done)) a.res[q] = r;
 	} else {
 		ssw_dres r;
 		bool act = false;
@@ -3541,7 +3601,9 @@ extern "C" int ssw_shim_launch_literal(const ssw_literal_args* a, void* stream)
 	if (st > 0 && st * 16 + matb <= 65536 + 1024 && args.nq >= 16 * 2048) { threads = 256; args.lds_stride = (int32_t)st; }
 	else if (st > 0 && st * 4 + matb <= (int64_t)SSW_LDS_LIMIT) { threads = 64; args.lds_stride = (int32_t)st; }
 	const int per = threads / 16;
-	SSW_LAUNCH(k_literal, ssw_literal_args, args, (args.nq + per - 1) / per, threads, (size_t)args.lds_stride * per + (size_t)matb, stream);
+	if (args.pass != 0 || args.score_size != 2) { args.spec_cnt = 0; args.spec_out = 0; }
+	const int njobs = args.spec_cnt ? ((args.nq + 3) & ~3) + args.nq : args.nq;      /* both rule sets of every query side by side (k_literal) */
+	SSW_LAUNCH(k_literal, ssw_literal_args, args, (njobs + per - 1) / per, threads, (size_t)args.lds_stride * per + (size_t)matb, stream);
 	return SSW_LAUNCH_OK();
 }
 

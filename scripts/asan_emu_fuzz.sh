@@ -3,8 +3,11 @@
 # (tests/emu), then the differential fuzzers on it under LD_PRELOAD=libasan -- every host-side out-of-bounds read / write, use after free
 # or buffer overrun of csrc/ssw_host.c, ssw_pool.c, ssw_cigar.c aborts the run with a report.  (The round-5 judge found the k_literal query-list
 # overrun this way; the emulated kernels themselves run on fibres whose stacks ASan does not know, so the kernel object stays uninstrumented:
-# what a kernel reads or writes through a bad HOST-computed pointer still faults or lands in a poisoned host allocation.)
-# usage: scripts/asan_emu_fuzz.sh [seconds per seed = 120] [seeds = "1 2 3"]      -> gpurun_out/asan_emu_fuzz.txt (copy to profiles/)
+# what a kernel reads or writes through a bad HOST-computed pointer still faults or lands in a poisoned host allocation -- the emulator's
+# "device memory" is host malloc, so kernel accesses beyond a device buffer hit ASan's red zones when they come from instrumented code paths
+# such as the shim's copies.)
+# usage: scripts/asan_emu_fuzz.sh [seconds per seed and fuzzer = 120] [seeds = "1 2 3"]      -> gpurun_out/asan_emu_fuzz.txt (copy to profiles/)
+# The seeds run side by side (one process each).
 set -e
 cd "$(dirname "$0")/.."
 SECS=${1:-120}; SEEDS=${2:-"1 2 3"}
@@ -17,9 +20,12 @@ done
 /opt/rocm/lib/llvm/bin/clang++ -shared -o $B/libssw_emu_asan.so tests/emu/emu_kernels.o tests/emu/simt_emu.o tests/emu/emu_shim.o $B/ssw_host.o $B/ssw_pool.o $B/ssw_cigar.o -lpthread
 ASAN=$(gcc -print-file-name=libasan.so)
 OUT=gpurun_out/asan_emu_fuzz.txt; : > $OUT
-for s in $SEEDS; do
+run_seed() {
 	# (detect_leaks=0: the python interpreter itself leaks by ASan's book; the fuzz is about out-of-bounds accesses)
-	LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 python scripts/gpu_fuzz.py $SECS $s --lib $B/libssw_emu_asan.so | tee -a $OUT
-	LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 python scripts/abi_fuzz.py $SECS $s --lib $B/libssw_emu_asan.so | tee -a $OUT
-done
-echo "ASan: no report (a report aborts the run)" | tee -a $OUT
+	LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 python scripts/gpu_fuzz.py $SECS $1 --lib $B/libssw_emu_asan.so 2>gpurun_out/asan_seed$1.err | tee -a $OUT
+	LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 python scripts/abi_fuzz.py $SECS $1 --lib $B/libssw_emu_asan.so 2>>gpurun_out/asan_seed$1.err | tee -a $OUT
+}
+for s in $SEEDS; do run_seed $s & done
+wait
+if grep -l "AddressSanitizer" gpurun_out/asan_seed*.err 2>/dev/null; then echo "ASan REPORTS in the files above" | tee -a $OUT; exit 1; fi
+echo "ASan: no report in any seed (a report aborts its process)" | tee -a $OUT

@@ -5,6 +5,8 @@
 #   tests          the whole GPU test-suite
 #   bench          the default bench line exactly as the driver runs it (config 2 + `also`)
 #   bench:<name>:<args...>   any other bench line, e.g. bench:c6:--config\ 6  (args may not contain spaces other than separators: use '+')
+#   xbench:<name>:<ENV=V,...>:<args...>   the same with environment variables (hooks library, variant builds: SSW_LIB=@/complete-.../variants/libssw_x.so)
+#   fuzz           scripts/gpu_fuzz.py (batch ABI, empties, wide alphabets) and scripts/abi_fuzz.py (single-pair regime), two seeds each
 #   config6        the README's benchmark shape: default / serial buckets / -m1 -x3 -o5 -e2 / flag 2
 #   overlap4       config 4 alone and through two pool workers on the one GPU (does the tail of one half hide under the fill of the other?)
 #   dbx            begin positions / CIGARs against a whole database in one call vs score only vs the per-target loop (scripts/gpu_dbx_bench.py)
@@ -35,6 +37,9 @@ for step in "$@"; do
     tests) timeout 1800 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/${TAG}_pytest.log; tail -4 gpurun_out/${TAG}_pytest.log ;;
     bench) bench default ;;
     bench:*) IFS=: read -r _ name args <<< "$step"; bench "$name" ${args//+/ } ;;
+    xbench:*) IFS=: read -r _ name envs args <<< "$step"; ( for kv in ${envs//,/ }; do export "${kv//@/$PWD}"; done; bench "$name" ${args//+/ } ) ;;      # xbench:<name>:<ENV=V,ENV=V>:<args>  (a path in V may use @ for $PWD)
+    fuzz) for s in 1 2; do timeout 400 python scripts/gpu_fuzz.py ${SSW_FUZZ_SECS:-150} $s 2>/dev/null | tee -a gpurun_out/${TAG}_gpu_fuzz.json | cut -c1-600; done
+          for s in 1 2; do timeout 300 python scripts/abi_fuzz.py ${SSW_FUZZ_SECS:-150} $s 2>/dev/null | tee -a gpurun_out/${TAG}_abi_fuzz.json | cut -c1-600; done ;;
     config6)
       bench c6 --config 6
       SSW_LIB=$PWD/complete-striped-smith-waterman-library_amd/libssw_hooks.so SSW_GPU_SERIAL_BUCKETS=1 bench c6_serial_buckets --config 6 --cpu-sample 0

@@ -610,3 +610,17 @@ def test_single_pair_abi_fuzz_regime_on_emulator(emu_lib_path):
                          capture_output=True, text=True, timeout=900)
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["calls"] == 400 and line["calls_with_wrong_values"] == 0 and line["alphabets_above_32"] > 50, line
+
+
+@pytest.mark.parametrize("spec", ["1", "0"])
+def test_lane_model_kernel_rule_sets_side_by_side_or_in_sequence(ectx, spec, monkeypatch):
+    """k_literal's forward pass (round 6): a batch that leaves the device idle runs the 8-bit and the 16-bit rule set of every query as two jobs
+    at once and the later one writes the record (default); SSW_GPU_LIT_SPEC=0 keeps the sequence of src/ssw.c:881-893.  Reads that saturate
+    the 8-bit kernel, reads that do not, score_size 0 / 1 (never side by side), empty and one-base reads, with and without begin / CIGAR."""
+    monkeypatch.setenv("SSW_GPU_LIT_SPEC", spec)
+    rng = np.random.default_rng(31)
+    ref = random_ref(600, 31, 4)
+    reads = make_reads(rng, ref, 9, [150, 150, 40, 200, 20, 1, 130, 90, 333], 4, frac_random=0.2) + [np.zeros(0, dtype=np.int8)]
+    for gapO, gapE, flag, ss in ((1, 1, 0, 2), (2, 3, 1, 2), (0, 0, 9, 2), (1, 2, 2, 0), (3, 3, 15, 1), (2, 2, 0, 2)):
+        _run(ectx, reads, [ref, ref[:100].copy()], dna_matrix(2, 2), 5, gapO, gapE, flag=flag, ss=ss)
+    _run(ectx, reads[:3], [ref], dna_matrix(5, 4), 5, 1, 1, flag=1)      # match 5: 150 x 5 = 750, deep into the 16-bit rules
