@@ -357,6 +357,7 @@ int   ssw_shim_device_count(void);
 int   ssw_shim_set_device(int dev);
 const char* ssw_shim_last_error(void);
 void* ssw_shim_stream_create(void);
+void* ssw_shim_stream_create_low(void);      /* lowest dispatch priority the device offers */
 void  ssw_shim_stream_destroy(void* stream);
 int   ssw_shim_stream_sync(void* stream);
 void* ssw_shim_malloc(size_t bytes);

@@ -60,6 +60,7 @@ typedef struct {
 	int trace_waves;        /* SSW_GPU_TRACE_WAVES=1/4/16: team size; 0: by band width */
 	int trace_unblocked;    /* SSW_GPU_TRACE_BLOCKED=0: teams with one cell per thread */
 	int trace_many;         /* SSW_GPU_TRACE_MANY=<n>: a traceback round with more than n pending alignments sizes its teams for throughput (tests: 0); default 4096 */
+	int no_pipe;            /* SSW_GPU_PIPE=0: the launches of a chunked short-query bucket one after the other on the main stream (the form before round 6) */
 	int no_lit_spec;        /* SSW_GPU_LIT_SPEC=0: the lane-model kernel runs its 16-bit rules after the 8-bit ones (never both side by side: the form before round 6) */
 	int trace_no_cls80;     /* SSW_GPU_TRACE_CLS80=0: no 80-KiB LDS class for the traceback teams (the classes before round 6) */
 	int trace_diag;         /* SSW_GPU_TRACE_DIAG=1: the anti-diagonal narrow-band kernel (k_trace_diag, four alignments per wavefront) in front of the row
@@ -81,6 +82,7 @@ struct ssw_gpu_ctx {
 	int device;
 	void* stream;
 	void* stream2;                      /* reductions of chunk i overlap the fill of chunk i+1 */
+	void* pstream;                      /* lowest dispatch priority: the odd launches of a pipelined series of fills (align_batch "pipe"), created with the first such series */
 	void* ustream;                      /* sequence uploads / translation (ssw_gpu_seqs_*): beside a running batch call, see upload_stream() */
 	void* tstream[SSW_TSTREAMS]; void* tev[SSW_TSTREAMS];   /* traceback classes of one negotiation round run side by side */
 	void *ev_fill[2], *ev_red[2];
@@ -157,6 +159,7 @@ static void knobs_load(ssw_knobs* k)
 	k->no_band = env_is("SSW_GPU_NO_BAND", '1');
 	k->trace_no_cls80 = env_is("SSW_GPU_TRACE_CLS80", '0');
 	k->no_lit_spec = env_is("SSW_GPU_LIT_SPEC", '0');
+	k->no_pipe = env_is("SSW_GPU_PIPE", '0');
 	k->no_tail = env_is("SSW_GPU_NO_TAIL", '1');
 	{ const int v = env_int("SSW_GPU_DB_TSUB", 0); k->db_tsub = v > 0 ? v : 0; }
 	{ const int v = env_int("SSW_GPU_DBX_SLAB", 0); k->dbx_slab = v > 0 ? v : 0; }
@@ -313,7 +316,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
 	ssw_shim_event_destroy(c->ev_c); ssw_shim_event_destroy(c->ev_d); ssw_shim_event_destroy(c->ev_db);
 	for (int i = 0; i < 2; ++i) { ssw_shim_event_destroy(c->ev_fill[i]); ssw_shim_event_destroy(c->ev_red[i]); }
-	ssw_shim_stream_destroy(c->stream2); ssw_shim_stream_destroy(c->ustream);
+	ssw_shim_stream_destroy(c->stream2); ssw_shim_stream_destroy(c->ustream); ssw_shim_stream_destroy(c->pstream);
 	for (int i = 0; i < SSW_TSTREAMS; ++i) { ssw_shim_stream_destroy(c->tstream[i]); ssw_shim_event_destroy(c->tev[i]); }
 	ssw_shim_stream_destroy(c->stream);
 	pthread_mutex_destroy(&c->mu);
@@ -510,6 +513,7 @@ typedef struct { int32_t R, strips, P16, lanes, use_x; int32_t first_pair, npair
    fit the budget together run side by side on the side streams, each in its own slice of the scratch buffers) */
 typedef struct {
 	int active, dbl, seg;
+	int pipe;                               /* the bucket's launches alternate between the main stream and a low-priority one, each with its own half of the scratch (below) */
 	int32_t tile, halo, ntiles;
 	int64_t maxcols, chunk;
 	size_t cm_bytes, sg_bytes, bnd_bytes, cand_bytes, q_ints, cs_ints;      /* scratch of one launch */
@@ -1750,7 +1754,16 @@ plan_again:
 				/* measured on MI355X (config 2): overlapping costs more than it saves -- the fill runs at ~100 % VALU issue, so the
 				   reduction's waves only take slots from it (2347 ms/step with, 2160 ms without); kept as an opt-in experiment */
 				const int dbl = !use_x && chunk < B->npairs && c->kn.overlap;
-				if (dbl) chunk = (int64_t)((c->cm_budget / 2) / (size_t)per_pair);
+				/* Pipelined launches (round 6).  A bucket that needs several launches -- its column maxima do not fit the budget at once -- used to
+				   run them one after the other on one stream, and every launch ended with a last, partly filled round of workgroups: all
+				   workgroups of a launch take the same ~50 ms (config 2), so the device drains for most of a workgroup's duration at two or three
+				   workgroups per compute unit instead of seven -- three times per 100 000 reads at a whole-HBM budget, 25 times at 16 GiB (-4 %).
+				   Now the launches alternate between the main stream and a stream of the LOWEST dispatch priority, each with its own half of
+				   the scratch: the command processor hands out the low-priority launch's workgroups only where the other launch has none
+				   left to hand out -- it fills the drain of its predecessor and is overtaken again by its successor.  Same work, same
+				   records; only the order in which workgroups reach the compute units changes. */
+				const int pipe = !use_x && !dbl && chunk < B->npairs && !c->kn.no_pipe;
+				if (dbl || pipe) chunk = (int64_t)((c->cm_budget / 2) / (size_t)per_pair);
 				if (chunk < 1) chunk = 1;
 				if (chunk > B->npairs) chunk = B->npairs;
 				if (!use_x && chunk < B->npairs) {
@@ -1766,10 +1779,10 @@ plan_again:
 					if (even <= chunk) chunk = even;
 					else if (chunk >= unit) chunk = chunk / unit * unit;
 				}
-				P->tile = tile; P->halo = halo; P->ntiles = ntiles; P->maxcols = maxcols; P->chunk = chunk; P->dbl = dbl;
+				P->tile = tile; P->halo = halo; P->ntiles = ntiles; P->maxcols = maxcols; P->chunk = chunk; P->dbl = dbl; P->pipe = pipe && chunk < B->npairs;
 				P->seg = !dbl && !c->kn.no_seg_reduce ;      /* the fill kernels also leave the maxima of 16-column groups, which is all the reduction reads */
-				P->cm_bytes = ALIGN16(4 * stride * chunk);
-				P->sg_bytes = P->seg ? ALIGN16(4 * seg_stride * chunk) : 0;
+				P->cm_bytes = ALIGN16(4 * stride * chunk) * (P->pipe ? 2 : 1);      /* (pipe: two sets, one per stream) */
+				P->sg_bytes = P->seg ? ALIGN16(4 * seg_stride * chunk) * (P->pipe ? 2 : 1) : 0;
 				P->bnd_bytes = use_x ? ALIGN16(16 * maxcols * ntiles * chunk) : 0;
 				P->cand_bytes = use_x ? ALIGN16(32 * ntiles * chunk) : 0;   /* 2 halves x 4 ints per job */
 				if (use_x && B->lanes == 64) { P->q_ints = chainq_queue_ints(chunk * ntiles * B->strips); P->cs_ints = chainq_cands_ints(chunk * ntiles * B->strips); }
@@ -1863,10 +1876,26 @@ plan_again:
 				uint32_t* d_cmB16 = dbl ? (uint32_t*)base_cmB16 : d_cmA16; uint32_t* d_cmB8 = dbl ? (uint32_t*)base_cmB8 : d_cmA8;
 				uint32_t* d_sg16 = P->seg ? (uint32_t*)(base_sg16 + P->sg_off) : 0; uint32_t* d_sg8 = P->seg ? (uint32_t*)(base_sg8 + P->sg_off) : 0;
 				int launch_i = 0;
+				const int pipe = P->pipe && !conc;
+				void *pe0 = 0, *pe1 = 0;
+				if (pipe) {
+					if (!c->pstream) c->pstream = ssw_shim_stream_create_low();
+					if (!c->pstream) { fail(c, "stream creation failed: %s", ssw_shim_last_error()); goto done; }
+					pe0 = next_event(c); pe1 = next_event(c);
+					/* (the low-priority stream starts after everything the main stream has queued so far: the call's uploads, the record memset) */
+					if (ssw_shim_event_record(pe0, c->stream) || ssw_shim_stream_wait_event(c->pstream, pe0)) { fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; }
+					d_cmB16 = (uint32_t*)((unsigned char*)d_cmA16 + P->cm_bytes / 2); d_cmB8 = (uint32_t*)((unsigned char*)d_cmA8 + P->cm_bytes / 2);
+				}
+				uint32_t* const d_sgA16 = d_sg16; uint32_t* const d_sgA8 = d_sg8;
 				for (int32_t p0 = 0; p0 < B->npairs; p0 += (int32_t)chunk, ++launch_i) {
 					const int32_t np = B->npairs - p0 < chunk ? B->npairs - p0 : (int32_t)chunk;
-					const int bi = dbl ? (launch_i & 1) : 0;
+					const int bi = dbl || pipe ? (launch_i & 1) : 0;
 					uint32_t* d_cm16 = bi ? d_cmB16 : d_cmA16; uint32_t* d_cm8 = bi ? d_cmB8 : d_cmA8;
+					if (pipe) {      /* odd launches: the other half of the scratch, the low-priority stream (in order on it: launch i + 2 follows the reduction of launch i) */
+						st = bi ? c->pstream : c->stream;
+						d_sg16 = P->seg ? (uint32_t*)((unsigned char*)d_sgA16 + (bi ? P->sg_bytes / 2 : 0)) : 0;
+						d_sg8 = P->seg ? (uint32_t*)((unsigned char*)d_sgA8 + (bi ? P->sg_bytes / 2 : 0)) : 0;
+					}
 					if (dbl && launch_i >= 2) ssw_shim_stream_wait_event(c->stream, c->ev_red[bi]);    /* the buffer set is free again */
 					ssw_fill_args fa;
 					fa.tgt = d_tgt; fa.refLen = refLen; fa.qcodes = Q->d_codes; fa.qoff = Q->d_off;
@@ -1883,7 +1912,7 @@ plan_again:
 					if (fill_form != 0 && B->lanes == 64 &&
 					    ssw_frame_params(&c->kn, (int64_t)B->P16 * (maxmat > 0 ? maxmat : 0), prm->gapO, prm->gapE, minmat, 64, &xfr_base, &xfr_kmask)) xform = 3;
 					void *e0 = 0, *e1 = 0;
-					if (!conc) { e0 = next_event(c); e1 = next_event(c); ssw_shim_event_record(e0, st); }
+					if (!conc && !pipe) { e0 = next_event(c); e1 = next_event(c); ssw_shim_event_record(e0, st); }
 					if (use_x) {
 						ssw_chainx_args xa; memset(&xa, 0, sizeof xa);
 						xa.tgt = d_tgt; xa.refLen = refLen; xa.qcodes = Q->d_codes; xa.qoff = Q->d_off; xa.mat = d_mat; xa.n = n;
@@ -1907,7 +1936,8 @@ plan_again:
 						defer[ndefer].fa = fa; defer[ndefer].R = B->R; defer[ndefer].wgs = (int64_t)np * fa.bpp; defer[ndefer].group = ssw_shim_fill_class(B->R) * 2 + (fa.form == 3);
 					} else
 					if (ssw_shim_launch_fill(B->R, &fa, st)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
-					if (!conc) { ssw_shim_event_record(e1, st); c->tm.fill_launches++; }
+					if (!conc && !pipe) ssw_shim_event_record(e1, st);      /* (pipe: one event pair around the whole series, below -- the launches overlap) */
+					if (!conc) c->tm.fill_launches++;
 					{
 						int64_t cols = 0;
 						for (int32_t k = 0; k < ntiles; ++k) {
@@ -1942,6 +1972,12 @@ plan_again:
 				if (dbl) {   /* everything later on the main stream sees all records of this bucket */
 					ssw_shim_stream_wait_event(c->stream, c->ev_red[0]);
 					if (launch_i > 1) ssw_shim_stream_wait_event(c->stream, c->ev_red[1]);
+				}
+				if (pipe) {   /* the main stream continues after the low-priority stream's last reduction; the series is timed as one (its reductions included: ~0.1 ms each) */
+					if (ssw_shim_event_record(c->ev_red[1], c->pstream) || ssw_shim_stream_wait_event(c->stream, c->ev_red[1]) || ssw_shim_event_record(pe1, c->stream)) {
+						fail(c, "stream join failed: %s", ssw_shim_last_error()); goto done;
+					}
+					st = c->stream;
 				}
 			}
 			if (conc && pass_x == 0 && ndefer > 0) {

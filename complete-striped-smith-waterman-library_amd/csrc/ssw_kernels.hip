@@ -3697,6 +3697,16 @@ extern "C" void* ssw_shim_stream_create(void)
 	if (shim_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return 0;
 	return (void*)s;
 }
+/* a stream whose kernels the command processor dispatches only when the normal-priority queues have nothing to dispatch (the filler of a
+   pipelined series of fill launches: ssw_host.c "pipe") */
+extern "C" void* ssw_shim_stream_create_low(void)
+{
+	hipStream_t s = 0;
+	int least = 0, greatest = 0;
+	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = 0; (void)hipGetLastError(); }
+	if (shim_check(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least), "hipStreamCreateWithPriority")) return 0;
+	return (void*)s;
+}
 extern "C" void ssw_shim_stream_destroy(void* s) { if (s) (void)hipStreamDestroy((hipStream_t)s); }
 extern "C" int ssw_shim_stream_sync(void* s) { return shim_check(hipStreamSynchronize((hipStream_t)s), "hipStreamSynchronize"); }
 extern "C" void* ssw_shim_malloc(size_t bytes)

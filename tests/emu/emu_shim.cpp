@@ -16,6 +16,7 @@ int ssw_shim_device_count(void) { const char* e = getenv("SSW_EMU_DEVICES"); con
 int ssw_shim_set_device(int) { return 0; }
 const char* ssw_shim_last_error(void) { return "emulator"; }
 void* ssw_shim_stream_create(void) { return (void*)1; }
+void* ssw_shim_stream_create_low(void) { return (void*)1; }
 void ssw_shim_stream_destroy(void*) {}
 int ssw_shim_stream_sync(void*) { return 0; }
 /* SSW_EMU_MALLOC_LIMIT_MB=<n>: a single device allocation above n MiB fails (the out-of-memory path of the host driver: SSW_ALLOC_RETRY) */
