@@ -341,7 +341,7 @@ def bench_dna(args, world, rank, local_rank, dist):
         step()
     barrier()
     t0 = time.perf_counter()
-    acc = {"fill_ms": 0.0, "fill_launches": 0, "fill_cells": 0, "reduce_ms": 0.0, "locate_ms": 0.0, "trace_ms": 0.0, "total_ms": 0.0}
+    acc = {"fill_ms": 0.0, "fill_launches": 0, "fill_cells": 0, "reduce_ms": 0.0, "locate_ms": 0.0, "trace_ms": 0.0, "total_ms": 0.0, "fill_pipelined": 0}
     res = cig = None
     tm = None
     for _ in range(args.steps):
@@ -473,6 +473,11 @@ def bench_dna(args, world, rank, local_rank, dist):
                                "frac_of_isa_ideal": round(real / VALU_PEAK_LANEOPS * ideal, 4),
                                "measured_peak_probe": round(probe / 1e12, 2), "ops_per_pair_row": ops,
                                "launch_ms": round(launch_ms, 3), "launches": int(acc["fill_launches"]),
+                               "launches_pipelined": int(acc.get("fill_pipelined", 0)),
+                               "launch_note": ("the %d fill launches of a step overlap (pipelined series: main stream / lowest-priority stream alternately, each with half of the scratch): "
+                                               "launch_ms = the HIP-event bracket around the series / launches; a rocprofv3 trace shows LONGER kernel durations (a low-priority launch "
+                                               "waits, dispatched, while its neighbours have workgroups to hand out) -- compare with union_ns of profiles/*_kernel_stats.csv"
+                                               % (acc["fill_launches"] // max(1, args.steps))) if acc.get("fill_pipelined", 0) else "serial launches: launch_ms is the kernel's average duration",
                                "fill_gcups_padded": round(acc["fill_cells"] / fill_s / 1e9, 1) if fill_s > 0 else 0.0,
                                "peak_note": "integer max-plus recurrence: neither MFMA nor HBM binds, the issue of vector instructions does.  `achieved` = readLen x refLen cells "
                                             "x %.1f recurrence instructions per row of a query pair / 2 / fill time; `peak` = one wave64 instruction per 4 cycles and SIMD = 256 CU x 4 SIMD "
@@ -619,7 +624,7 @@ def bench_config3_full(args, world, rank, local_rank, dist):
             align(resident[mine[0]])
     if dist is not None:
         dist.barrier()
-    acc = {"fill_ms": 0.0, "fill_launches": 0, "fill_cells": 0, "reduce_ms": 0.0, "locate_ms": 0.0, "trace_ms": 0.0, "total_ms": 0.0, "n_word": 0, "n_byte": 0}
+    acc = {"fill_ms": 0.0, "fill_launches": 0, "fill_cells": 0, "reduce_ms": 0.0, "locate_ms": 0.0, "trace_ms": 0.0, "total_ms": 0.0, "n_word": 0, "n_byte": 0, "fill_pipelined": 0}
     results = {}
     tm = None
     t0 = time.perf_counter()

@@ -1937,7 +1937,7 @@ plan_again:
 					} else
 					if (ssw_shim_launch_fill(B->R, &fa, st)) { fail(c, "fill launch failed: %s", ssw_shim_last_error()); goto done; }
 					if (!conc && !pipe) ssw_shim_event_record(e1, st);      /* (pipe: one event pair around the whole series, below -- the launches overlap) */
-					if (!conc) c->tm.fill_launches++;
+					if (!conc) { c->tm.fill_launches++; if (pipe) c->tm.fill_pipelined++; }
 					{
 						int64_t cols = 0;
 						for (int32_t k = 0; k < ntiles; ++k) {

@@ -50,7 +50,7 @@ class Timing(C.Structure):
                 ("fill_cells", C.c_int64), ("cells", C.c_int64), ("reduce_ms", C.c_double), ("locate_ms", C.c_double),
                 ("trace_ms", C.c_double), ("n_word", C.c_int64), ("n_byte", C.c_int64), ("fill_kernel", C.c_char * 48),
                 ("fill_ops_per_row", C.c_double), ("fill_rows_per_lane", C.c_int32), ("fill_strips", C.c_int32),
-                ("db_repeats", C.c_int64)]
+                ("db_repeats", C.c_int64), ("fill_pipelined", C.c_int64)]
 
 
 HIT_DTYPE = np.dtype([("score1", "<u2"), ("score2", "<u2"), ("ref_end1", "<i4"), ("read_end1", "<i4"), ("ref_end2", "<i4")], align=True)

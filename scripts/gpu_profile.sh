@@ -4,7 +4,7 @@
 #   per counter group, no tracing domains next to --pmc) on reduced batches of configs 2 and 5 and on config 4 at full size
 #   usage: bash scripts/gpu_profile.sh [round-name, default round4]
 cd "${GRAFT_REPO_ROOT:-.}"
-ROUND=${1:-round5}
+ROUND=${1:-round6}
 export TMPDIR=/tmp
 P=$PWD/gpurun_out/prof
 rm -rf $P; mkdir -p $P

@@ -54,7 +54,8 @@ for step in "$@"; do
       bench literal_2k --reads 2000 --gap-open 1 --gap-extend 1 --steps 1 --warmup 1 --cpu-sample 200 --also none
       bench literal_20k --reads 20000 --gap-open 1 --gap-extend 1 --steps 1 --warmup 1 --cpu-sample 200 --also none ;;
     dropin) timeout 600 python scripts/gpu_dropin_cli.py > gpurun_out/${TAG}_dropin_cli.log 2>&1; tail -c 2500 gpurun_out/${TAG}_dropin_cli.log ;;
-    profile) bash scripts/gpu_profile.sh > gpurun_out/${TAG}_profile.log 2>&1; tail -6 gpurun_out/${TAG}_profile.log ;;
+    profile) bash scripts/gpu_profile.sh ${SSW_PROFILE_ROUND:-round6} > gpurun_out/${TAG}_profile.log 2>&1; tail -6 gpurun_out/${TAG}_profile.log ;;
+    timeline:*) IFS=: read -r _ name args <<< "$step"; bash scripts/gpu_trace_timeline.sh "$name" ${args//+/ } > gpurun_out/${TAG}_timeline_$name.log 2>&1; tail -3 gpurun_out/${TAG}_timeline_$name.log ;;
     *) echo "unknown step $step" ;;
   esac
 done

@@ -29,11 +29,28 @@ for cfg in (2, 4, 5, 6):
         rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), max(sgpr_count), "
                           "max(lds_size), max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
         tot = sum(r[2] for r in rows) or 1
+        # round 6: launches of one kernel may OVERLAP (the pipelined fill series of ssw_host.c: a low-priority launch waits, dispatched, while its
+        # predecessor and successor have workgroups to hand out -- its duration is not its service time).  union_ns = the wall time during which
+        # at least one dispatch of the kernel was running: for serial launches it equals total_ns, for a pipelined series it is the series' length.
+        cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+        union = {}
+        if "start" in cols and "end" in cols:
+            for name, in db.execute("select distinct name from kernels"):
+                iv = sorted(db.execute("select start, end from kernels where name = ?", (name,)).fetchall())
+                u = 0; cs, ce = None, None
+                for a_, b_ in iv:
+                    if cs is None: cs, ce = a_, b_
+                    elif a_ <= ce: ce = max(ce, b_)
+                    else: u += ce - cs; cs, ce = a_, b_
+                if cs is not None: u += ce - cs
+                union[name] = u
         with open(os.path.join(out_dir, ROUND + "_config%d_kernel_stats.csv" % cfg), "w") as f:
             f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --config %d --steps 1 --warmup %d --cpu-sample 0 [--also none] --plain   (durations in ns; vgpr = the trace record's arch_vgpr field, NOT the allocation: the code objects say 72 for k_fill<10,frame>)\n" % (cfg, 0 if cfg == 5 else 1))
-            f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent,vgpr,sgpr,lds_bytes,max_grid_x,workgroup_x\n")
+            f.write("# union_ns: wall time with at least one dispatch of the kernel running.  The fill launches of a bucket that needs several of them are PIPELINED since round 6 (main stream / lowest-priority\n")
+            f.write("# stream alternately): their durations overlap, total_ns and avg_ns count waiting -- union_ns / passes over the batch is the fill time bench.py brackets with HIP events (roofline.launch_ms x launches).\n")
+            f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent,vgpr,sgpr,lds_bytes,max_grid_x,workgroup_x,union_ns\n")
             for r in rows:
-                f.write("\"%s\",%d,%d,%.0f,%d,%d,%.3f,%d,%d,%d,%d,%d\n" % (r[0], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot, r[6], r[7], r[8], r[9], r[10]))
+                f.write("\"%s\",%d,%d,%.0f,%d,%d,%.3f,%d,%d,%d,%d,%d,%d\n" % (r[0], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot, r[6], r[7], r[8], r[9], r[10], union.get(r[0], r[2])))
         print(open(os.path.join(out_dir, ROUND + "_config%d_kernel_stats.csv" % cfg)).read()[:1500])
 
 import bench      # noqa: E402  (kernel_source_id: the hash over ssw_kernels.hip + lanes.h + ssw_dev.h that bench.py compares)
