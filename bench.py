@@ -51,7 +51,7 @@ VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9    # packed 16-bit (VOP3P) instructions
 FULL = os.path.join(ROOT, "tests", "golden", "full")
 CSRC = os.path.join(ROOT, "complete-striped-smith-waterman-library_amd", "csrc")
 KERNEL_SRCS = [os.path.join(CSRC, f) for f in ("ssw_kernels.hip", "lanes.h", "ssw_dev.h")]      # everything the device code is made of
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round5_traffic.json")                         # written by scripts/gpu_profile.sh
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "round6_traffic.json")                         # written by scripts/gpu_profile.sh
 # VALU issue, two yardsticks: every instruction of the recurrence charged a 4-cycle slot -- what the kernels' mix actually costs
 # (profiles/round3_mix_issue_probe.txt) -- and the ISA ideal in which the three 32-bit adds of a row issue in 2.2 cycles as in a pure stream
 CYCLES_PER_PAIR_ROW_4CYCLE = 6.5 * 4.0

@@ -624,3 +624,50 @@ def test_lane_model_kernel_rule_sets_side_by_side_or_in_sequence(ectx, spec, mon
     for gapO, gapE, flag, ss in ((1, 1, 0, 2), (2, 3, 1, 2), (0, 0, 9, 2), (1, 2, 2, 0), (3, 3, 15, 1), (2, 2, 0, 2)):
         _run(ectx, reads, [ref, ref[:100].copy()], dna_matrix(2, 2), 5, gapO, gapE, flag=flag, ss=ss)
     _run(ectx, reads[:3], [ref], dna_matrix(5, 4), 5, 1, 1, flag=1)      # match 5: 150 x 5 = 750, deep into the 16-bit rules
+
+
+@pytest.mark.parametrize("pipe", ["1", "0"])
+def test_chunked_bucket_launches_pipelined_or_serial(emu_lib_path, pipe, monkeypatch):
+    """round 6: a short-query bucket whose column maxima do not fit the budget at once runs its launches alternately on the main stream and on a
+    lowest-priority stream, each with half of the scratch (default), or one after the other (SSW_GPU_PIPE=0): same records either way, and the
+    timing says which form ran.  Two buckets (100- and 150-bp reads), score only and with begin / CIGAR, an odd number of launches."""
+    monkeypatch.setenv("SSW_GPU_PIPE", pipe)
+    lib = ssw_amd.load(emu_lib_path)
+    ctx = ssw_amd.Context(0, lib)
+    try:
+        lib.ssw_gpu_set_budget(ctx.h, 1 << 20)      # 1 MiB: a handful of pairs per launch
+        rng = np.random.default_rng(61)
+        ref = random_ref(6000, 61, 4)
+        reads = make_reads(rng, ref, 140, [100] * 81 + [150] * 59, 4)
+        for flag in (0, 2):
+            _run(ctx, reads, [ref], dna_matrix(2, 2), 5, flag=flag)
+            t = ctx.timing()
+            assert t["fill_launches"] >= 4
+            assert (t["fill_pipelined"] == t["fill_launches"]) if pipe == "1" else (t["fill_pipelined"] == 0)
+    finally:
+        ctx.close()
+
+
+def test_parked_single_pair_contexts_are_released(emu_lib_path):
+    """round-5 advisor: a caller thread that ends parks its implicit context; ssw_gpu_release_parked() closes the parked ones (and at most four
+    stay parked however many threads came and went)."""
+    import ctypes as C
+    import threading
+    lib = ssw_amd.load(emu_lib_path)
+    i8p = C.POINTER(C.c_int8)
+    ref = random_ref(300, 71, 4); read = ref[40:100].copy(); mat = dna_matrix(2, 2)
+    scores = []
+
+    def worker():
+        p = lib.ssw_init(read.ctypes.data_as(i8p), len(read), mat.ctypes.data_as(i8p), 5, 2)
+        a = lib.ssw_align(p, ref.ctypes.data_as(i8p), len(ref), 3, 1, 0, 0, 0, 15)
+        scores.append(a.contents.nScore)
+        lib.align_destroy(a); lib.init_destroy(p)
+    lib.ssw_gpu_release_parked()
+    for _ in range(3):      # three bursts of four short-lived caller threads
+        th = [threading.Thread(target=worker) for _ in range(4)]
+        [t.start() for t in th]; [t.join() for t in th]
+    assert scores == [120] * 12
+    n = lib.ssw_gpu_release_parked()
+    assert 1 <= n <= 4, n      # later bursts took over what the first one parked; never more than four stay parked
+    assert lib.ssw_gpu_release_parked() == 0
