@@ -60,6 +60,8 @@ typedef struct {
 	int trace_waves;        /* SSW_GPU_TRACE_WAVES=1/4/16: team size; 0: by band width */
 	int trace_unblocked;    /* SSW_GPU_TRACE_BLOCKED=0: teams with one cell per thread */
 	int trace_many;         /* SSW_GPU_TRACE_MANY=<n>: a traceback round with more than n pending alignments sizes its teams for throughput (tests: 0); default 4096 */
+	int trace_early;        /* SSW_GPU_TRACE_EARLY=<n>: batches of at least n tracebacks start the teams of the alignments that are wide from the start beside round 0.  Built and measured in
+	                           round 6: SLOWER (config 4's traceback 175 -> 221 ms), off by default (0 / unset: never) -- kept with its tests as the measured form of "overlap the tail" */
 	int no_pipe;            /* SSW_GPU_PIPE=0: the launches of a chunked short-query bucket one after the other on the main stream (the form before round 6) */
 	int no_lit_spec;        /* SSW_GPU_LIT_SPEC=0: the lane-model kernel runs its 16-bit rules after the 8-bit ones (never both side by side: the form before round 6) */
 	int trace_no_cls80;     /* SSW_GPU_TRACE_CLS80=0: no 80-KiB LDS class for the traceback teams (the classes before round 6) */
@@ -91,6 +93,7 @@ struct ssw_gpu_ctx {
 	ssw_gpu_timing tm;
 	dbuf mat, pairs, pairs2, qlist, res, cm16, cm8, cm16b, cm8b, scratch, cigar, cigar2, need, goff, gpool, bnd, tlist, cand, tresume, queue, cands, sg16, sg8, qerr, fmtab;
 	dbuf sres, svq, svt, scnt;          /* flagged database search: survivor records, their (query, target) maps, counters */
+	dbuf scratch0, need0, list0;        /* traceback: round 0 of the narrow alignments while the wide ones' teams already run (trace_phase "early") */
 	void** ev; int nev, capev;          /* event pairs around fill launches */
 	void *ev_t0, *ev_a, *ev_b, *ev_c, *ev_d, *ev_db;
 	size_t cm_budget;                   /* bytes allowed for the two column-max buffers */
@@ -160,6 +163,7 @@ static void knobs_load(ssw_knobs* k)
 	k->trace_no_cls80 = env_is("SSW_GPU_TRACE_CLS80", '0');
 	k->no_lit_spec = env_is("SSW_GPU_LIT_SPEC", '0');
 	k->no_pipe = env_is("SSW_GPU_PIPE", '0');
+	k->trace_early = env_int("SSW_GPU_TRACE_EARLY", 0);
 	k->no_tail = env_is("SSW_GPU_NO_TAIL", '1');
 	{ const int v = env_int("SSW_GPU_DB_TSUB", 0); k->db_tsub = v > 0 ? v : 0; }
 	{ const int v = env_int("SSW_GPU_DBX_SLAB", 0); k->dbx_slab = v > 0 ? v : 0; }
@@ -311,6 +315,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	dbuf_free(&c->mat); dbuf_free(&c->pairs); dbuf_free(&c->qlist); dbuf_free(&c->res); dbuf_free(&c->cm16);
 	dbuf_free(&c->cm8); dbuf_free(&c->cm16b); dbuf_free(&c->cm8b); dbuf_free(&c->cigar2); dbuf_free(&c->scratch); dbuf_free(&c->cigar); dbuf_free(&c->need); dbuf_free(&c->goff); dbuf_free(&c->gpool); dbuf_free(&c->bnd); dbuf_free(&c->tlist); dbuf_free(&c->pairs2); dbuf_free(&c->cand); dbuf_free(&c->tresume); dbuf_free(&c->queue); dbuf_free(&c->cands); dbuf_free(&c->sg16); dbuf_free(&c->sg8); dbuf_free(&c->qerr); dbuf_free(&c->fmtab);
 	dbuf_free(&c->sres); dbuf_free(&c->svq); dbuf_free(&c->svt); dbuf_free(&c->scnt);
+	dbuf_free(&c->scratch0); dbuf_free(&c->need0); dbuf_free(&c->list0);
 	for (int i = 0; i < c->capev; ++i) ssw_shim_event_destroy(c->ev[i]);
 	free(c->ev);
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
@@ -1021,6 +1026,15 @@ typedef struct {
 } trace_in;
 typedef struct { uint32_t* d_cig; int64_t cig_stride; int did_trace; int list_dirty; /* d_list was overwritten */ } trace_out;
 
+/* bytes of one band row of the ONE-wavefront traceback team (ssw_kernels.hip trace_rowbytes / trace_cpt_class with 64 threads), restated for the host: only used to
+   tell which alignments round 0's scratch cannot hold anyway (a wrong guess sorts an alignment into the other launch -- never a wrong result) */
+static int64_t host_trace_rowbytes1(int64_t band)
+{
+	const int64_t cells = band * 2 + 3 + 1 + 12, cpt = (band * 2 + 1 + 63) / 64;
+	const int64_t C = cpt <= 1 ? 1 : cpt <= 2 ? 2 : cpt <= 4 ? 4 : 0;
+	return ((cells + (C > 1 ? cells / C + 3 : 0)) * 4 + 15) & ~(int64_t)15;
+}
+
 static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 {
 		int64_t cig_stride = 0;
@@ -1067,11 +1081,83 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 		const int64_t full = (int64_t)maxlen + ti->ref_span;
 		const int64_t worst = (3 * (2 * full + 8) * 4 + (2 * full + 1) * (int64_t)maxlen * 3 + 64 + 15) / 16 * 16;
 		int trace_ok = 1;
+		/* Early teams (round 6, EXPERIMENT, off by default: SSW_GPU_TRACE_EARLY=<n> in the hooks build).  banded_sw starts at the band |refLen' - readLen'| + 1
+		   (src/ssw.c:941-944): an alignment whose FIRST band already wants more than round 0's scratch (bands above 48) comes back from round 0 at once, untouched --
+		   config 4's ~500 unrelated reads, whose teams then walk 10^4 rows five or six times while the device is otherwise nearly idle (VALU busy 0.2).  Those
+		   alignments are known from the records before round 0 runs: here their team classes are launched beside round 0 of the narrow ones (a side stream
+		   with its own list / scratch / need buffers).  MEASURED on config 4 (profiles/round6_experiments.json): traceback 175 -> 221 ms.  The teams' round is bound
+		   by its longest alignment's serial chain, and that chain gets slower when 9 500 issue-bound wavefronts share its compute units (124 -> 168 ms); the handful of
+		   narrow alignments that outgrow round 0 then need rounds of their own (38 + 16 ms) instead of riding along with the 497.  The serial order stays. */
+		int early = 0, round_first = 0;
+		int32_t n_narrow = 0, *lst0 = 0, *hnb0 = 0;
+		{
+			const int32_t emin = c->kn.trace_early > 0 ? c->kn.trace_early : 2048;
+			if (c->kn.trace_early > 0 && use_wave0 && use_wave && !c->kn.trace_diag && ti->nids >= emin &&
+			    sstride * (int64_t)ti->nids <= (int64_t)((size_t)32 << 30)) {
+				ssw_dres* hr = (ssw_dres*)malloc(sizeof(ssw_dres) * (size_t)nq);
+				lst0 = (int32_t*)malloc(sizeof(int32_t) * (size_t)ti->nids); hnb0 = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)ti->nids);
+				if (!hr || !lst0 || !hnb0) { free(hr); free(lst0); free(hnb0); free(pend); free(lst); free(hnb); fail(c, "out of host memory%s", ""); return -1; }
+				if (ssw_shim_d2h(hr, d_res, sizeof(ssw_dres) * (size_t)nq, c->stream) || ssw_shim_stream_sync(c->stream)) {
+					free(hr); free(lst0); free(hnb0); free(pend); free(lst); free(hnb); return fail(c, "result download failed: %s", ssw_shim_last_error());
+				}
+				int32_t ne = 0;
+				for (int32_t k = 0; k < ti->nids; ++k) {
+					const int32_t q = ti->ids[k];
+					const ssw_dres* r = &hr[q];
+					int wide0 = 0; int64_t want = 0, band0 = 0;
+					if (r->want_cigar && r->status == 0) {
+						const int64_t rl = (int64_t)r->ref_end1 - r->ref_begin1 + 1, ql = (int64_t)r->read_end1 - r->read_begin1 + 1;
+						band0 = (rl > ql ? rl - ql : ql - rl) + 1;
+						want = 3 * host_trace_rowbytes1(band0) + (band0 + 1) * ql + 16;
+						wide0 = want > sstride && band0 < 0x3fffffff;
+					}
+					if (wide0) { pend[ne].key = (int32_t)band0; pend[ne].need = (int32_t)((want + 4095) >> 12); pend[ne].q = q; ++ne; }
+					else lst0[n_narrow++] = q;
+				}
+				free(hr);
+				if (ne >= 8 && n_narrow >= emin / 2) { early = 1; npend = ne; round_first = 1; }
+				else { for (int32_t k = 0; k < ti->nids; ++k) { pend[k].key = 0; pend[k].need = 0; pend[k].q = ti->ids[k]; } n_narrow = 0; }
+			}
+		}
+		if (early) {
+			void* s0 = c->tstream[5];
+			int32_t* d_list0 = (int32_t*)ensure(c, &c->list0, sizeof(int32_t) * (size_t)n_narrow);
+			uint8_t* d_scr0 = (uint8_t*)ensure(c, &c->scratch0, (size_t)(sstride * n_narrow));
+			int32_t* d_need0 = (int32_t*)ensure(c, &c->need0, sizeof(int32_t) * 2 * (size_t)n_narrow);
+			if (!d_list0 || !d_scr0 || !d_need0) { free(lst0); free(hnb0); free(pend); free(lst); free(hnb); return -1; }
+			ssw_trace_args ta;
+			ta.tgt = d_tgt; ta.qcodes = Q->d_codes; ta.qoff = Q->d_off; ta.qlist = d_list0; ta.nq = n_narrow; ta.mat = d_mat; ta.n = n; ta.vm = ti->vm;
+			ta.gapO = prm->gapO; ta.gapE = prm->gapE; ta.res = d_res; ta.scratch = d_scr0; ta.scratch_stride = sstride; ta.soff = 0;
+			ta.cigar = d_cig; ta.cigar_stride = cig_stride; ta.need = d_need0; ta.resume = d_resume; ta.unblocked = trace_unblocked; ta.waves = 1;
+			ta.lds_bytes = trace_no_lds ? 0 : (int32_t)ssw_shim_trace_lds_need(64, 1);
+			resume_zeroed = 1;
+			/* (the side stream starts after the window passes and the zeroed resume state on the main stream; the teams below are queued on the main stream
+			   and the other side streams right after this event, i.e. ahead of the narrow alignments' wavefronts in the queues) */
+			if (ssw_shim_memset(d_resume, 0, sizeof(int32_t) * 8 * (size_t)nq, c->stream) || ssw_shim_event_record(c->ev_db, c->stream) || ssw_shim_stream_wait_event(s0, c->ev_db) ||
+			    ssw_shim_h2d(d_list0, lst0, sizeof(int32_t) * (size_t)n_narrow, s0) || ssw_shim_launch_trace_wave(&ta, s0)) {      /* (what it needs comes back in the second phase: a copy into pageable memory would hold the host here until the launch is done) */
+				free(lst0); free(hnb0); free(pend); free(lst); free(hnb); return fail(c, "trace launch failed: %s", ssw_shim_last_error());
+			}
+			to->list_dirty = 1;
+			if (c->kn.debug) fprintf(stderr, "[ssw_gpu] %.1f ms: trace, early teams: %d alignments are wide from the start (their classes follow), round 0 of the other %d on a side stream\n", dbg_ms(), npend, n_narrow);
+		}
+		for (int phase = 0; phase < (early ? 2 : 1) && trace_ok; ++phase) {
+		if (phase == 1) {      /* the narrow alignments' round 0 has run beside the teams: whoever outgrew its scratch there goes through the rounds now */
+			if (ssw_shim_d2h(hnb0, c->need0.p, sizeof(int32_t) * 2 * (size_t)n_narrow, c->tstream[5]) || ssw_shim_stream_sync(c->tstream[5])) { fail(c, "trace launch failed: %s", ssw_shim_last_error()); trace_ok = 0; break; }
+			npend = 0;
+			for (int32_t k = 0; k < n_narrow; ++k)
+				if (hnb0[k] != 0) {
+					if (hnb0[k] < 0) { fail(c, "internal error: CIGAR slot too small%s", ""); trace_ok = 0; break; }
+					pend[npend].key = hnb0[n_narrow + k]; pend[npend].need = hnb0[k]; pend[npend].q = lst0[k]; ++npend;
+				}
+			if (c->kn.debug) fprintf(stderr, "[ssw_gpu] %.1f ms: trace, early teams: round 0 of the narrow alignments done, %d of them pending\n", dbg_ms(), npend);
+			did_trace = 1;
+			if (!trace_ok) break;
+		}
 		/* Termination.  An alignment that comes back pending names the band that did not fit and the bytes that band wants; the next round grants
 		   at least that (see cap_i below), so the band is walked and the alignment either finishes or reports a band at least twice as wide.
 		   banded_sw walks bands <= max(refLen', readLen') only (src/ssw.c:679), the single retry at the full band (945-957) included: after at most
 		   log2(span) + 2 rounds nothing is pending.  64 is that bound for any 32-bit span, not a budget -- reaching it would be a bug. */
-		for (int round = 0; round < 64 && npend > 0 && trace_ok; ++round) {
+		for (int round = round_first; round < 64 && npend > 0 && trace_ok; ++round) {
 			tpend* nextp = (tpend*)malloc(sizeof(tpend) * (size_t)npend);
 			int32_t nnext = 0;
 			if (!nextp) { fail(c, "out of host memory%s", ""); trace_ok = 0; break; }
@@ -1244,6 +1330,14 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 			did_trace = 1;
 			free(pend); pend = nextp; npend = nnext;
 		}
+		if (early && phase == 0 && trace_ok && npend == 0) {      /* (the list of the second phase is at most the narrow alignments) */
+			free(pend);
+			pend = (tpend*)malloc(sizeof(tpend) * (size_t)(n_narrow > 0 ? n_narrow : 1));
+			if (!pend) { fail(c, "out of host memory%s", ""); trace_ok = 0; }
+		}
+		}      /* phase */
+		if (early) ssw_shim_stream_sync(c->tstream[5]);      /* (also on a failure above: nothing of this call may still be running when its buffers are reused) */
+		free(lst0); free(hnb0);
 		free(pend); free(lst); free(hnb);
 		if (!trace_ok) return -1;
 		if (npend > 0) { fail(c, "internal error: traceback scratch negotiation did not converge%s", ""); return -1; }

@@ -155,3 +155,25 @@ def empties_case(rng):
     reads = [np.zeros(0, dtype=np.int8) if L == 0 else make_reads(rng, base, 1, [L], nc, frac_random=0.3)[0] for L in lens]
     return (reads, refs, mat, n, gapO, gapE, int(rng.choice([0, 0, 1, 2, 8, 9, 15, 6])), int(rng.choice([0, 0, 30])), int(rng.choice([0, 40, 1000])),
             int(rng.choice([-1, -1, 0, 15, 40])), int(rng.choice([2, 2, 2, 0, 1])))
+
+
+def early_team_batch(rng, nreads=24, rlen=300):
+    """a batch for the traceback's EARLY teams (round 6): a third of the reads are wide from the start (one long deletion: |refLen' - readLen'| + 1 is far above
+    round 0's band of 48 -> their teams are launched before round 0), a sixth start narrow and outgrow round 0's scratch (three insertions and three deletions of 20 bases
+    that cancel in length: band0 is 1, the path needs a band above 60 -> pending after round 0, second phase), the others are plain.  -> (reads, ref)"""
+    ref = _random_ref(10 * rlen, int(rng.integers(1 << 30)), 4)
+    reads = make_reads(rng, ref, nreads, [rlen] * nreads, 4, sub=0.02, ins=0.004, dele=0.004, frac_random=0.0)
+    for i in range(nreads):
+        o = int(rng.integers(0, len(ref) - 3 * rlen))
+        if i % 3 == 0:
+            gap = int(rng.integers(60, 200))
+            reads[i] = np.ascontiguousarray(np.concatenate([ref[o:o + rlen // 2], ref[o + rlen // 2 + gap:o + rlen + gap]])[:rlen])
+        elif i % 6 == 1:      # three insertions of 20, then three deletions of 20: the ends line up (band0 = 1), the path strays 60 columns in between
+            pc = rlen // 8
+            parts, at = [], o
+            for k in range(7):
+                parts.append(ref[at:at + pc]); at += pc
+                if k < 3: parts.append(rng.integers(0, 4, size=20, dtype=np.int8))
+                elif k < 6: at += 20
+            reads[i] = np.ascontiguousarray(np.concatenate(parts)[:rlen])
+    return reads, ref

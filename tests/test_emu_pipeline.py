@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import ssw_amd
-from parity import compare_batch, empties_case, empties_two_call_repro, free_gap_open_case, make_reads, narrow_band_batches
+from parity import compare_batch, early_team_batch, empties_case, empties_two_call_repro, free_gap_open_case, make_reads, narrow_band_batches
 from sswutil import blosum50, dna_matrix, random_ref
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -671,3 +671,16 @@ def test_parked_single_pair_contexts_are_released(emu_lib_path):
     n = lib.ssw_gpu_release_parked()
     assert 1 <= n <= 4, n      # later bursts took over what the first one parked; never more than four stay parked
     assert lib.ssw_gpu_release_parked() == 0
+
+
+@pytest.mark.parametrize("early", ["12", "0"])
+def test_traceback_early_teams_beside_round_zero(ectx, early, monkeypatch):
+    """round 6: alignments whose first band (|refLen' - readLen'| + 1, src/ssw.c:941-944) is already beyond round 0's scratch get their teams BEFORE round 0, which runs
+    beside them on a side stream with its own buffers; narrow alignments that outgrow round 0 there go through the rounds afterwards (second phase).  Same records and
+    CIGARs as the serial order (the default: the early form measured slower on config 4 and is an opt-in experiment of the hooks build) and as the reference."""
+    monkeypatch.setenv("SSW_GPU_TRACE_EARLY", early)
+    rng = np.random.default_rng(41)
+    for flag in (2, 9):
+        reads, ref = early_team_batch(rng)
+        res = _run(ectx, reads, [ref], dna_matrix(2, 2), 5, flag=flag)
+        assert (res["cigarLen"][:, 0] > 0).sum() >= 20

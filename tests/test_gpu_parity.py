@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from parity import compare_batch, empties_case, empties_two_call_repro, free_gap_open_case, make_reads, narrow_band_batches
+from parity import compare_batch, early_team_batch, empties_case, empties_two_call_repro, free_gap_open_case, make_reads, narrow_band_batches
 from sswutil import RES_FIELDS, blosum50, dna_matrix, encode_dna, random_ref, sample_reads
 
 pytestmark = pytest.mark.gpu
@@ -479,3 +479,14 @@ def test_single_pair_abi_fuzz_regime(product_lib_path):
                          capture_output=True, text=True, timeout=600)
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["calls"] > 300 and line["calls_with_wrong_values"] == 0 and line["alphabets_above_32"] > 50, line
+
+
+@pytest.mark.parametrize("early", ["64", "0"])
+def test_traceback_early_teams_beside_round_zero(gpu_hctx, early, monkeypatch):
+    """the teams of alignments that are wide from the start run beside round 0 of the narrow ones (round 6; emulator twin in tests/test_emu_pipeline.py): 3-kb reads so that
+    the teams and round 0 really overlap on the device, both orders, every record and CIGAR against the reference"""
+    monkeypatch.setenv("SSW_GPU_TRACE_EARLY", early)
+    rng = np.random.default_rng(43)
+    for flag in (2, 9):
+        reads, ref = early_team_batch(rng, nreads=192, rlen=3000)
+        _run(gpu_hctx, reads, [ref], dna_matrix(2, 2), 5, flag=flag, check=list(range(0, 192, 4)) + list(range(1, 192, 6)))
