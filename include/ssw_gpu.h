@@ -169,8 +169,8 @@ int ssw_gpu_search_db(ssw_gpu_ctx* ctx, const ssw_gpu_seqs* queries, const ssw_g
  * calls on one const s_profile* are legal, as with the reference (src/ssw.c has no mutable global state).
  * Streaming callers: while a batch call runs on a context, ONE other thread may prepare the next block on the same context with the
  * ssw_gpu_seqs_* calls (upload, ASCII translation, reverse complement) and free finished sets; those run on the context's upload stream
- * and do not queue behind the batch call's kernels (ssw_test_gpu's three stages, bench.py --config 3 --full).  The first such call of a
- * context must have returned before the first batch call starts.
+ * and do not queue behind the batch call's kernels (ssw_test_gpu's three stages, bench.py --config 3 --full).  The context's lazily created
+ * streams and its error text are guarded by a lock (round 6): the feeder thread's first upload may race the first batch call.
  */
 
 /*
