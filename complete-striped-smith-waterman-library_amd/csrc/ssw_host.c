@@ -1573,8 +1573,10 @@ static int align_batch_locked(ssw_gpu_ctx* c, const ssw_gpu_seqs* Q, const ssw_g
 	/* measured on 10-kb DNA reads: fill 1462 / 1514 / 1550 / 1604 / 1568 ms at 12 / 11 / 10 / 9 / 8 rows per lane (9..12 share an LDS
 	   footprint -- three 16-byte profile chunks per lane and residue --, and the more rows a step has, the less its fixed part
 	   weighs; before the record branch was deferred by a step 10 was ahead of 12, profiles/round2_sweep_d_config4_xr*.json vs
-	   round2_sweep_o_config4_xr*.json); the window passes, which carry two target rings and more registers, are fastest at 8 */
-	int32_t xrcap = 8;
+	   round2_sweep_o_config4_xr*.json).  The window passes carry two target rings and more registers; round 2 found them fastest at 8 rows per lane.  Measured again in
+	   round 6 -- since round 4 the reverse pass walks a diagonal band, where every strip pays 2 x band columns beside its own rows, so fewer, taller strips win: config 4's
+	   window passes 138.0 / 112.7 / 101.2 / 86.5 / 85.4 ms at 4 / 6 / 8 / 10 / 12 rows per lane (profiles/round6_experiments.json): 12 */
+	int32_t xrcap = 12;
 	{
 		if (c->kn.xlanes16) xlanes = 16;
 		if (c->kn.xr) { xrmax = c->kn.xr; xrcap = xrmax; }
