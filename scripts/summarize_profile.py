@@ -100,7 +100,7 @@ for cfg, k in ((2, "k_fill<10, 3>"), (4, "k_chainq<12, false, 3>"), (5, "k_filld
 #   VALU busy              = 4 x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)   (share of the 4-cycle issue slots; gfx94x's VALUBusy uses SQ_ACTIVE_INST_VALU the same way)
 #   LDS busy               = SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE / 8)       (share of the cycles in which a CU's LDS array works)
 util = {}
-WATCH = {2: ["k_fill<10, 3>"], 4: ["k_chainq<12, false, 3>", "k_chainq<8, true, 3>", "k_trace_wave<16>", "k_trace_wave<4>", "k_trace_wave<1>"], 5: ["k_filldb<20, 16, true>", "k_filldb<19, 16, true>"]}
+WATCH = {2: ["k_fill<10, 3>"], 4: ["k_chainq<12, false, 3>", "k_chainq<12, true, 3>", "k_chainq<8, true, 3>", "k_trace_wave<16>", "k_trace_wave<4>", "k_trace_wave<1>"], 5: ["k_filldb<20, 16, true>", "k_filldb<19, 16, true>"]}
 for cfg, names in WATCH.items():
     for k in names:
         d = {}
