@@ -32,7 +32,8 @@ typedef struct ssw_gpu_seqs ssw_gpu_seqs;  /* a set of residue-code sequences re
    (src/ssw.h:86, 126-134) that are not the sequences themselves. */
 typedef struct {
 	const int8_t* mat;   /* n*n scores, mat[target_code*n + read_code] (host pointer) */
-	int32_t n;
+	int32_t n;           /* alphabet size, any n >= 1 like the reference: up to 32 letters on the profile kernels; above that (and whenever gapO <= gapE) on the
+	                        lane-model kernel -- the reference's answer at CPU-class speed; beyond 128 only the leading 128 x 128 block is addressable by int8 codes */
 	uint8_t gapO;        /* weight_gapO */
 	uint8_t gapE;        /* weight_gapE */
 	uint8_t flag;        /* as ssw_align */

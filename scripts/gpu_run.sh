@@ -35,7 +35,7 @@ bench() { local name=$1; shift; timeout 900 python bench.py "$@" > gpurun_out/${
 for step in "$@"; do
   case "$step" in
     tests) timeout 1800 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/${TAG}_pytest.log; tail -4 gpurun_out/${TAG}_pytest.log ;;
-    bench) bench default ;;
+    bench) bench default --gpus 1 --steps 20 --warmup 5 ;;      # (the driver's command line: python3 bench.py --gpus 1 --steps 20 --warmup 5)
     bench:*) IFS=: read -r _ name args <<< "$step"; bench "$name" ${args//+/ } ;;
     xbench:*) IFS=: read -r _ name envs args <<< "$step"; ( for kv in ${envs//,/ }; do export "${kv//@/$PWD}"; done; bench "$name" ${args//+/ } ) ;;      # xbench:<name>:<ENV=V,ENV=V>:<args>  (a path in V may use @ for $PWD)
     fuzz) for s in 1 2; do timeout 400 python scripts/gpu_fuzz.py ${SSW_FUZZ_SECS:-150} $s 2>/dev/null | tee -a gpurun_out/${TAG}_gpu_fuzz.json | cut -c1-600; done
