@@ -38,8 +38,8 @@ for step in "$@"; do
     bench) bench default --gpus 1 --steps 20 --warmup 5 ;;      # (the driver's command line: python3 bench.py --gpus 1 --steps 20 --warmup 5)
     bench:*) IFS=: read -r _ name args <<< "$step"; bench "$name" ${args//+/ } ;;
     xbench:*) IFS=: read -r _ name envs args <<< "$step"; ( for kv in ${envs//,/ }; do export "${kv//@/$PWD}"; done; bench "$name" ${args//+/ } ) ;;      # xbench:<name>:<ENV=V,ENV=V>:<args>  (a path in V may use @ for $PWD)
-    fuzz) for s in 1 2; do timeout 400 python scripts/gpu_fuzz.py ${SSW_FUZZ_SECS:-150} $s 2>/dev/null | tee -a gpurun_out/${TAG}_gpu_fuzz.json | cut -c1-600; done
-          for s in 1 2; do timeout 300 python scripts/abi_fuzz.py ${SSW_FUZZ_SECS:-150} $s 2>/dev/null | tee -a gpurun_out/${TAG}_abi_fuzz.json | cut -c1-600; done ;;
+    fuzz) for s in ${SSW_FUZZ_SEEDS:-1 2}; do timeout $(( ${SSW_FUZZ_SECS:-150} + 250 )) python scripts/gpu_fuzz.py ${SSW_FUZZ_SECS:-150} $s 2>/dev/null | tee -a gpurun_out/${TAG}_gpu_fuzz.json | cut -c1-600; done
+          for s in ${SSW_FUZZ_SEEDS:-1 2}; do timeout $(( ${SSW_FUZZ_SECS:-150} + 150 )) python scripts/abi_fuzz.py ${SSW_FUZZ_SECS:-150} $s 2>/dev/null | tee -a gpurun_out/${TAG}_abi_fuzz.json | cut -c1-600; done ;;
     config6)
       bench c6 --config 6
       SSW_LIB=$PWD/complete-striped-smith-waterman-library_amd/libssw_hooks.so SSW_GPU_SERIAL_BUCKETS=1 bench c6_serial_buckets --config 6 --cpu-sample 0
