@@ -6,7 +6,7 @@ each -- round-5 verdict: no fuzzer drew them, which is how an out-of-bounds of t
 database path from four targets on), ALL CALLS ON ONE LONG-LIVED CONTEXT (what a call leaves in the pooled buffers is the next call's
 environment).  Every record and CIGAR is compared (tests/parity.py); one call in six that returns CIGARs runs again with mark_mismatch (the device's
 '=' / 'X' / soft-clip rewrite and edit distance against the reference's own mark_mismatch() on the raw CIGAR); a call that fails is counted separately from a wrong value.
-usage: gpu_fuzz.py <seconds> <seed> [--emu | --lib <path>]        -> one JSON line
+usage: gpu_fuzz.py <seconds> <seed> [--emu | --lib <path>] [--only <k>]        -> one JSON line   (--only: just call k of the seed; SSW_FUZZ_TRACE=1: the parameters of every call on stderr before it runs)
 (--lib: another build of the emulated library, e.g. the AddressSanitizer one of scripts/asan_emu_fuzz.sh)"""
 import json
 import os
@@ -24,6 +24,7 @@ from sswutil import blosum50, dna_matrix   # noqa: E402
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 emu = "--emu" in sys.argv
+only = int(sys.argv[sys.argv.index("--only") + 1]) if "--only" in sys.argv else 0
 libpath = sys.argv[sys.argv.index("--lib") + 1] if "--lib" in sys.argv else os.path.join(ROOT, "tests", "emu", "libssw_emu.so") if emu else None
 emu = emu or "--lib" in sys.argv
 lib = ssw_amd.load(libpath)
@@ -80,6 +81,12 @@ while time.time() < t_end:
     if n > 32: regimes["alphabet>32"] += 1
     if int(np.max(lens)) > 768: regimes["multi_strip_queries"] += 1
     calls += 1; aln += nq * nt
+    if os.environ.get("SSW_FUZZ_TRACE"):      # one line per call BEFORE it runs (a crash is then the last line)
+        print("call %d: n %d gapO %d gapE %d flag %d ss %d filters %d filterd %d maskLen %d nq %d lens %s nt %d tlens %s" % (calls, n, gapO, gapE, flag, ss, filters, filterd, maskLen, nq, [len(r) for r in reads], nt, [len(r) for r in refs]), file=sys.stderr, flush=True)
+    if only and calls != only:      # --only <k>: the inputs of call k of this seed alone (the generator's draws do not depend on results)
+        rng.random()
+        if calls > only: break
+        continue
     Q = ctx.upload(reads); T = ctx.upload(refs)
     try:
         res, cig = ctx.align_batch(Q, T, mat, n, gapO, gapE, flag, filters, filterd, maskLen, ss)
@@ -109,7 +116,8 @@ while time.time() < t_end:
                         if int(b["cigarLen"]) > 0: bad.append("mark_mismatch: a CIGAR where the raw call has none")
                         continue
                     buf = libc.malloc(4 * k)
-                    C.memmove(buf, cig[int(a["cigar_off"]):int(a["cigar_off"]) + k].astype(np.uint32).ctypes.data, 4 * k)
+                    raw = np.ascontiguousarray(cig[int(a["cigar_off"]):int(a["cigar_off"]) + k], dtype=np.uint32)      # (kept in a name: a temporary's buffer may be gone before memmove reads it)
+                    C.memmove(buf, raw.ctypes.data, 4 * k)
                     pc = C.cast(buf, u32p); cl = C.c_int32(k)
                     nm = R.mark_mismatch(int(a["ref_begin1"]), int(a["read_begin1"]), int(a["read_end1"]), rf.ctypes.data_as(i8p), rd.ctypes.data_as(i8p), len(rd), C.byref(pc), C.byref(cl))
                     want = [int(pc[x]) for x in range(cl.value)]

@@ -57,7 +57,8 @@ def _mark_case(ctx, nreads, reflen, seed):
         # the reference's own function on the raw CIGAR (it frees and replaces a malloc'ed array)
         libc = C.CDLL(None); libc.malloc.restype = C.c_void_p; libc.free.argtypes = [C.c_void_p]
         buf = libc.malloc(4 * n)
-        C.memmove(buf, rcig[int(a["cigar_off"]):int(a["cigar_off"]) + n].astype(np.uint32).ctypes.data, 4 * n)
+        rawc = np.ascontiguousarray(rcig[int(a["cigar_off"]):int(a["cigar_off"]) + n], dtype=np.uint32)      # (kept in a name: a temporary's buffer may be gone before memmove reads it)
+        C.memmove(buf, rawc.ctypes.data, 4 * n)
         pc = C.cast(buf, u32p); cl = C.c_int32(n)
         nm = R.mark_mismatch(int(a["ref_begin1"]), int(a["read_begin1"]), int(a["read_end1"]), _ptr(ref, i8p), _ptr(rd, i8p), len(rd), C.byref(pc), C.byref(cl))
         want = [int(pc[k]) for k in range(cl.value)]
