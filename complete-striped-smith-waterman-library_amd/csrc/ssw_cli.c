@@ -279,7 +279,7 @@ static void* queue_pop(queue* q)                /* NULL: closed and drained */
 }
 
 typedef struct {
-	const char* qfile; int32_t batch; int reverse, reverse_fatal; const int8_t* table; int nt_table;
+	gzFile qf; int32_t batch; int reverse, reverse_fatal; const int8_t* table; int nt_table;
 	ssw_gpu_ctx* g; ssw_gpu_pool* gp; ssw_gpu_seqs* T; int32_t nt;
 	ssw_gpu_params prm;
 	queue parsed, aligned;
@@ -298,14 +298,7 @@ static void* stage_parse(void* arg)
 {
 	pipeline* pl = (pipeline*)arg;
 	reader* qr = (reader*)xmalloc(sizeof(reader)); memset(qr, 0, sizeof *qr);
-	qr->f = gzopen(pl->qfile, "r");
-	if (!qr->f) {      /* (no exit() from a worker thread: the main thread may be inside its stdout buffer -- the failure travels as a work item) */
-		fprintf(stderr, "gzopen of '%s' failed.\n", pl->qfile);
-		work* w = (work*)xmalloc(sizeof(work)); memset(w, 0, sizeof *w);
-		w->fatal = EXIT_FAILURE; queue_push(&pl->parsed, w);
-		free(qr);
-		return 0;
-	}
+	qr->f = pl->qf;      /* opened by main() before anything else, like the reference (src/main.c:434-439) */
 	gzbuffer(qr->f, 1 << 20);
 	int32_t ramp = pl->batch < 4096 ? pl->batch : 4096;
 	for (int first = 1; ; first = 0) {
@@ -429,6 +422,95 @@ static void usage(void)
 	                "\t-g N\tSpread every batch over N workers (one per device, round-robin over the visible devices). [default: one device]\n\n");
 }
 
+
+/* ---- the command line ------------------------------------------------------------------------------------------------------
+ * Default: the reference's own scanner, reproduced literally (src/main.c:247-330), because "the same command line gives the same
+ * bytes" is what a drop-in means -- and the reference's scanner is NOT getopt:
+ *   - every character of an argument that starts with '-' is an option letter ("-cs" = -c -s; unknown letters are ignored);
+ *   - a value option (m x o e a f) takes the NEXT argument unless that starts with '-' ("-m5" and "-x -3" give no value);
+ *   - after taking a value it goes on scanning at the SAME character index in the value's string.  A value shorter than that
+ *     index ("-e 1": index 2 of "1") puts the scan behind the string's end -- undefined in C, but on Linux the argument
+ *     strings lie back to back (then the environment's), so the reference binary reads the following argument as option letters:
+ *     "ssw_test -o 5 -e 2 ref.fa reads.fq" takes the 'r' of "ref.fa" as -r and its 'e' as "-e ref.fa" (gap extension 0).
+ *     Reproduced here on the same memory, bounds-checked: only strings that are verified to follow each other are read, and a
+ *     note on stderr says what the overrun changed.  (Value options first and a flag such as -c last, or two-character values
+ *     like "-e 02", never trigger it.)
+ *   - the two files are the first argument that is not an option (or the value of one) and the one after it.
+ * -b / -g (this program's own options) are honoured only inside a genuine option argument: the reference ignores those letters.
+ * SSW_CLI_ARGS=getopt selects a conventional parser instead (options anywhere, "-m5", negative values). */
+typedef struct {
+	int32_t *match, *mismatch, *gap_open, *gap_ext, *filter, *batch, *gpus, *protein, *path, *reverse, *sam, *header;
+	const char** mat_name;
+} cli_opts;
+
+static int scan_args_getopt(int argc, char* const argv[], cli_opts* o, const char* files[2])
+{
+	int nfiles = 0;
+	for (int i = 1; i < argc; ++i) {
+		if (argv[i][0] != '-' || !argv[i][1]) { if (nfiles < 2) files[nfiles++] = argv[i]; continue; }
+		for (int j = 1; argv[i][j]; ++j) {
+			const char c = argv[i][j];
+			if (c == 'p') *o->protein = 1; else if (c == 'c') *o->path = 1; else if (c == 'r') *o->reverse = 1;
+			else if (c == 's') *o->sam = 1; else if (c == 'h') *o->header = 1;
+			else if (strchr("mxoefabg", c)) {
+				const char* val = argv[i][j + 1] ? &argv[i][j + 1] : (i + 1 < argc ? argv[++i] : 0);
+				if (!val) return 1;
+				if (c == 'm') *o->match = atoi(val); else if (c == 'x') *o->mismatch = atoi(val); else if (c == 'o') *o->gap_open = atoi(val);
+				else if (c == 'e') *o->gap_ext = atoi(val); else if (c == 'f') *o->filter = atoi(val); else if (c == 'b') *o->batch = atoi(val);
+				else if (c == 'g') *o->gpus = atoi(val); else *o->mat_name = val;
+				break;
+			}
+		}
+	}
+	return nfiles < 2;
+}
+
+extern char** environ;
+
+static int scan_args_reference(int argc, char* const argv[], cli_opts* o, const char* files[2])
+{
+	/* the bytes the reference's scan can reach: argv[1..] and, behind them, the environment -- as far as they really lie back to back */
+	const char* lim = argc > 1 ? argv[1] + strlen(argv[1]) + 1 : 0;
+	int contiguous = argc > 1;
+	for (int k = 2; k < argc && contiguous; ++k) { if (argv[k] == lim) lim += strlen(argv[k]) + 1; else contiguous = 0; }
+	for (char** e = environ; contiguous && e && *e; ++e) { if (*e == lim) lim += strlen(*e) + 1; else break; }
+	char note[512]; size_t nn = 0; note[0] = 0;
+	for (int i = 1; i < argc; i++) {
+		if (argv[i][0] != '-') continue;
+		const char* own = argv[i];
+		const char* own_end = own + strlen(own);               /* behind this: not this option argument any more */
+		const char* cur_end = own_end;                         /* end of the string the index is applied to (it changes when a value is taken) */
+		for (int j = 1; ; j++) {
+			const char* p = argv[i] + j;
+			const int over = argv[i] != own || p > own_end;
+			if (p > cur_end && !(contiguous && p >= argv[1] && p < lim)) break;      /* nothing verified to read there: stop like at a terminator */
+			const char c = *p;
+			if (!c) break;
+			int32_t* iv = c == 'm' ? o->match : c == 'x' ? o->mismatch : c == 'o' ? o->gap_open : c == 'e' ? o->gap_ext : c == 'f' ? o->filter :
+			              (!over && c == 'b') ? o->batch : (!over && c == 'g') ? o->gpus : 0;
+			int hit = 0;
+			if (iv || c == 'a') {
+				if (i + 1 < argc && argv[i + 1][0] != '-') {
+					if (iv) *iv = atoi(argv[i + 1]); else *o->mat_name = argv[i + 1];
+					i++; hit = 1; cur_end = argv[i] + strlen(argv[i]);
+				}
+			} else if (c == 'p') { *o->protein = 1; hit = 1; } else if (c == 'c') { *o->path = 1; hit = 1; } else if (c == 'r') { *o->reverse = 1; hit = 1; }
+			else if (c == 's') { *o->sam = 1; hit = 1; } else if (c == 'h') { *o->header = 1; hit = 1; }
+			if (hit && over && nn + 48 < sizeof note) nn += (size_t)snprintf(note + nn, sizeof note - nn, hit && (iv || c == 'a') ? " -%c %.24s" : " -%c", c, argv[i]);
+		}
+		if (nn) {
+			fprintf(stderr, "ssw_test_gpu: note: the option scan behind \"%s\" ran on into the following arguments, as the reference's ssw_test does "
+			                "(src/main.c:253-300), and took from them:%s.  Give value options first and a flag (e.g. -c) last, or SSW_CLI_ARGS=getopt.\n", own, note);
+			nn = 0; note[0] = 0;
+		}
+	}
+	int first = 1;
+	while (first < argc && argv[first][0] == '-') first += (argv[first][1] && strchr("mxoeafbg", argv[first][1])) ? 2 : 1;
+	if (first + 2 > argc) return 1;
+	files[0] = argv[first]; files[1] = argv[first + 1];
+	return 0;
+}
+
 int main(int argc, char* const argv[])
 {
 	/* stdout buffer first, before ANY output (the SAM header below): setvbuf after I/O on the stream is undefined (round-5 advisor) */
@@ -437,24 +519,11 @@ int main(int argc, char* const argv[])
 	int32_t match = 2, mismatch = 2, gap_open = 3, gap_ext = 1, path = 0, reverse = 0, n = 5, sam = 0, protein = 0, header = 0, filter = 0;
 	int32_t batch = 65536, gpus = 0;
 	const char* mat_name = 0;
-	const char* files[2]; int nfiles = 0;
-	for (int i = 1; i < argc; ++i) {
-		if (argv[i][0] != '-' || !argv[i][1]) { if (nfiles < 2) files[nfiles++] = argv[i]; continue; }
-		for (int j = 1; argv[i][j]; ++j) {
-			const char o = argv[i][j];
-			if (o == 'p') protein = 1; else if (o == 'c') path = 1; else if (o == 'r') reverse = 1;
-			else if (o == 's') sam = 1; else if (o == 'h') header = 1;
-			else if (o == 'm' || o == 'x' || o == 'o' || o == 'e' || o == 'f' || o == 'a' || o == 'b' || o == 'g') {
-				const char* val = argv[i][j + 1] ? &argv[i][j + 1] : (i + 1 < argc ? argv[++i] : 0);
-				if (!val) { usage(); return 1; }
-				if (o == 'm') match = atoi(val); else if (o == 'x') mismatch = atoi(val); else if (o == 'o') gap_open = atoi(val);
-				else if (o == 'e') gap_ext = atoi(val); else if (o == 'f') filter = atoi(val); else if (o == 'b') batch = atoi(val); else if (o == 'g') gpus = atoi(val);
-				else mat_name = val;
-				break;
-			}
-		}
-	}
-	if (nfiles < 2) { usage(); return 1; }
+	const char* files[2] = {0, 0};
+	cli_opts o = {&match, &mismatch, &gap_open, &gap_ext, &filter, &batch, &gpus, &protein, &path, &reverse, &sam, &header, &mat_name};
+	const char* mode = getenv("SSW_CLI_ARGS");
+	if (mode && !strcmp(mode, "getopt")) { if (scan_args_getopt(argc, argv, &o, files)) { usage(); return 1; } }
+	else if (scan_args_reference(argc, argv, &o, files)) { usage(); return 1; }
 	if (batch < 1) batch = 1;
 	cli_trace_on = getenv("SSW_CLI_TRACE") != 0; cli_t0 = cli_now();
 	init_tables();
@@ -470,16 +539,22 @@ int main(int argc, char* const argv[])
 	const int reverse_fatal = reverse && n == 24;
 	if (reverse && (n != 5 || protein)) reverse = 0;
 
-	/* the target file is read once */
+	/* the reference's order (src/main.c:434-449): the query file is opened first -- a failure ends the run before a byte is written -- */
+	gzFile qf = gzopen(files[1], "r");
+	if (!qf) { fprintf(stderr, "gzopen of '%s' failed.\n", files[1]); return EXIT_FAILURE; }
+	/* -- and the target file is read once.  One that cannot be opened is a target set without sequences there (kseq reads nothing from a
+	   NULL handle, src/main.c:493-495): no alignment lines, exit code 0; said on stderr here */
 	reader tr; memset(&tr, 0, sizeof tr);
 	tr.f = gzopen(files[0], "r");
-	if (!tr.f) { fprintf(stderr, "gzopen of '%s' failed.\n", files[0]); return EXIT_FAILURE; }
 	record* targets = 0; int32_t nt = 0, capt = 0;
-	for (record rec; read_record(&tr, &rec); ) {
-		if (nt == capt) { capt = capt ? capt * 2 : 16; targets = (record*)xrealloc(targets, sizeof(record) * capt); }
-		targets[nt++] = rec;
+	if (!tr.f) fprintf(stderr, "ssw_test_gpu: gzopen of the target file '%s' failed: no target sequences.\n", files[0]);
+	else {
+		for (record rec; read_record(&tr, &rec); ) {
+			if (nt == capt) { capt = capt ? capt * 2 : 16; targets = (record*)xrealloc(targets, sizeof(record) * capt); }
+			targets[nt++] = rec;
+		}
+		gzclose(tr.f);
 	}
-	gzclose(tr.f);
 	CLI_TRACE("target file parsed: %d sequences", nt);
 	if (sam && header && path) {
 		fprintf(stdout, "@HD\tVN:1.4\tSO:queryname\n");
@@ -522,7 +597,7 @@ int main(int argc, char* const argv[])
 	/* ---- three stages on three threads, two batches in flight between each pair of them (reference loop: src/main.c:462-526):
 	       parse (file -> records + one ASCII block)  ->  device (upload + translation + alignment)  ->  format + write (this thread) */
 	pipeline pl; memset(&pl, 0, sizeof pl);
-	pl.qfile = files[1]; pl.batch = batch; pl.reverse = reverse; pl.reverse_fatal = reverse_fatal; pl.table = table; pl.nt_table = table == nt_code;
+	pl.qf = qf; pl.batch = batch; pl.reverse = reverse; pl.reverse_fatal = reverse_fatal; pl.table = table; pl.nt_table = table == nt_code;
 	pl.g = g; pl.gp = gp; pl.T = T; pl.nt = nt;
 	pl.prm.mat = mat; pl.prm.n = n; pl.prm.gapO = (uint8_t)gap_open; pl.prm.gapE = (uint8_t)gap_ext; pl.prm.flag = path ? 2 : 0; pl.prm.filters = (uint16_t)filter;
 	pl.prm.filterd = 0; pl.prm.maskLen = -1; pl.prm.score_size = 2; pl.prm.mark_mismatch = sam ? 1 : 0;

@@ -62,6 +62,8 @@ typedef struct {
 	int trace_many;         /* SSW_GPU_TRACE_MANY=<n>: a traceback round with more than n pending alignments sizes its teams for throughput (tests: 0); default 4096 */
 	int trace_early;        /* SSW_GPU_TRACE_EARLY=<n>: batches of at least n tracebacks start the teams of the alignments that are wide from the start beside round 0.  Built and measured in
 	                           round 6: SLOWER (config 4's traceback 175 -> 221 ms), off by default (0 / unset: never) -- kept with its tests as the measured form of "overlap the tail" */
+	int pipe_low_prio;      /* SSW_GPU_PIPE_PRIO=low: the extra streams of a pipelined series at the LOWEST dispatch priority (the first form of round 6; measured slower) */
+	int pipe_parts;         /* SSW_GPU_PIPE_PARTS=2..8: the number of scratch parts / streams of a pipelined series (default 2; more were measured slower) */
 	int no_pipe;            /* SSW_GPU_PIPE=0: the launches of a chunked short-query bucket one after the other on the main stream (the form before round 6) */
 	int no_lit_spec;        /* SSW_GPU_LIT_SPEC=0: the lane-model kernel runs its 16-bit rules after the 8-bit ones (never both side by side: the form before round 6) */
 	int trace_no_cls80;     /* SSW_GPU_TRACE_CLS80=0: no 80-KiB LDS class for the traceback teams (the classes before round 6) */
@@ -84,7 +86,7 @@ struct ssw_gpu_ctx {
 	int device;
 	void* stream;
 	void* stream2;                      /* reductions of chunk i overlap the fill of chunk i+1 */
-	void* pstream;                      /* lowest dispatch priority: the odd launches of a pipelined series of fills (align_batch "pipe"), created with the first such series */
+	void* pstream[7]; void* ev_pipe[7]; /* launches 1, 2, .. (mod the number of parts) of a pipelined series of fills (align_batch "pipe"), created with the first series that needs them */
 	void* ustream;                      /* sequence uploads / translation (ssw_gpu_seqs_*): beside a running batch call, see upload_stream() */
 	void* tstream[SSW_TSTREAMS]; void* tev[SSW_TSTREAMS];   /* traceback classes of one negotiation round run side by side */
 	void *ev_fill[2], *ev_red[2];
@@ -163,6 +165,8 @@ static void knobs_load(ssw_knobs* k)
 	k->trace_no_cls80 = env_is("SSW_GPU_TRACE_CLS80", '0');
 	k->no_lit_spec = env_is("SSW_GPU_LIT_SPEC", '0');
 	k->no_pipe = env_is("SSW_GPU_PIPE", '0');
+	k->pipe_low_prio = env_is("SSW_GPU_PIPE_PRIO", 'l');
+	{ const int v = env_int("SSW_GPU_PIPE_PARTS", 0); k->pipe_parts = v >= 2 && v <= 8 ? v : 0; }
 	k->trace_early = env_int("SSW_GPU_TRACE_EARLY", 0);
 	k->no_tail = env_is("SSW_GPU_NO_TAIL", '1');
 	{ const int v = env_int("SSW_GPU_DB_TSUB", 0); k->db_tsub = v > 0 ? v : 0; }
@@ -321,7 +325,7 @@ void ssw_gpu_close(ssw_gpu_ctx* c)
 	ssw_shim_event_destroy(c->ev_t0); ssw_shim_event_destroy(c->ev_a); ssw_shim_event_destroy(c->ev_b);
 	ssw_shim_event_destroy(c->ev_c); ssw_shim_event_destroy(c->ev_d); ssw_shim_event_destroy(c->ev_db);
 	for (int i = 0; i < 2; ++i) { ssw_shim_event_destroy(c->ev_fill[i]); ssw_shim_event_destroy(c->ev_red[i]); }
-	ssw_shim_stream_destroy(c->stream2); ssw_shim_stream_destroy(c->ustream); ssw_shim_stream_destroy(c->pstream);
+	ssw_shim_stream_destroy(c->stream2); ssw_shim_stream_destroy(c->ustream); for (int i = 0; i < 7; ++i) { ssw_shim_stream_destroy(c->pstream[i]); ssw_shim_event_destroy(c->ev_pipe[i]); }
 	for (int i = 0; i < SSW_TSTREAMS; ++i) { ssw_shim_stream_destroy(c->tstream[i]); ssw_shim_event_destroy(c->tev[i]); }
 	ssw_shim_stream_destroy(c->stream);
 	pthread_mutex_destroy(&c->mu);
@@ -518,7 +522,7 @@ typedef struct { int32_t R, strips, P16, lanes, use_x; int32_t first_pair, npair
    fit the budget together run side by side on the side streams, each in its own slice of the scratch buffers) */
 typedef struct {
 	int active, dbl, seg;
-	int pipe;                               /* the bucket's launches alternate between the main stream and a low-priority one, each with its own half of the scratch (below) */
+	int pipe;                               /* 0, or the number of parts (2 unless a hook says otherwise): the launches of the bucket go round the main stream and the extra one(s), each with its own part of the scratch (below) */
 	int32_t tile, halo, ntiles;
 	int64_t maxcols, chunk;
 	size_t cm_bytes, sg_bytes, bnd_bytes, cand_bytes, q_ints, cs_ints;      /* scratch of one launch */
@@ -1854,12 +1858,19 @@ plan_again:
 				   run them one after the other on one stream, and every launch ended with a last, partly filled round of workgroups: all
 				   workgroups of a launch take the same ~50 ms (config 2), so the device drains for most of a workgroup's duration at two or three
 				   workgroups per compute unit instead of seven -- three times per 100 000 reads at a whole-HBM budget, 25 times at 16 GiB (-4 %).
-				   Now the launches alternate between the main stream and a stream of the LOWEST dispatch priority, each with its own half of
-				   the scratch: the command processor hands out the low-priority launch's workgroups only where the other launch has none
-				   left to hand out -- it fills the drain of its predecessor and is overtaken again by its successor.  Same work, same
-				   records; only the order in which workgroups reach the compute units changes. */
+				   Now the launches alternate between the main stream and a second stream, each with its own half of the scratch: the two
+				   launches in flight share the compute units, each one's drain and reduction is covered by the other, and launch i + 2 follows
+				   the reduction of launch i on its stream.  Same work, same records; only the order in which workgroups reach the compute
+				   units changes.  The second stream has the main stream's priority: at the LOWEST priority (the first form; SSW_GPU_PIPE_PRIO=low
+				   in the hooks build) its launches only got the slots the main stream's left over, fell behind and ran out the series alone --
+				   config 2 on one box, two / four / eight parts at the lowest priority against two at equal priority: 10 073 / 10 211 / 10 282 /
+				   10 353 GCUPS under 16 GiB, 10 377 / 10 446 / 10 423 / 10 480 under 64 GiB, 10 398-10 437 / 10 413 / 10 443 / 10 469-10 514 with
+				   the whole HBM; more than two parts at equal priority lose again (10 127 under 64 GiB: the streams share hardware queues).
+				   profiles/round6_pipeline_parts.txt. */
 				const int pipe = !use_x && !dbl && chunk < B->npairs && !c->kn.no_pipe;
-				if (dbl || pipe) chunk = (int64_t)((c->cm_budget / 2) / (size_t)per_pair);
+				int parts = dbl || pipe ? 2 : 1;
+				if (pipe && c->kn.pipe_parts) parts = c->kn.pipe_parts;
+				if (parts > 1) chunk = (int64_t)((c->cm_budget / (size_t)parts) / (size_t)per_pair);
 				if (chunk < 1) chunk = 1;
 				if (chunk > B->npairs) chunk = B->npairs;
 				if (!use_x && chunk < B->npairs) {
@@ -1875,10 +1886,10 @@ plan_again:
 					if (even <= chunk) chunk = even;
 					else if (chunk >= unit) chunk = chunk / unit * unit;
 				}
-				P->tile = tile; P->halo = halo; P->ntiles = ntiles; P->maxcols = maxcols; P->chunk = chunk; P->dbl = dbl; P->pipe = pipe && chunk < B->npairs;
+				P->tile = tile; P->halo = halo; P->ntiles = ntiles; P->maxcols = maxcols; P->chunk = chunk; P->dbl = dbl; P->pipe = pipe && chunk < B->npairs ? parts : 0;
 				P->seg = !dbl && !c->kn.no_seg_reduce ;      /* the fill kernels also leave the maxima of 16-column groups, which is all the reduction reads */
-				P->cm_bytes = ALIGN16(4 * stride * chunk) * (P->pipe ? 2 : 1);      /* (pipe: two sets, one per stream) */
-				P->sg_bytes = P->seg ? ALIGN16(4 * seg_stride * chunk) * (P->pipe ? 2 : 1) : 0;
+				P->cm_bytes = ALIGN16(4 * stride * chunk) * (P->pipe ? P->pipe : 1);      /* (pipe: one set per stream) */
+				P->sg_bytes = P->seg ? ALIGN16(4 * seg_stride * chunk) * (P->pipe ? P->pipe : 1) : 0;
 				P->bnd_bytes = use_x ? ALIGN16(16 * maxcols * ntiles * chunk) : 0;
 				P->cand_bytes = use_x ? ALIGN16(32 * ntiles * chunk) : 0;   /* 2 halves x 4 ints per job */
 				if (use_x && B->lanes == 64) { P->q_ints = chainq_queue_ints(chunk * ntiles * B->strips); P->cs_ints = chainq_cands_ints(chunk * ntiles * B->strips); }
@@ -1972,25 +1983,28 @@ plan_again:
 				uint32_t* d_cmB16 = dbl ? (uint32_t*)base_cmB16 : d_cmA16; uint32_t* d_cmB8 = dbl ? (uint32_t*)base_cmB8 : d_cmA8;
 				uint32_t* d_sg16 = P->seg ? (uint32_t*)(base_sg16 + P->sg_off) : 0; uint32_t* d_sg8 = P->seg ? (uint32_t*)(base_sg8 + P->sg_off) : 0;
 				int launch_i = 0;
-				const int pipe = P->pipe && !conc;
+				const int pipe = conc ? 0 : P->pipe;      /* the number of parts: 0 (not pipelined), 2..4 */
 				void *pe0 = 0, *pe1 = 0;
 				if (pipe) {
-					if (!c->pstream) c->pstream = ssw_shim_stream_create_low();
-					if (!c->pstream) { fail(c, "stream creation failed: %s", ssw_shim_last_error()); goto done; }
 					pe0 = next_event(c); pe1 = next_event(c);
-					/* (the low-priority stream starts after everything the main stream has queued so far: the call's uploads, the record memset) */
-					if (ssw_shim_event_record(pe0, c->stream) || ssw_shim_stream_wait_event(c->pstream, pe0)) { fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; }
-					d_cmB16 = (uint32_t*)((unsigned char*)d_cmA16 + P->cm_bytes / 2); d_cmB8 = (uint32_t*)((unsigned char*)d_cmA8 + P->cm_bytes / 2);
+					if (ssw_shim_event_record(pe0, c->stream)) { fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; }
+					for (int k = 0; k < pipe - 1; ++k) {
+						if (!c->pstream[k]) { c->pstream[k] = c->kn.pipe_low_prio ? ssw_shim_stream_create_low() : ssw_shim_stream_create(); c->ev_pipe[k] = ssw_shim_event_create(); }
+						if (!c->pstream[k] || !c->ev_pipe[k]) { fail(c, "stream creation failed: %s", ssw_shim_last_error()); goto done; }
+						/* (the low-priority streams start after everything the main stream has queued so far: the call's uploads, the record memset) */
+						if (ssw_shim_stream_wait_event(c->pstream[k], pe0)) { fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; }
+					}
 				}
 				uint32_t* const d_sgA16 = d_sg16; uint32_t* const d_sgA8 = d_sg8;
 				for (int32_t p0 = 0; p0 < B->npairs; p0 += (int32_t)chunk, ++launch_i) {
 					const int32_t np = B->npairs - p0 < chunk ? B->npairs - p0 : (int32_t)chunk;
-					const int bi = dbl || pipe ? (launch_i & 1) : 0;
+					const int bi = pipe ? launch_i % pipe : dbl ? (launch_i & 1) : 0;
 					uint32_t* d_cm16 = bi ? d_cmB16 : d_cmA16; uint32_t* d_cm8 = bi ? d_cmB8 : d_cmA8;
-					if (pipe) {      /* odd launches: the other half of the scratch, the low-priority stream (in order on it: launch i + 2 follows the reduction of launch i) */
-						st = bi ? c->pstream : c->stream;
-						d_sg16 = P->seg ? (uint32_t*)((unsigned char*)d_sgA16 + (bi ? P->sg_bytes / 2 : 0)) : 0;
-						d_sg8 = P->seg ? (uint32_t*)((unsigned char*)d_sgA8 + (bi ? P->sg_bytes / 2 : 0)) : 0;
+					if (pipe) {      /* launch i: part i mod parts of the scratch; parts 1.. on the low-priority streams (in order on each: launch i + parts follows the reduction of launch i) */
+						st = bi ? c->pstream[bi - 1] : c->stream;
+						d_cm16 = (uint32_t*)((unsigned char*)d_cmA16 + (size_t)bi * (P->cm_bytes / (size_t)pipe)); d_cm8 = (uint32_t*)((unsigned char*)d_cmA8 + (size_t)bi * (P->cm_bytes / (size_t)pipe));
+						d_sg16 = P->seg ? (uint32_t*)((unsigned char*)d_sgA16 + (size_t)bi * (P->sg_bytes / (size_t)pipe)) : 0;
+						d_sg8 = P->seg ? (uint32_t*)((unsigned char*)d_sgA8 + (size_t)bi * (P->sg_bytes / (size_t)pipe)) : 0;
 					}
 					if (dbl && launch_i >= 2) ssw_shim_stream_wait_event(c->stream, c->ev_red[bi]);    /* the buffer set is free again */
 					ssw_fill_args fa;
@@ -2069,10 +2083,10 @@ plan_again:
 					ssw_shim_stream_wait_event(c->stream, c->ev_red[0]);
 					if (launch_i > 1) ssw_shim_stream_wait_event(c->stream, c->ev_red[1]);
 				}
-				if (pipe) {   /* the main stream continues after the low-priority stream's last reduction; the series is timed as one (its reductions included: ~0.1 ms each) */
-					if (ssw_shim_event_record(c->ev_red[1], c->pstream) || ssw_shim_stream_wait_event(c->stream, c->ev_red[1]) || ssw_shim_event_record(pe1, c->stream)) {
-						fail(c, "stream join failed: %s", ssw_shim_last_error()); goto done;
-					}
+				if (pipe) {   /* the main stream continues after the low-priority streams' last reductions; the series is timed as one (its reductions included: ~0.1 ms each) */
+					for (int k = 0; k < pipe - 1; ++k)
+						if (ssw_shim_event_record(c->ev_pipe[k], c->pstream[k]) || ssw_shim_stream_wait_event(c->stream, c->ev_pipe[k])) { fail(c, "stream join failed: %s", ssw_shim_last_error()); goto done; }
+					if (ssw_shim_event_record(pe1, c->stream)) { fail(c, "stream join failed: %s", ssw_shim_last_error()); goto done; }
 					st = c->stream;
 				}
 			}

@@ -626,12 +626,14 @@ def test_lane_model_kernel_rule_sets_side_by_side_or_in_sequence(ectx, spec, mon
     _run(ectx, reads[:3], [ref], dna_matrix(5, 4), 5, 1, 1, flag=1)      # match 5: 150 x 5 = 750, deep into the 16-bit rules
 
 
-@pytest.mark.parametrize("pipe", ["1", "0"])
+@pytest.mark.parametrize("pipe", ["1", "0", "parts2", "parts3", "parts4"])
 def test_chunked_bucket_launches_pipelined_or_serial(emu_lib_path, pipe, monkeypatch):
-    """round 6: a short-query bucket whose column maxima do not fit the budget at once runs its launches alternately on the main stream and on a
-    lowest-priority stream, each with half of the scratch (default), or one after the other (SSW_GPU_PIPE=0): same records either way, and the
-    timing says which form ran.  Two buckets (100- and 150-bp reads), score only and with begin / CIGAR, an odd number of launches."""
-    monkeypatch.setenv("SSW_GPU_PIPE", pipe)
+    """round 6: a short-query bucket whose column maxima do not fit the budget at once runs its launches in turn on the main stream and on a second
+    stream, each with its own half of the scratch (default; SSW_GPU_PIPE_PARTS = more streams and parts, measured slower on the MI355X), or one
+    after the other (SSW_GPU_PIPE=0): same records either way, and the timing says which form ran.  Two buckets (100- and 150-bp reads), score
+    only and with begin / CIGAR, a number of launches that no number of parts divides."""
+    if pipe.startswith("parts"): monkeypatch.setenv("SSW_GPU_PIPE_PARTS", pipe[5:]); pipe = "1"
+    else: monkeypatch.setenv("SSW_GPU_PIPE", pipe)
     lib = ssw_amd.load(emu_lib_path)
     ctx = ssw_amd.Context(0, lib)
     try:
