@@ -474,9 +474,9 @@ def bench_dna(args, world, rank, local_rank, dist):
                                "measured_peak_probe": round(probe / 1e12, 2), "ops_per_pair_row": ops,
                                "launch_ms": round(launch_ms, 3), "launches": int(acc["fill_launches"]),
                                "launches_pipelined": int(acc.get("fill_pipelined", 0)),
-                               "launch_note": ("the %d fill launches of a step overlap (pipelined series: main stream / lowest-priority stream alternately, each with half of the scratch): "
-                                               "launch_ms = the HIP-event bracket around the series / launches; a rocprofv3 trace shows LONGER kernel durations (a low-priority launch "
-                                               "waits, dispatched, while its neighbours have workgroups to hand out) -- compare with union_ns of profiles/*_kernel_stats.csv"
+                               "launch_note": ("the %d fill launches of a step overlap (pipelined series: main stream / a second stream alternately, each with half of the scratch, two launches in flight): "
+                                               "launch_ms = the HIP-event bracket around the series / launches; a rocprofv3 trace shows LONGER kernel durations (two launches "
+                                               "share the compute units) -- compare with union_ns of profiles/*_kernel_stats.csv"
                                                % (acc["fill_launches"] // max(1, args.steps))) if acc.get("fill_pipelined", 0) else "serial launches: launch_ms is the kernel's average duration",
                                "fill_gcups_padded": round(acc["fill_cells"] / fill_s / 1e9, 1) if fill_s > 0 else 0.0,
                                "peak_note": "integer max-plus recurrence: neither MFMA nor HBM binds, the issue of vector instructions does.  `achieved` = readLen x refLen cells "
@@ -526,7 +526,7 @@ def bench_dna(args, world, rank, local_rank, dist):
                     out["value_default_budget"] = {"value": round(cells_per_step / d2 / 1e9, 2), "unit": "GCUPS", "scratch_budget_gib": round(b2 / 2.0 ** 30, 1),
                                                    "fill_launches_per_step": int(ctx2.timing()["fill_launches"]),
                                                    "note": "same batch, a second context with the library's default budget; `value` ran under ssw_gpu_set_budget_exclusive "
-                                                           "(%.1f GiB); the budget sweep is profiles/round5_budget_sweep_config2.txt" % (budget / 2.0 ** 30)}
+                                                           "(%.1f GiB); budget sweeps: profiles/round6_pipeline_parts.txt, round5_budget_sweep_config2.txt" % (budget / 2.0 ** 30)}
                     Qd.free(); Td.free(); ctx2.close()
                 except Exception as e:      # the metric's line must survive a failure here
                     out["value_default_budget"] = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -1991,7 +1991,7 @@ plan_again:
 					for (int k = 0; k < pipe - 1; ++k) {
 						if (!c->pstream[k]) { c->pstream[k] = c->kn.pipe_low_prio ? ssw_shim_stream_create_low() : ssw_shim_stream_create(); c->ev_pipe[k] = ssw_shim_event_create(); }
 						if (!c->pstream[k] || !c->ev_pipe[k]) { fail(c, "stream creation failed: %s", ssw_shim_last_error()); goto done; }
-						/* (the low-priority streams start after everything the main stream has queued so far: the call's uploads, the record memset) */
+						/* (the extra streams start after everything the main stream has queued so far: the call's uploads, the record memset) */
 						if (ssw_shim_stream_wait_event(c->pstream[k], pe0)) { fail(c, "stream wait failed: %s", ssw_shim_last_error()); goto done; }
 					}
 				}
@@ -2000,7 +2000,7 @@ plan_again:
 					const int32_t np = B->npairs - p0 < chunk ? B->npairs - p0 : (int32_t)chunk;
 					const int bi = pipe ? launch_i % pipe : dbl ? (launch_i & 1) : 0;
 					uint32_t* d_cm16 = bi ? d_cmB16 : d_cmA16; uint32_t* d_cm8 = bi ? d_cmB8 : d_cmA8;
-					if (pipe) {      /* launch i: part i mod parts of the scratch; parts 1.. on the low-priority streams (in order on each: launch i + parts follows the reduction of launch i) */
+					if (pipe) {      /* launch i: part i mod parts of the scratch; parts 1.. on the extra streams (in order on each: launch i + parts follows the reduction of launch i) */
 						st = bi ? c->pstream[bi - 1] : c->stream;
 						d_cm16 = (uint32_t*)((unsigned char*)d_cmA16 + (size_t)bi * (P->cm_bytes / (size_t)pipe)); d_cm8 = (uint32_t*)((unsigned char*)d_cmA8 + (size_t)bi * (P->cm_bytes / (size_t)pipe));
 						d_sg16 = P->seg ? (uint32_t*)((unsigned char*)d_sgA16 + (size_t)bi * (P->sg_bytes / (size_t)pipe)) : 0;
@@ -2083,7 +2083,7 @@ plan_again:
 					ssw_shim_stream_wait_event(c->stream, c->ev_red[0]);
 					if (launch_i > 1) ssw_shim_stream_wait_event(c->stream, c->ev_red[1]);
 				}
-				if (pipe) {   /* the main stream continues after the low-priority streams' last reductions; the series is timed as one (its reductions included: ~0.1 ms each) */
+				if (pipe) {   /* the main stream continues after the extra streams' last reductions; the series is timed as one (its reductions included: ~0.1 ms each) */
 					for (int k = 0; k < pipe - 1; ++k)
 						if (ssw_shim_event_record(c->ev_pipe[k], c->pstream[k]) || ssw_shim_stream_wait_event(c->stream, c->ev_pipe[k])) { fail(c, "stream join failed: %s", ssw_shim_last_error()); goto done; }
 					if (ssw_shim_event_record(pe1, c->stream)) { fail(c, "stream join failed: %s", ssw_shim_last_error()); goto done; }

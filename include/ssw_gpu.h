@@ -80,7 +80,7 @@ typedef struct {
 	int32_t fill_rows_per_lane;
 	int32_t fill_strips;
 	int64_t db_repeats;    /* (rounds 1-2: workgroups of the database search that repeated in the int16 form; always 0 since the column-frame form) */
-	int64_t fill_pipelined; /* fill launches of the call that ran as a PIPELINED series (main stream / lowest-priority stream alternately, round 6): they overlap,
+	int64_t fill_pipelined; /* fill launches of the call that ran as a PIPELINED series (main stream / a second stream alternately, two launches in flight, round 6): they overlap,
 	                           fill_ms brackets each series as a whole -- fill_ms / fill_launches is then the series' time per launch, not a kernel's duration */
 	/* new fields are only ever appended here; ssw_gpu_last_timing_sized lets a caller built against an older header keep its layout */
 } ssw_gpu_timing;

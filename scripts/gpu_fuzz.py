@@ -6,7 +6,9 @@ each -- round-5 verdict: no fuzzer drew them, which is how an out-of-bounds of t
 database path from four targets on), ALL CALLS ON ONE LONG-LIVED CONTEXT (what a call leaves in the pooled buffers is the next call's
 environment).  Every record and CIGAR is compared (tests/parity.py); one call in six that returns CIGARs runs again with mark_mismatch (the device's
 '=' / 'X' / soft-clip rewrite and edit distance against the reference's own mark_mismatch() on the raw CIGAR); a call that fails is counted separately from a wrong value.
-usage: gpu_fuzz.py <seconds> <seed> [--emu | --lib <path>] [--only <k>]        -> one JSON line   (--only: just call k of the seed; SSW_FUZZ_TRACE=1: the parameters of every call on stderr before it runs)
+--budget: every call under a scratch budget drawn anew (1 MiB .. 64 MiB, now and then the default) and batches of up to 300 queries against targets of up to 4 000
+residues, so that the chunked paths run: pipelined series of fill launches, traceback rounds cut by the budget, database size classes cut into several launches.
+usage: gpu_fuzz.py <seconds> <seed> [--emu | --lib <path>] [--only <k>] [--budget]        -> one JSON line   (--only: just call k of the seed; SSW_FUZZ_TRACE=1: the parameters of every call on stderr before it runs)
 (--lib: another build of the emulated library, e.g. the AddressSanitizer one of scripts/asan_emu_fuzz.sh)"""
 import json
 import os
@@ -25,6 +27,7 @@ secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 emu = "--emu" in sys.argv
 only = int(sys.argv[sys.argv.index("--only") + 1]) if "--only" in sys.argv else 0
+small_budget = "--budget" in sys.argv
 libpath = sys.argv[sys.argv.index("--lib") + 1] if "--lib" in sys.argv else os.path.join(ROOT, "tests", "emu", "libssw_emu.so") if emu else None
 emu = emu or "--lib" in sys.argv
 lib = ssw_amd.load(libpath)
@@ -37,7 +40,7 @@ from sswutil import ref_lib      # noqa: E402
 R = ref_lib(required=True)
 libc = C.CDLL(None); libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]; libc.free.argtypes = [C.c_void_p]
 u32p = C.POINTER(C.c_uint32); i8p = C.POINTER(C.c_int8)
-regimes = {"multi_strip_queries": 0, "alphabet>32": 0, "gapO>gapE": 0, "gapO<=gapE": 0, "gapO=0": 0, "db_path": 0, "calls_with_empty_query": 0, "calls_with_empty_target": 0}
+regimes = {"small_budget_calls": 0, "calls_with_pipelined_fill_launches": 0, "multi_strip_queries": 0, "alphabet>32": 0, "gapO>gapE": 0, "gapO<=gapE": 0, "gapO=0": 0, "db_path": 0, "calls_with_empty_query": 0, "calls_with_empty_target": 0}
 first = []
 while time.time() < t_end:
     kind = rng.random()
@@ -71,6 +74,16 @@ while time.time() < t_end:
     nq = int(rng.integers(1, 10))
     lens = rng.integers(1, 701, size=nq) if rng.random() < 0.3 else rng.integers(1, 160, size=nq)
     if rng.random() < 0.06: lens = rng.integers(700, 2600, size=nq)      # several row strips of the 64-lane strip kernel (768 rows each at 12 per lane), their window passes, team tracebacks
+    if small_budget:      # (draws of its own: the default mode's sequence of calls does not change)
+        big = rng.random() < 0.6
+        if big:
+            nq = int(rng.integers(20, 301 if not emu else 61))
+            lens = rng.integers(1, 160, size=nq) if rng.random() < 0.7 else rng.integers(100, 420, size=nq)
+            if rng.random() < 0.5: lens[:] = int(lens[0])      # one geometry bucket: ONE series of launches
+            refs = [rng.integers(0, nc, size=int(rng.integers(500, 4001 if not emu else 1501)), dtype=np.int8) for _ in range(nt)]
+        budget = int(rng.choice([1, 1, 2, 4, 16, 64, 0])) << 20
+        lib.ssw_gpu_set_budget(ctx.h, budget)
+        regimes["small_budget_calls"] += int(budget != 0)
     lens = np.where(rng.random(nq) < 0.07, 0, lens)
     reads = make_reads(rng, max(refs, key=len), nq, lens, nc, sub=0.06 if nc > 1 else 0.0, frac_random=0.3)      # (one letter: nothing to substitute)
     regimes["calls_with_empty_query"] += int((lens == 0).any()); regimes["calls_with_empty_target"] += int(any(len(r) == 0 for r in refs))
@@ -96,6 +109,7 @@ while time.time() < t_end:
         continue
     finally:
         Q.free(); T.free()
+    if small_budget: regimes["calls_with_pipelined_fill_launches"] += int(ctx.timing().get("fill_pipelined", 0) > 0)
     bad = compare_batch(res, cig, reads, refs, mat, n, gapO, gapE, flag, filters, filterd, maskLen, ss, max_report=2)
     # one call in six that returns CIGARs again with ssw_gpu_params.mark_mismatch: the device's k_mark against the reference's own mark_mismatch() on the raw CIGAR
     if not bad and rng.random() < 0.17 and int((res["cigarLen"] > 0).sum()) > 0:

@@ -29,8 +29,8 @@ for cfg in (2, 4, 5, 6):
         rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), max(sgpr_count), "
                           "max(lds_size), max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
         tot = sum(r[2] for r in rows) or 1
-        # round 6: launches of one kernel may OVERLAP (the pipelined fill series of ssw_host.c: a low-priority launch waits, dispatched, while its
-        # predecessor and successor have workgroups to hand out -- its duration is not its service time).  union_ns = the wall time during which
+        # round 6: launches of one kernel may OVERLAP (the pipelined fill series of ssw_host.c: two launches in flight share the compute units
+        # -- a launch's duration is not its service time).  union_ns = the wall time during which
         # at least one dispatch of the kernel was running: for serial launches it equals total_ns, for a pipelined series it is the series' length.
         cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
         union = {}
@@ -46,7 +46,7 @@ for cfg in (2, 4, 5, 6):
                 union[name] = u
         with open(os.path.join(out_dir, ROUND + "_config%d_kernel_stats.csv" % cfg), "w") as f:
             f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --config %d --steps 1 --warmup %d --cpu-sample 0 [--also none] --plain   (durations in ns; vgpr = the trace record's arch_vgpr field, NOT the allocation: the code objects say 72 for k_fill<10,frame>)\n" % (cfg, 0 if cfg == 5 else 1))
-            f.write("# union_ns: wall time with at least one dispatch of the kernel running.  The fill launches of a bucket that needs several of them are PIPELINED since round 6 (main stream / lowest-priority\n")
+            f.write("# union_ns: wall time with at least one dispatch of the kernel running.  The fill launches of a bucket that needs several of them are PIPELINED since round 6 (main stream / a second\n")
             f.write("# stream alternately): their durations overlap, total_ns and avg_ns count waiting -- union_ns / passes over the batch is the fill time bench.py brackets with HIP events (roofline.launch_ms x launches).\n")
             f.write("kernel,calls,total_ns,avg_ns,min_ns,max_ns,percent,vgpr,sgpr,lds_bytes,max_grid_x,workgroup_x,union_ns\n")
             for r in rows:
