@@ -5,7 +5,9 @@ same entry point), query / entry lengths 0..700 (above 640 residues: generic pat
 function that stops the stream at a random chunk, score_size 0 / 1 / 2.  Checked per call: (a) the batch records equal the reference's (tests/parity.py),
 (b) the assembled hits equal the batch records field by field (a pair the reference answers with NULL carries ref_end2 = -2), (c) the chunks arrive in
 order with the promised sizes, (d) a stop code comes back as the call's return value and nothing later is delivered.
-usage: db_fuzz.py <seconds> <seed> [--emu | --lib <path>]        -> one JSON line"""
+--budget: every call under a scratch budget drawn anew (1 MiB .. 16 MiB, now and then the default), up to 60 queries x 200 entries: size classes that do not fit
+their slice of the scratch are cut into several launches, the generic path's batches are chunked.  A call that the library REFUSES for its budget counts separately.
+usage: db_fuzz.py <seconds> <seed> [--emu | --lib <path>] [--budget]        -> one JSON line"""
 import json
 import os
 import sys
@@ -25,7 +27,9 @@ libpath = sys.argv[sys.argv.index("--lib") + 1] if "--lib" in sys.argv else os.p
 ctx = ssw_amd.Context(0, ssw_amd.load(libpath))
 rng = np.random.default_rng(seed)
 t_end = time.time() + secs
-calls = pairs = wrong = stops = generic = 0
+calls = pairs = wrong = stops = generic = refused = 0
+small_budget = "--budget" in sys.argv
+emu_ = "--emu" in sys.argv or "--lib" in sys.argv
 first = []
 FIELDS = ("score1", "score2", "ref_end1", "read_end1", "ref_end2")
 while time.time() < t_end:
@@ -43,6 +47,9 @@ while time.time() < t_end:
         gapO = int(rng.integers(0, 6)); gapE = gapO + int(rng.integers(0, 4))
     nt = int(rng.integers(1, 41)); nq = int(rng.integers(1, 9))
     tmax = 700 if rng.random() < 0.1 else 300
+    if small_budget:      # (draws of its own)
+        if rng.random() < 0.6: nt = int(rng.integers(20, 201 if not emu_ else 61)); nq = int(rng.integers(4, 61 if not emu_ else 17))
+        ctx.lib.ssw_gpu_set_budget(ctx.h, int(rng.choice([1, 1, 2, 4, 16, 0])) << 20)
     db = [rng.integers(0, nc, size=0 if rng.random() < 0.06 else int(rng.integers(1, tmax + 1)), dtype=np.int8) for _ in range(nt)]
     lens = rng.integers(1, 701, size=nq) if rng.random() < 0.25 else rng.integers(1, 330, size=nq)
     lens = np.where(rng.random(nq) < 0.06, 0, lens)
@@ -82,12 +89,13 @@ while time.time() < t_end:
         elif rc != 0: bad.append("search_db returned %d" % rc)
         if seen != want_seen: bad.append("chunks %s, expected %s" % (seen[:4], want_seen[:4]))
     except Exception as e:      # noqa: BLE001
-        bad.append("call failed: " + str(e)[:200])
+        if small_budget and "budget" in str(e): refused += 1; bad = []
+        else: bad.append("call failed: " + str(e)[:200])
     finally:
         Q.free(); T.free()
     if bad:
         wrong += 1
         if len(first) < 5: first.append({"what": bad[0][:300], "n": n, "gapO": gapO, "gapE": gapE, "ss": ss, "nq": nq, "nt": nt, "chunk": chunk, "qlens": [len(q) for q in qs][:8]})
 print(json.dumps({"fuzz": "streamed database search", "seconds": secs, "seed": seed, "library": libpath or "libssw.so on the GPU", "calls": calls, "pairs": pairs, "calls_wrong": wrong,
-                  "calls_on_the_generic_path": generic, "calls_stopped_by_the_caller": stops, "first": first}))
+                  "calls_on_the_generic_path": generic, "small_budgets": small_budget, "calls_refused_for_the_budget": refused, "calls_stopped_by_the_caller": stops, "first": first}))
 sys.exit(1 if wrong else 0)

@@ -181,7 +181,15 @@ def cli_goldens():
             "matrix_file_p_r_ignored": ["-p", "-a", "wt4.tbl", "-c", "-r", "target.fastq", "query.fastq"],
             # alignments whose traceback fails (s_align.flag 1, no CIGAR; SURVEY 8.0 "Quirk"): SAM output still carries the soft
             # clips that mark_mismatch adds (tbfail.fa / tbfail.fq are fixtures of this repo, found by random search)
-            "tbfail_cs": ["-m", "09", "-x", "04", "-c", "-s", "tbfail.fa", "tbfail.fq"], "tbfail_c": ["-m", "09", "-x", "04", "-c", "tbfail.fa", "tbfail.fq"]}
+            "tbfail_cs": ["-m", "09", "-x", "04", "-c", "-s", "tbfail.fa", "tbfail.fq"], "tbfail_c": ["-m", "09", "-x", "04", "-c", "tbfail.fa", "tbfail.fq"],
+            # round 6: what the reference's scanner (main.c:247-330) really does with command lines that are not written for it -- the CLI reproduces it:
+            # a one-character value directly in front of the files: the scan runs on into "r1.fa" / "r1_query.fq" (-r, -f r1.fa, -e r1_query.fq = gap extension 0)
+            "scan_overrun_o5e2": ["-c", "-o", "5", "-e", "2", "r1.fa", "r1_query.fq"],
+            "scan_combined_cs": ["-cs", "target.fastq", "query.fastq"],                                  # every character of a '-' argument is an option letter
+            "scan_m_without_value": ["-m", "-c", "target.fastq", "query.fastq"],                         # a value may not start with '-': -m keeps its default
+            "scan_attached_value_ignored": ["-c", "-x5", "-s", "target.fastq", "query.fastq"],           # "-x5": x takes the NEXT argument unless it starts with '-'; here it does
+            "scan_options_behind_files": ["target.fastq", "query.fastq", "-f", "15", "-c"],
+            "scan_missing_target_csh": ["-c", "-s", "-h", "no_such_file.fa", "query.fastq"]}              # a target file that cannot be opened: header line only, exit code 0
     # fixture of this repo (not a reference file): the first two demo reads with an empty FASTQ record between them
     q = open(os.path.join(DEMO, "query.fastq")).read().split("\n")
     with open(os.path.join(out, "empty_read.fq"), "w") as f:
