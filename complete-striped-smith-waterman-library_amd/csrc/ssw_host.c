@@ -62,6 +62,7 @@ typedef struct {
 	int trace_many;         /* SSW_GPU_TRACE_MANY=<n>: a traceback round with more than n pending alignments sizes its teams for throughput (tests: 0); default 4096 */
 	int trace_early;        /* SSW_GPU_TRACE_EARLY=<n>: batches of at least n tracebacks start the teams of the alignments that are wide from the start beside round 0.  Built and measured in
 	                           round 6: SLOWER (config 4's traceback 175 -> 221 ms), off by default (0 / unset: never) -- kept with its tests as the measured form of "overlap the tail" */
+	int pipe_any_count;     /* SSW_GPU_PIPE_EVEN=0: a pipelined series may have a number of launches that the streams do not share evenly (the form before this was measured) */
 	int pipe_low_prio;      /* SSW_GPU_PIPE_PRIO=low: the extra streams of a pipelined series at the LOWEST dispatch priority (the first form of round 6; measured slower) */
 	int pipe_parts;         /* SSW_GPU_PIPE_PARTS=2..8: the number of scratch parts / streams of a pipelined series (default 2; more were measured slower) */
 	int no_pipe;            /* SSW_GPU_PIPE=0: the launches of a chunked short-query bucket one after the other on the main stream (the form before round 6) */
@@ -166,6 +167,7 @@ static void knobs_load(ssw_knobs* k)
 	k->no_lit_spec = env_is("SSW_GPU_LIT_SPEC", '0');
 	k->no_pipe = env_is("SSW_GPU_PIPE", '0');
 	k->pipe_low_prio = env_is("SSW_GPU_PIPE_PRIO", 'l');
+	k->pipe_any_count = env_is("SSW_GPU_PIPE_EVEN", '0');
 	{ const int v = env_int("SSW_GPU_PIPE_PARTS", 0); k->pipe_parts = v >= 2 && v <= 8 ? v : 0; }
 	k->trace_early = env_int("SSW_GPU_TRACE_EARLY", 0);
 	k->no_tail = env_is("SSW_GPU_NO_TAIL", '1');
@@ -1878,7 +1880,11 @@ plan_again:
 					   than the others: the launches of a bucket get the same number of pairs (not full chunks and a remainder), and that
 					   number makes the workgroup count a multiple of the CU count (256 on an unpartitioned MI355X; read from the device).
 					   16 tiles per pair left 1600 workgroups per launch on a 5 Mb target: 6 or 7 per CU, 12 % lost. */
-					const int64_t bpp = (ntiles + 15) / 16, nl = (B->npairs + chunk - 1) / chunk;
+					const int64_t bpp = (ntiles + 15) / 16;
+					int64_t nl = (B->npairs + chunk - 1) / chunk;
+					/* a pipelined series: as many launches on one stream as on the other, so that both reach the end together (5 launches were 3 + 2: the
+					   last one ran alone, its drain exposed) */
+					if (pipe && parts > 1 && !c->kn.pipe_any_count && nl % parts) nl += parts - nl % parts;
 					int64_t even = (B->npairs + nl - 1) / nl;                      /* pairs per launch if all launches are alike */
 					const int64_t ncu = c->dev_cus;
 					const int64_t unit = ncu / (bpp > ncu ? ncu : bpp) > 0 ? ncu / (bpp > ncu ? ncu : bpp) : 1;      /* pairs that make one workgroup per compute unit */

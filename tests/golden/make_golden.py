@@ -161,6 +161,7 @@ def cli_goldens():
     os.makedirs(out, exist_ok=True)
     for f in ("target.fastq", "query.fastq", "protein1.fa", "protein2.fa", "r1.fa", "r1_query.fq", "1k.fa"):
         shutil.copy(os.path.join(DEMO, f), os.path.join(out, f))
+    shutil.copy(os.path.join(DEMO, "r1.fa"), os.path.join(out, "ref.fa")); shutil.copy(os.path.join(DEMO, "r1_query.fq"), os.path.join(out, "query_reads.fq"))
     runs = {"config1_c": ["-c", "target.fastq", "query.fastq"], "config1_csh": ["-c", "-s", "-h", "target.fastq", "query.fastq"],
             "config1_plain": ["target.fastq", "query.fastq"], "config1_cr": ["-c", "-r", "target.fastq", "query.fastq"],
             "protein_pc": ["-p", "-c", "protein1.fa", "protein2.fa"], "r1_cr": ["-c", "-r", "r1.fa", "r1_query.fq"],
@@ -183,8 +184,10 @@ def cli_goldens():
             # clips that mark_mismatch adds (tbfail.fa / tbfail.fq are fixtures of this repo, found by random search)
             "tbfail_cs": ["-m", "09", "-x", "04", "-c", "-s", "tbfail.fa", "tbfail.fq"], "tbfail_c": ["-m", "09", "-x", "04", "-c", "tbfail.fa", "tbfail.fq"],
             # round 6: what the reference's scanner (main.c:247-330) really does with command lines that are not written for it -- the CLI reproduces it:
-            # a one-character value directly in front of the files: the scan runs on into "r1.fa" / "r1_query.fq" (-r, -f r1.fa, -e r1_query.fq = gap extension 0)
-            "scan_overrun_o5e2": ["-c", "-o", "5", "-e", "2", "r1.fa", "r1_query.fq"],
+            # a one-character value directly in front of the files: the scan runs on into "ref.fa" / "query_reads.fq" (-r, -e ref.fa = gap extension 0, -f query_reads.fq,
+            # -r, -s) and ends on the terminator of the LAST argument -- file names chosen so: a scan that leaves the arguments reads the environment, and the
+            # output would depend on the caller's first environment string (ref.fa / query_reads.fq are copies of r1.fa / r1_query.fq)
+            "scan_overrun_e2": ["-c", "-e", "2", "ref.fa", "query_reads.fq"],
             "scan_combined_cs": ["-cs", "target.fastq", "query.fastq"],                                  # every character of a '-' argument is an option letter
             "scan_m_without_value": ["-m", "-c", "target.fastq", "query.fastq"],                         # a value may not start with '-': -m keeps its default
             "scan_attached_value_ignored": ["-c", "-x5", "-s", "target.fastq", "query.fastq"],           # "-x5": x takes the NEXT argument unless it starts with '-'; here it does

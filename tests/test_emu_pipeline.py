@@ -670,8 +670,15 @@ def test_parked_single_pair_contexts_are_released(emu_lib_path):
         th = [threading.Thread(target=worker) for _ in range(4)]
         [t.start() for t in th]; [t.join() for t in th]
     assert scores == [120] * 12
+    # Thread.join() returns when the Python function has ended -- the OS thread may still be on its way out, and it is its thread-specific destructor that
+    # parks the context: a burst can find the list empty and open new contexts (seen under load: five parked at the end).  The cap is applied by the next LIVE
+    # caller (a dying thread may not call into the runtime): give the threads time to end, make one more call from this thread, then count.
+    import time
+    time.sleep(0.5)
+    worker()
+    assert scores[-1] == 120
     n = lib.ssw_gpu_release_parked()
-    assert 1 <= n <= 4, n      # later bursts took over what the first one parked; never more than four stay parked
+    assert 1 <= n <= 4, n      # never more than four stay parked once a live caller came by
     assert lib.ssw_gpu_release_parked() == 0
 
 
