@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Build container: differential fuzz of the batched CLI (csrc/ssw_cli.c as tests/emu/ssw_test_emu, i.e. on the SIMT emulator) against the reference's own ssw_test, compiled
-here from /root/reference/src (main.c + ssw.c, gcc -O2, into /tmp -- nothing of it enters the repository): random FASTA / FASTQ inputs (several targets, multi-line records,
+"""Differential fuzz of the batched CLI (csrc/ssw_cli.c: tests/emu/ssw_test_emu on the SIMT emulator in the build container, ssw_test_gpu itself with --gpu on the GPU
+box) against the reference's own ssw_test (oracle/_ref/ssw_test_ref: main.c + ssw.c compiled from where they lie by oracle/Makefile `refcli`): random FASTA / FASTQ inputs (several targets, multi-line records,
 lower case, N and other letters, reads of 1..300 residues, DNA and protein), random options (-m -x -o -e -f -c -r -s -h -p).  stdout must be byte-identical, the exit code
 equal.  (The run time line "CPU time: ..." goes to stderr in both.)
-usage: cli_fuzz.py <seconds> <seed>        -> one JSON line"""
+usage: cli_fuzz.py <seconds> <seed> [--gpu]        -> one JSON line   (--gpu: on the GPU box, ssw_test_gpu itself against the prebuilt oracle/_ref/ssw_test_ref)"""
 import json
 import os
 import shutil
@@ -20,11 +20,16 @@ secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 emu_dir = os.path.join(ROOT, "tests", "emu")
-subprocess.run(["make", "-C", emu_dir, "-s", "libssw_emu.so", "ssw_test_emu"], check=True)
-ref_exe = os.path.join(tempfile.gettempdir(), "ssw_test_reference")
-if not os.path.exists(ref_exe):
-    subprocess.run(["gcc", "-O2", "-o", ref_exe, os.path.join(REF_SRC, "main.c"), os.path.join(REF_SRC, "ssw.c"), "-lm", "-lz"], check=True, stderr=subprocess.DEVNULL)
-our_exe = os.path.join(emu_dir, "ssw_test_emu")
+on_gpu = "--gpu" in sys.argv      # GPU box: the product binary ssw_test_gpu against the prebuilt oracle/_ref/ssw_test_ref (oracle/Makefile `refcli`; /root/reference does not exist there)
+if on_gpu:
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "ssw_test_ref")
+    our_exe = os.path.join(ROOT, "complete-striped-smith-waterman-library_amd", "ssw_test_gpu")
+    assert os.path.exists(ref_exe) and os.path.exists(our_exe), "build oracle/_ref/ssw_test_ref (make -C oracle refcli) and ssw_test_gpu first"
+else:
+    subprocess.run(["make", "-C", emu_dir, "-s", "libssw_emu.so", "ssw_test_emu"], check=True)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "refcli"], check=True, stdout=subprocess.DEVNULL)
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "ssw_test_ref")
+    our_exe = os.path.join(emu_dir, "ssw_test_emu")
 DNA, AA = "ACGT", "ARNDCQEGHILKMFPSTWYV"
 
 
@@ -95,11 +100,12 @@ while time.time() < t_end:
     weird = rng.random() < 0.4 and not use_matrix
     if use_matrix: letters = mletters + mletters.lower()
     nt = int(rng.integers(1, 4))
-    targets = [("t%d" % i, seq(letters, int(rng.integers(1, 500)), weird)) for i in range(nt)]
+    long_run = on_gpu and rng.random() < 0.15      # GPU box: now and then targets of some kb and reads of several hundred residues (strip kernel, team traceback)
+    targets = [("t%d" % i, seq(letters, int(rng.integers(1, 500 if not long_run else 6000)), weird)) for i in range(nt)]
     reads = []
     for i in range(int(rng.integers(1, 8))):
         tname, ts = targets[int(rng.integers(0, nt))]
-        L = int(rng.integers(1, 300 if not protein else 200))
+        L = int(rng.integers(1, (300 if not protein else 200) if not long_run else 1500))
         if rng.random() < 0.7 and len(ts) > L:
             o = int(rng.integers(0, len(ts) - L)); s = list(ts[o:o + L])
             for _ in range(int(rng.integers(0, 1 + L // 10))):
@@ -159,5 +165,5 @@ while time.time() < t_end:
             first.append({"args": args, "rc": [a.returncode, b.returncode], "first_differing_line": k, "reference": la[k][:160] if k < len(la) else None, "ours": lb[k][:160] if k < len(lb) else None,
                           "targets": [len(s) for _, s in targets], "reads": [len(s) for _, s in reads], "stderr_ours": b.stderr.decode(errors="replace")[-200:]})
             for fn in (tf, qf) + (("mat.tbl",) if use_matrix else ()): shutil.copy(os.path.join(tmp, fn), os.path.join(tmp, "bad%d_%s" % (wrong, fn)))
-print(json.dumps({"fuzz": "ssw_test_gpu (emulated) vs the reference's ssw_test: stdout bytes and exit code", "seconds": secs, "seed": seed, "runs": runs, "reference_crashed_or_hung": skipped, "runs_with_a_difference": wrong, "kept_inputs_in": tmp if wrong else None, "first": first}))
+print(json.dumps({"fuzz": "ssw_test_gpu (%s) vs the reference's ssw_test: stdout bytes and exit code" % ("on the GPU" if on_gpu else "emulated"), "seconds": secs, "seed": seed, "runs": runs, "reference_crashed_or_hung": skipped, "runs_with_a_difference": wrong, "kept_inputs_in": tmp if wrong else None, "first": first}))
 sys.exit(1 if wrong else 0)
