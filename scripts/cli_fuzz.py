@@ -29,7 +29,7 @@ else:
     subprocess.run(["make", "-C", emu_dir, "-s", "libssw_emu.so", "ssw_test_emu"], check=True)
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "refcli"], check=True, stdout=subprocess.DEVNULL)
     ref_exe = os.path.join(ROOT, "oracle", "_ref", "ssw_test_ref")
-    our_exe = os.path.join(emu_dir, "ssw_test_emu")
+    our_exe = os.environ.get("SSW_CLI_EXE") or os.path.join(emu_dir, "ssw_test_emu")      # (SSW_CLI_EXE: another build of the emulated CLI, e.g. an AddressSanitizer one)
 DNA, AA = "ACGT", "ARNDCQEGHILKMFPSTWYV"
 
 
