@@ -1989,7 +1989,7 @@ plan_again:
 				uint32_t* d_cmB16 = dbl ? (uint32_t*)base_cmB16 : d_cmA16; uint32_t* d_cmB8 = dbl ? (uint32_t*)base_cmB8 : d_cmA8;
 				uint32_t* d_sg16 = P->seg ? (uint32_t*)(base_sg16 + P->sg_off) : 0; uint32_t* d_sg8 = P->seg ? (uint32_t*)(base_sg8 + P->sg_off) : 0;
 				int launch_i = 0;
-				const int pipe = conc ? 0 : P->pipe;      /* the number of parts: 0 (not pipelined), 2..4 */
+				const int pipe = conc ? 0 : P->pipe;      /* the number of parts: 0 (not pipelined), 2 (a hook: up to 8) */
 				void *pe0 = 0, *pe1 = 0;
 				if (pipe) {
 					pe0 = next_event(c); pe1 = next_event(c);

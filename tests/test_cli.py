@@ -30,6 +30,20 @@ def test_cli_stdout_matches_reference_on_emulator(emu_lib_path, name):
     _check(os.path.join(HERE, "emu", "ssw_test_emu"), name)
 
 
+def test_cli_conventional_parser_on_request(emu_lib_path, monkeypatch):
+    """SSW_CLI_ARGS=getopt: options anywhere, attached values ("-f15"), where the reference's scanner (the default, pinned by the scan_* goldens) would
+    take the next argument -- the target file -- as the value: same bytes as the golden of "-c -f 15"."""
+    subprocess.run(["make", "-C", os.path.join(HERE, "emu"), "-s", "ssw_test_emu"], check=True)
+    exe = os.path.join(HERE, "emu", "ssw_test_emu")
+    want = open(os.path.join(CLI_DIR, "config1_f15.stdout")).read()
+    monkeypatch.setenv("SSW_CLI_ARGS", "getopt")
+    r = subprocess.run([exe, "target.fastq", "-f15", "query.fastq", "-c"], cwd=CLI_DIR, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout == want
+    monkeypatch.delenv("SSW_CLI_ARGS")
+    r = subprocess.run([exe, "-c", "-f15", "target.fastq", "query.fastq"], cwd=CLI_DIR, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1 and r.stdout == "" and "Usage" in r.stderr      # the reference's scanner: "-f15" takes "target.fastq" as its value, one file is left: usage, exit code 1 (as the reference)
+
+
 @pytest.mark.parametrize("name,workers", POOLED)
 def test_cli_pooled_stdout_on_emulator(emu_lib_path, name, workers, monkeypatch):
     monkeypatch.setenv("SSW_EMU_DEVICES", "2")
