@@ -62,6 +62,7 @@ typedef struct {
 	int trace_many;         /* SSW_GPU_TRACE_MANY=<n>: a traceback round with more than n pending alignments sizes its teams for throughput (tests: 0); default 4096 */
 	int trace_early;        /* SSW_GPU_TRACE_EARLY=<n>: batches of at least n tracebacks start the teams of the alignments that are wide from the start beside round 0.  Built and measured in
 	                           round 6: SLOWER (config 4's traceback 175 -> 221 ms), off by default (0 / unset: never) -- kept with its tests as the measured form of "overlap the tail" */
+	int trace_w1max, trace_w4max, trace_headroom;      /* SSW_GPU_TRACE_W1MAX / _W4MAX / _HEADROOM: widest doubled band (2b) walked by a one- / four-wavefront team when a round is about latency (96 / 256), scratch granted as a multiple of what the band that did not fit wants (8) */
 	int pipe_any_count;     /* SSW_GPU_PIPE_EVEN=0: a pipelined series may have a number of launches that the streams do not share evenly (the form before this was measured) */
 	int pipe_low_prio;      /* SSW_GPU_PIPE_PRIO=low: the extra streams of a pipelined series at the LOWEST dispatch priority (the first form of round 6; measured slower) */
 	int pipe_parts;         /* SSW_GPU_PIPE_PARTS=2..8: the number of scratch parts / streams of a pipelined series (default 2; more were measured slower) */
@@ -139,6 +140,7 @@ static void knobs_load(ssw_knobs* k)
 	k->db_chain_best = 1;
 	k->trace_wave = -1;
 	k->trace_many = 4096;
+	k->trace_w1max = 96; k->trace_w4max = 256; k->trace_headroom = 8;
 #ifdef SSW_GPU_TEST_HOOKS
 	{ const int v = env_int("SSW_GPU_FRAME_K", 0); k->frame_k = v >= 16 ? v : 0; }
 	k->queue_mode = env_is("SSW_GPU_QUEUE", 'j') ? 1 : env_is("SSW_GPU_QUEUE", 's') ? 2 : 0;
@@ -168,6 +170,9 @@ static void knobs_load(ssw_knobs* k)
 	k->no_pipe = env_is("SSW_GPU_PIPE", '0');
 	k->pipe_low_prio = env_is("SSW_GPU_PIPE_PRIO", 'l');
 	k->pipe_any_count = env_is("SSW_GPU_PIPE_EVEN", '0');
+	{ const int v = env_int("SSW_GPU_TRACE_W1MAX", 0); if (v >= 2 && v <= 254) k->trace_w1max = v; }
+	{ const int v = env_int("SSW_GPU_TRACE_W4MAX", 0); if (v >= 2 && v <= 3070) k->trace_w4max = v; }
+	{ const int v = env_int("SSW_GPU_TRACE_HEADROOM", 0); if (v >= 2 && v <= 64) k->trace_headroom = v; }
 	{ const int v = env_int("SSW_GPU_PIPE_PARTS", 0); k->pipe_parts = v >= 2 && v <= 8 ? v : 0; }
 	k->trace_early = env_int("SSW_GPU_TRACE_EARLY", 0);
 	k->no_tail = env_is("SSW_GPU_NO_TAIL", '1');
@@ -1228,7 +1233,10 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 					                                     dbg_ms(), cnt_row, (long long)sstride, nnext);
 				}
 			} else {
-				/* every pending alignment gets a multiple of what it last needed (one or two more band doublings).  The
+				/* every pending alignment gets a multiple of what it last needed: EIGHT times while that is below 32 MiB (three more band doublings), twice above.  Four
+				   times (two doublings) left ONE of config 4's 10 000 alignments pending after the round of the wide bands, and its team then walked 10^4 rows alone on the
+				   device: a round of 15.7 ms for one alignment (profiles/round6_traceback_rounds.txt: traceback 172.5 -> 157.9 ms; one-/four-wavefront teams for wider bands
+				   than today were measured in the same call and are slower).  The
 				   launches of a round -- one per (LDS size, team size) class, split further by the HBM budget -- work on
 				   different alignments and different scratch: they are issued on separate streams and run side by side
 				   (each is bound by the latency of its longest alignment, not by throughput). */
@@ -1253,13 +1261,13 @@ static int trace_phase(ssw_gpu_ctx* c, const trace_in* ti, trace_out* to)
 						hoff[soff_at] = 0;
 						while (g1 < npend) {
 							const int64_t nb_ = (int64_t)pend[g1].need * 4096;
-							int64_t cap_i = (nb_ * (nb_ < ((int64_t)32 << 20) ? 4 : 2) + 65536 + 15) / 16 * 16;
+							int64_t cap_i = (nb_ * (nb_ < ((int64_t)32 << 20) ? c->kn.trace_headroom : 2) + 65536 + 15) / 16 * 16;
 							if (cap_i > worst) cap_i = worst > nb_ ? worst : nb_;      /* headroom up to the widest band there can be -- but never less than what was asked for */
 							if ((g1 > g0 || ngrp > 0) && batch_total + total + cap_i > budget) break;
 							if (use_wave) {
 								/* a band row of 2b+1 cells is walked in chunks of 64 cells per wavefront: wide bands get 4 or 16 wavefronts */
 								const int32_t b2 = pend[g1].key > (1 << 20) ? (1 << 21) : 2 * pend[g1].key;
-								int wv = b2 <= 96 ? 1 : b2 <= 256 ? 4 : 16;
+								int wv = b2 <= c->kn.trace_w1max ? 1 : b2 <= c->kn.trace_w4max ? 4 : 16;
 								/* ... when the round is about LATENCY (config 4: a few hundred wide bands, a compute unit each).  A round of tens of
 								   thousands of alignments (the survivors of a protein search: ~300 rows, bands of 50 .. 500) is about THROUGHPUT: a
 								   team of 1024 threads on a row of 400 cells leaves 600 of them waiting at two barriers per row, and the device
