@@ -2451,7 +2451,7 @@ static int g_next_device = 0;
    have been destroyed, and a hipFree / hipStreamDestroy from there works on freed memory.  Round 4's hook closed the context right there;
    with 16 caller threads ending together that corrupted the heap now and then (a crash at process exit, found with the round-5 latency
    harness).  Parked contexts are reused by the next new caller thread; more than SSW_PARK_MAX of them are closed by the next LIVE thread that
-   comes through implicit_get, and ssw_gpu_release_parked() closes all of them (round-5 advisor: after a burst of N caller threads the process
+   comes through implicit_get (new or not), and ssw_gpu_release_parked() closes all of them (round-5 advisor: after a burst of N caller threads the process
    kept N contexts' HBM until exit).  What is still parked at process exit goes with the process. */
 #define SSW_PARK_MAX 4
 static pthread_mutex_t g_park_mu = PTHREAD_MUTEX_INITIALIZER;
@@ -2504,7 +2504,10 @@ static implicit_ctx* implicit_get(void)
 {
 	pthread_once(&g_ictx_once, implicit_key_init);
 	implicit_ctx* ic = (implicit_ctx*)pthread_getspecific(g_ictx_key);
-	if (ic) return ic;
+	if (ic) {      /* (any live caller applies the cap, not only a new thread: a burst of short-lived threads may park its contexts after the last new thread came by) */
+		if (__atomic_load_n(&g_nparked, __ATOMIC_RELAXED) > SSW_PARK_MAX) parked_trim(SSW_PARK_MAX);
+		return ic;
+	}
 	pthread_mutex_lock(&g_park_mu);      /* a context parked by a caller thread that ended: taken over as it is (its device, its buffers, its resident target) */
 	ic = g_parked;
 	if (ic) { g_parked = ic->next; --g_nparked; }

@@ -673,7 +673,8 @@ def test_parked_single_pair_contexts_are_released(emu_lib_path):
     assert scores == [120] * 12
     # Thread.join() returns when the Python function has ended -- the OS thread may still be on its way out, and it is its thread-specific destructor that
     # parks the context: a burst can find the list empty and open new contexts (seen under load: five parked at the end).  The cap is applied by the next LIVE
-    # caller (a dying thread may not call into the runtime): give the threads time to end, make one more call from this thread, then count.
+    # caller, whether it already has a context of its own (this thread, after earlier tests of the process) or not -- a dying thread may not call into the
+    # runtime: give the threads time to end, make one more call from this thread, then count.
     import time
     time.sleep(0.5)
     worker()
